@@ -1,0 +1,142 @@
+"""ORACLE-SIDE PROTOTYPE (test infrastructure) of the algorithm the HIP QP kernel runs.
+
+This is a numpy transliteration of `nrmp_qp_kernel` (neupan_amd/csrc/nrmp_qp.hip): the
+NRMP problem (reference: neupan/blocks/nrmp.py:263-383, neupan/robot/robot.py:142-236)
+condensed onto x = (u, d) by eliminating the states through the linearised dynamics, with
+the squared-hinge rows handled through their own stationarity condition e = lam_f / ro_obs
+(so no epigraph variables are carried), solved by a Mehrotra predictor-corrector.
+
+It exists so that tests can (1) compare the condensed algorithm with the uncondensed
+oracle (oracle/nrmp_qp.py) on the CPU, where failures are easy to debug, and (2) compare
+the GPU kernel with the same algorithm iteration by iteration.  It is NOT on any product
+path: only tests/ import it.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .nrmp_qp import NrmpProblem
+
+
+def condense(pb: NrmpProblem):
+    """Return H (n,n), g (n), F (mf,n), f (mf), Crows (mc,n), c (mc), Phi, cvec with
+    x = [u_0x,u_0y,...,u_{T-1}y, d_0..d_{T-1}], n = 3T (2T when no_obs)."""
+    T, M = pb.T, pb.M
+    nu = 2 * T
+    n = nu + (0 if pb.no_obs else T)
+    Phi = np.zeros((T + 1, 3, nu))
+    cv = np.zeros((T + 1, 3))
+    cv[0] = pb.nom_s[:, 0]
+    for t in range(T):
+        Phi[t + 1] = pb.A[t] @ Phi[t]
+        Phi[t + 1][:, 2 * t:2 * t + 2] += pb.B[t]
+        cv[t + 1] = pb.A[t] @ cv[t] + pb.C[t]
+    mask = pb.state_weight()
+    Ws = 2.0 * mask * pb.q_s ** 2 + pb.bk            # d2/ds2 of state + proximal cost
+    H = np.zeros((n, n))
+    g = np.zeros(n)
+    for t in range(1, T + 1):
+        H[:nu, :nu] += Phi[t].T @ (Ws[:, None] * Phi[t])
+        lin = 2.0 * mask * pb.q_s * (pb.q_s * cv[t] - pb.qref_s[:, t]) + pb.bk * (cv[t] - pb.nom_s[:, t])
+        g[:nu] += Phi[t].T @ lin
+    for t in range(T):
+        H[2 * t, 2 * t] += 2.0 * pb.p_u ** 2
+        g[2 * t] += -2.0 * pb.p_u * pb.puref[t]
+    F = np.zeros((0, n)); f = np.zeros(0)
+    if not pb.no_obs:
+        g[nu:] = -pb.eta
+        F = np.zeros((T * M, n)); f = np.zeros(T * M)
+        for t in range(T):
+            for j in range(M):
+                F[t * M + j, :nu] = pb.fa[t, j] @ Phi[t + 1][0:2]
+                F[t * M + j, nu + t] = -1.0
+                f[t * M + j] = pb.fb[t, j] - pb.fa[t, j] @ cv[t + 1][0:2]
+    rows, rhs = [], []
+
+    def add(coeffs, bound):
+        if not np.isfinite(bound):
+            return
+        r = np.zeros(n)
+        for i, v in coeffs:
+            r[i] = v
+        rows.append(r); rhs.append(bound)
+    for t in range(T):
+        for k in range(2):
+            add([(2 * t + k, 1.0)], pb.speed_bound[k]); add([(2 * t + k, -1.0)], pb.speed_bound[k])
+    for t in range(T - 1):
+        for k in range(2):
+            add([(2 * t + 2 + k, 1.0), (2 * t + k, -1.0)], pb.acce_bound[k])
+            add([(2 * t + 2 + k, -1.0), (2 * t + k, 1.0)], pb.acce_bound[k])
+    if not pb.no_obs:
+        for t in range(T):
+            add([(nu + t, 1.0)], pb.d_max); add([(nu + t, -1.0)], -max(pb.d_min, 0.0))
+    C = np.array(rows) if rows else np.zeros((0, n)); c = np.array(rhs) if rhs else np.zeros(0)
+    return H, g, F, f, C, c, Phi, cv
+
+
+def solve_condensed(pb: NrmpProblem, tol=1e-12, max_iter=40, trace=None):
+    H, g, F, f, C, c, Phi, cv = condense(pb)
+    n = H.shape[0]; T = pb.T; nu = 2 * T
+    ro = pb.ro_obs
+    mc, mf = C.shape[0], F.shape[0]
+    m = mc + mf
+    # start: u inside its box (nominal controls clipped), d mid-range
+    x = np.zeros(n)
+    if not pb.no_obs:
+        x[nu:] = 0.5 * (max(pb.d_min, 0.0) + pb.d_max)
+    lc = np.ones(mc); wc = np.maximum(c - C @ x, 1.0)
+    lf = np.ones(mf); wf = np.maximum(F @ x - f + lf / ro, 1.0)
+    scale_d = 1.0 + np.abs(g).max()
+    scale_p = 1.0 + (np.abs(c).max() if mc else 0.0)
+    best = (np.inf, x.copy(), 0)
+    stall = 0
+    for it in range(max_iter + 1):
+        r1 = H @ x + g + C.T @ lc - F.T @ lf
+        r2 = C @ x + wc - c
+        r3 = F @ x - f + lf / ro - wf
+        mu = (lc @ wc + lf @ wf) / max(m, 1)
+        merit = max(np.abs(r1).max() / scale_d, (np.abs(r2).max() if mc else 0.0) / scale_p,
+                    (np.abs(r3).max() if mf else 0.0) / scale_p, mu)
+        if trace is not None:
+            trace.append(dict(it=it, merit=merit, mu=mu, x=x.copy()))
+        if not np.isfinite(merit):
+            break
+        if merit < best[0]:
+            best = (merit, x.copy(), it); stall = 0
+        else:
+            stall += 1
+        if merit <= tol or stall >= 3 or it == max_iter or mu < 1e-15:
+            break
+        Dc = lc / wc
+        Df = lf / (wf + lf / ro)
+        K = H + C.T @ (Dc[:, None] * C) + F.T @ (Df[:, None] * F)
+        try:
+            L = np.linalg.cholesky(K)
+        except np.linalg.LinAlgError:      # gap closed past fp64 resolution: keep the best iterate
+            break
+
+        def solve(r4c, r4f):
+            rhs = -r1 - C.T @ ((lc * r2 - r4c) / wc) - F.T @ ((r4f + lf * r3) / (wf + lf / ro))
+            dx = np.linalg.solve(L.T, np.linalg.solve(L, rhs))
+            dwc = -r2 - C @ dx
+            dlc = (-r4c - lc * dwc) / wc
+            dlf = -(r4f + lf * r3 + lf * (F @ dx)) / (wf + lf / ro)
+            dwf = F @ dx + dlf / ro + r3
+            return dx, dwc, dlc, dwf, dlf
+
+        def max_step(v, dv):
+            neg = dv < 0
+            return 1.0 if not neg.any() else min(1.0, float(np.min(-v[neg] / dv[neg])))
+
+        dx, dwc, dlc, dwf, dlf = solve(lc * wc, lf * wf)
+        a_aff = min(max_step(wc, dwc), max_step(lc, dlc), max_step(wf, dwf), max_step(lf, dlf))
+        mu_aff = ((lc + a_aff * dlc) @ (wc + a_aff * dwc) + (lf + a_aff * dlf) @ (wf + a_aff * dwf)) / max(m, 1)
+        sigma = (mu_aff / mu) ** 3
+        dx, dwc, dlc, dwf, dlf = solve(lc * wc + dwc * dlc - sigma * mu, lf * wf + dwf * dlf - sigma * mu)
+        a = min(1.0, 0.995 * min(max_step(wc, dwc), max_step(lc, dlc), max_step(wf, dwf), max_step(lf, dlf)))
+        x = x + a * dx; wc = wc + a * dwc; lc = lc + a * dlc; wf = wf + a * dwf; lf = lf + a * dlf
+    merit, x, it_used = best
+    u = x[:nu].reshape(T, 2).T.copy()
+    s = np.stack([Phi[t] @ x[:nu] + cv[t] for t in range(T + 1)], axis=1)
+    d = None if pb.no_obs else x[nu:].reshape(1, T).copy()
+    return s, u, d, {"iters": it_used, "merit": merit}

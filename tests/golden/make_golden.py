@@ -1,0 +1,281 @@
+"""Generate tests/golden/*.npz from the UNMODIFIED reference code (build container only).
+
+    python tests/golden/make_golden.py
+
+What comes from where
+---------------------
+* geometry.npz         G,h from the reference's `robot` class (robot.py:30-71).
+* stage_<case>.npz     outputs of the reference's own generate_point_flow (pan.py:150),
+                       DUNE.forward (dune.py:58), generate_coefficient_parameter_value
+                       (nrmp.py:220) and generate_state_parameter_value (robot.py:239),
+                       executed unmodified under the inert stubs of ref_stub_loader.py.
+* pan_<case>.npz       the reference's PAN.forward (pan.py:109) executed unmodified EXCEPT
+                       that `nrmp_layer.nrmp_layer` (the CvxpyLayer, nrmp.py:144/286) is
+                       replaced by `OracleLayer` below, because cvxpylayers/ECOS are not
+                       installed: "reference code with substituted solver".
+* qp_cases.npz         NRMP problems + solutions by oracle/nrmp_qp.py, cross-checked here
+                       against HiGHS' QP solver (third party, bundled in scipy) on the same
+                       uncondensed problem.
+
+If cvxpy+cvxpylayers+diffcp+ecos ever import, `real_solver_stack_available()` is True, the
+stubs are not installed and pan_<case>.npz holds the true reference output (field
+`solver` says which).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+from ref_stub_loader import import_reference, real_solver_stack_available  # noqa: E402
+
+ref = import_reference()
+from neupan.blocks import PAN  # noqa: E402  (reference)
+from neupan.robot import robot as RefRobot  # noqa: E402
+
+from neupan_amd.scenes import CONFIGS, make_scene  # noqa: E402
+from oracle.nrmp_qp import NrmpProblem, _assemble_full, kkt_certificate, solve_nrmp_qp  # noqa: E402
+
+CKPT = {k: os.path.join(HERE, "checkpoints", f"{k}_model_5000.pth")
+        for k in ("diff_robot_default", "acker_robot_default", "polygon_robot")}
+REAL = real_solver_stack_available()
+
+
+class OracleLayer:
+    """Stands in for `CvxpyLayer.__call__` (nrmp.py:144): same 58-tensor argument list
+    (nrmp.py:152-166), same return convention (double tensors s, u, d)."""
+
+    def __init__(self, nrmp):
+        self.nrmp = nrmp
+        self.problems = []
+
+    def __call__(self, *params, solver_args=None):
+        n = self.nrmp
+        T = n.T
+        p = [x.detach().double().numpy() for x in params]
+        nom_s, qref, puref = p[0], p[1], p[2]
+        A = np.stack(p[3:3 + T]); B = np.stack(p[3 + T:3 + 2 * T]); C = np.stack(p[3 + 2 * T:3 + 3 * T])
+        k = 3 + 3 * T
+        if n.no_obs:
+            fa = fb = None
+            q_s, p_u = p[k], p[k + 1]
+            eta = d_max = d_min = 0.0
+        else:
+            fa = np.stack(p[k:k + T]); fb = np.stack(p[k + T:k + 2 * T])
+            q_s, p_u, eta, d_max, d_min = p[k + 2 * T:k + 2 * T + 5]
+        r = n.robot
+        pb = NrmpProblem(nom_s, qref, puref, A, B, C, fa, fb, q_s, p_u, eta, d_max, d_min,
+                         n.ro_obs, n.bk, r.speed_bound, r.acce_bound, r.kinematics)
+        self.problems.append(pb)
+        s, u, d = solve_nrmp_qp(pb)
+        out = [torch.from_numpy(s), torch.from_numpy(u)]
+        if d is not None:
+            out.append(torch.from_numpy(d))
+        return out
+
+
+def build_pan(cfg, **over):
+    kw = dict(receding=cfg.T, step_time=cfg.dt, iter_num=cfg.iter_num, dune_max_num=cfg.n_points,
+              nrmp_max_num=cfg.nrmp_max_num, dune_checkpoint=CKPT[cfg.checkpoint],
+              iter_threshold=0.0, adjust_kwargs=dict(cfg.adjust))
+    robot_kw = dict(cfg.robot)
+    robot_kw.update(over.pop("robot", {}))
+    kw.update(over)
+    rb = RefRobot(kw["receding"], kw["step_time"], **robot_kw)
+    pan = PAN(robot=rb, **kw)
+    if not REAL:
+        pan.nrmp_layer.nrmp_layer = OracleLayer(pan.nrmp_layer)
+    return pan, rb
+
+
+def t(a):
+    return None if a is None else torch.from_numpy(np.asarray(a))
+
+
+def stack(lst):
+    return np.stack([x.detach().numpy() for x in lst])
+
+
+def stage_case(name, cfg, scene_idx, n_points, **over):
+    pan, rb = build_pan(cfg, **over)
+    sc = make_scene(cfg, scene_idx, n_points)
+    nom_s, nom_u = t(sc["nom_s"]), t(sc["nom_u"])
+    pts, vel = t(sc["points"]), t(sc["velocities"])
+    flow, Rl, pl = pan.generate_point_flow(nom_s, pts, vel)
+    mu_l, lam_l, sp_l = pan.dune_layer(flow, Rl, pl)
+    fafb = pan.nrmp_layer.generate_coefficient_parameter_value(mu_l, lam_l, sp_l)
+    T = pan.T
+    st = rb.generate_state_parameter_value(nom_s, nom_u, t(sc["ref_s"]), t(sc["ref_us"]))
+    out = dict(nom_s=sc["nom_s"], nom_u=sc["nom_u"], points=sc["points"],
+               velocities=np.zeros((2, 0), np.float32) if sc["velocities"] is None else sc["velocities"],
+               has_vel=np.array(sc["velocities"] is not None),
+               flow=stack(flow), R=stack(Rl), pts_t=stack(pl),
+               mu=stack(mu_l), lam=stack(lam_l), sorted_pts=stack(sp_l),
+               min_distance=np.float32(pan.min_distance),
+               fa=stack(fafb[:T]), fb=stack(fafb[T:]),
+               A=stack(st[3:3 + T]), B=stack(st[3 + T:3 + 2 * T]), C=stack(st[3 + 2 * T:3 + 3 * T]),
+               G=rb.G, h=rb.h, dune_max_num=np.array(pan.dune_max_num), nrmp_max_num=np.array(pan.nrmp_max_num))
+    np.savez_compressed(os.path.join(HERE, f"stage_{name}.npz"), **out)
+    print("stage", name, {k: getattr(v, "shape", None) for k, v in out.items() if k in ("mu", "fa", "flow")})
+
+
+def pan_case(name, cfg, scene_idx, n_points, calls=1, **over):
+    """`calls` consecutive PAN.forward calls on the same planner (the stop criterion keeps
+    state across calls, pan.py:100-105,241); call c uses scene scene_idx+c warm-started with
+    the previous optimal controls the way neupan.forward does (neupan.py:118-137)."""
+    pan, rb = build_pan(cfg, **over)
+    out = dict(calls=np.array(calls), solver=np.array("reference" if REAL else "substituted-oracle"))
+    prev_u = None
+    for c in range(calls):
+        sc = make_scene(cfg, scene_idx + c, n_points)
+        if prev_u is not None:
+            sc["nom_u"] = prev_u
+        pts = None if n_points == 0 else t(sc["points"])
+        iters_before = len(pan.nrmp_layer.nrmp_layer.problems) if not REAL else 0
+        s, u, d = pan(t(sc["nom_s"]), t(sc["nom_u"]), t(sc["ref_s"]), t(sc["ref_us"]), pts, t(sc["velocities"]))
+        iters = (len(pan.nrmp_layer.nrmp_layer.problems) - iters_before) if not REAL else -1
+        prev_u = u.detach().numpy().copy()
+        for k, v in sc.items():
+            if v is not None:
+                out[f"c{c}_{k}"] = v
+        out[f"c{c}_has_vel"] = np.array(sc["velocities"] is not None)
+        out[f"c{c}_opt_s"] = s.detach().numpy(); out[f"c{c}_opt_u"] = u.detach().numpy()
+        out[f"c{c}_opt_d"] = np.zeros((1, 0), np.float32) if d is None else d.detach().numpy()
+        out[f"c{c}_iters"] = np.array(iters)
+        md = pan.min_distance
+        out[f"c{c}_min_distance"] = np.float32(float(md))
+        if pan.nrmp_points is not None and n_points:
+            out[f"c{c}_nrmp_points"] = pan.nrmp_points
+    np.savez_compressed(os.path.join(HERE, f"pan_{name}.npz"), **out)
+    print("pan", name, "iters", [int(out[f"c{c}_iters"]) for c in range(calls)])
+    return pan
+
+
+def highs_solve(P, q, A, b, G, h):
+    """Solve min 1/2 z'Pz+q'z, Az=b, Gz<=h with HiGHS (scipy's bundled highspy core)."""
+    from scipy.optimize._highspy import _core as hc
+    from scipy.sparse import csc_matrix, tril
+    n = P.shape[0]
+    rows = np.vstack([A, G])
+    lo = np.concatenate([b, np.full(G.shape[0], -hc.kHighsInf)])
+    hi = np.concatenate([b, h])
+    H = hc._Highs()
+    H.setOptionValue("output_flag", False)
+    for opt, val in (("primal_feasibility_tolerance", 1e-10), ("dual_feasibility_tolerance", 1e-10)):
+        H.setOptionValue(opt, val)
+    lp = hc.HighsLp()
+    lp.num_col_, lp.num_row_ = n, rows.shape[0]
+    lp.col_cost_ = q
+    lp.col_lower_ = np.full(n, -hc.kHighsInf); lp.col_upper_ = np.full(n, hc.kHighsInf)
+    lp.row_lower_, lp.row_upper_ = lo, hi
+    Am = csc_matrix(rows)
+    lp.a_matrix_.format_ = hc.MatrixFormat.kColwise
+    lp.a_matrix_.num_col_, lp.a_matrix_.num_row_ = n, rows.shape[0]
+    lp.a_matrix_.start_, lp.a_matrix_.index_, lp.a_matrix_.value_ = Am.indptr, Am.indices, Am.data
+    hess = hc.HighsHessian()
+    Pl = csc_matrix(tril(csc_matrix(P)))
+    hess.dim_ = n
+    hess.format_ = hc.HessianFormat.kTriangular
+    hess.start_, hess.index_, hess.value_ = Pl.indptr, Pl.indices, Pl.data
+    model = hc.HighsModel()
+    model.lp_ = lp
+    model.hessian_ = hess
+    H.passModel(model)
+    H.run()
+    status = H.modelStatusToString(H.getModelStatus())
+    return np.array(H.getSolution().col_value), status
+
+
+def qp_cases(problems):
+    out = {}
+    keep = []
+    for i, pb in enumerate(problems):
+        s, u, d, info = solve_nrmp_qp(pb, return_info=True)
+        cert = kkt_certificate(pb, s, u, d)
+        P, q, A, b, G, h, (ns, nu, nd, ne) = _assemble_full(pb)
+        # tiny regularisation-free HiGHS solve; its active-set QP needs P PSD (it is)
+        try:
+            z, status = highs_solve(P, q, A, b, G, h)
+            uh = z[ns:ns + nu].reshape(pb.T, 2).T
+            dh = z[ns + nu:ns + nu + nd].reshape(1, -1)
+            sh = z[:ns].reshape(pb.T + 1, 3).T
+            obj_h = pb.objective(sh, uh, dh.reshape(-1) if nd else None)
+        except Exception as e:  # pragma: no cover
+            print("HiGHS failed on", i, e)
+            continue
+        obj_o = pb.objective(s, u, None if d is None else d.reshape(-1))
+        print(f"qp {i}: ipm iters {info['iters']} merit {info['merit']:.1e} cert stat {cert['stat']:.1e} "
+              f"| HiGHS {status} |u-u_h| {np.abs(u - uh).max():.2e} obj diff {obj_o - obj_h:+.2e}")
+        pre = f"q{len(keep)}_"
+        for k in ("nom_s", "qref_s", "puref", "A", "B", "C", "fa", "fb", "q_s", "speed_bound", "acce_bound"):
+            v = getattr(pb, k)
+            out[pre + k] = np.zeros(0) if v is None else v
+        out[pre + "scalars"] = np.array([pb.p_u, pb.eta, pb.d_max, pb.d_min, pb.ro_obs, pb.bk])
+        out[pre + "kin"] = np.array(pb.kinematics)
+        out[pre + "s"], out[pre + "u"] = s, u
+        out[pre + "d"] = np.zeros((1, 0)) if d is None else d
+        out[pre + "u_highs"], out[pre + "obj_highs"], out[pre + "obj_oracle"] = uh, obj_h, obj_o
+        keep.append(i)
+    out["count"] = np.array(len(keep))
+    np.savez_compressed(os.path.join(HERE, "qp_cases.npz"), **out)
+
+
+def main():
+    # ---- geometry -------------------------------------------------------------------
+    geo = {}
+    for name, kw in (("diff", CONFIGS["diff_1k_T10_K10"].robot), ("acker", CONFIGS["acker_2k_T20_K15"].robot),
+                     ("polygon", dict(kinematics="diff", vertices=[[-0.8, -1.0], [-1.8, 1.0], [1.8, 1.0], [0.8, -1.0]],
+                                      max_speed=[8, 3], max_acce=[8, 3]))):
+        rb = RefRobot(10, 0.1, **kw)
+        geo[name + "_G"], geo[name + "_h"] = rb.G, rb.h
+        geo[name + "_speed_bound"], geo[name + "_acce_bound"] = np.asarray(rb.speed_bound, float), np.asarray(rb.acce_bound, float)
+    np.savez(os.path.join(HERE, "geometry.npz"), **geo)
+
+    c2 = CONFIGS["diff_1k_T10_K10"]; dy = CONFIGS["dyna_4k_T10_K10"]; ak = CONFIGS["acker_2k_T20_K15"]
+    poly_robot = dict(kinematics="diff", vertices=[[-0.8, -1.0], [-1.8, 1.0], [1.8, 1.0], [0.8, -1.0]],
+                      max_speed=[8, 3], max_acce=[8, 3], length=None, width=None)
+    omni_robot = dict(kinematics="omni", length=1.6, width=2.0, max_speed=[8, 6.28], max_acce=[3, 3])
+
+    # ---- per-stage vectors from unmodified reference code -----------------------------
+    stage_case("diff_n1000", c2, 0, 1000)
+    stage_case("dyna_n300", dy, 5, 300, dune_max_num=300)
+    stage_case("acker_n200", ak, 1, 200, dune_max_num=200, receding=20)
+    stage_case("diff_n7", c2, 2, 7)
+    stage_case("diff_n1", c2, 3, 1)
+    stage_case("decimate_1000_to_100", c2, 4, 1000, dune_max_num=100)
+    stage_case("polygon_n150", c2, 6, 150, robot=poly_robot, dune_checkpoint=CKPT["polygon_robot"])
+    stage_case("omni_n64", c2, 7, 64, robot=omni_robot)
+
+    # ---- PAN.forward through the reference's control flow -----------------------------
+    pans = []
+    pans.append(pan_case("diff_n1000_k3", c2, 0, 1000, iter_num=3))
+    pans.append(pan_case("diff_n200_k10", c2, 8, 200, iter_num=10))
+    pans.append(pan_case("dyna_n300_k4", dy, 5, 300, iter_num=4, dune_max_num=300))
+    pans.append(pan_case("acker_n200_k4", ak, 1, 200, iter_num=4, dune_max_num=200))
+    pans.append(pan_case("diff_n7_k3", c2, 2, 7, iter_num=3))
+    pans.append(pan_case("omni_n64_k3", c2, 7, 64, iter_num=3, robot=omni_robot))
+    pans.append(pan_case("polygon_n150_k3", c2, 6, 150, iter_num=3, robot=poly_robot,
+                         dune_checkpoint=CKPT["polygon_robot"]))
+    pans.append(pan_case("nopoints_k3", c2, 9, 0, iter_num=3))
+    pans.append(pan_case("noobs_m0_k3", c2, 10, 50, iter_num=3, nrmp_max_num=0))
+    # reference defaults: iter_num=2.., early exit with the default threshold, 3 chained calls
+    pans.append(pan_case("default_thr_3calls", c2, 11, 100, calls=3, iter_num=6, iter_threshold=0.1, dune_max_num=100))
+    pans.append(pan_case("qs_vector_k2", c2, 12, 100, iter_num=2,
+                         adjust_kwargs=dict(c2.adjust, q_s=[1.0, 0.8, 0.3])))
+
+    # ---- QP problems + HiGHS cross-check ----------------------------------------------
+    if not REAL:
+        probs = []
+        for p in pans:
+            ps = p.nrmp_layer.nrmp_layer.problems
+            probs += ps[:2] + ps[-1:]
+        qp_cases(probs)
+
+
+if __name__ == "__main__":
+    main()

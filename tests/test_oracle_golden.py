@@ -1,0 +1,166 @@
+"""CPU tests: the oracle restatement vs vectors produced by the UNMODIFIED reference code
+(tests/golden/make_golden.py) and vs the reference's own fixtures (results.txt G/h)."""
+import numpy as np
+import pytest
+
+from helpers import CONFIGS, golden, make_oracle, robot_numbers
+from oracle import pan_oracle as po
+from oracle.condensed_ipm import solve_condensed
+from oracle.nrmp_qp import NrmpProblem, kkt_certificate, solve_nrmp_qp
+
+POLY = dict(kinematics="diff", vertices=[[-0.8, -1.0], [-1.8, 1.0], [1.8, 1.0], [0.8, -1.0]],
+            max_speed=[8, 3], max_acce=[8, 3])
+OMNI = dict(kinematics="omni", length=1.6, width=2.0, max_speed=[8, 6.28], max_acce=[3, 3])
+
+
+def test_geometry_matches_reference_results_txt():
+    # reference fixtures: example/model/diff_robot_default/results.txt:1-8,
+    # example/model/acker_robot_default/results.txt:1-8, example/model/polygon_robot/results.txt:1-8
+    expect = {
+        "diff": ([[0, -1.6], [2, 0], [0, 1.6], [-2, 0]], [1.6, 1.6, 1.6, 1.6], CONFIGS["diff_1k_T10_K10"].robot),
+        "acker": ([[0, -4.6], [1.6, 0], [0, 4.6], [-1.6, 0]], [3.68, 6.08, 3.68, 1.28], CONFIGS["acker_2k_T20_K15"].robot),
+        "polygon": ([[0, -1.6], [2, -1], [0, 3.6], [-2, -1]], [1.6, 2.6, 3.6, 2.6], POLY),
+    }
+    geo = golden("geometry")
+    for name, (G, h, kw) in expect.items():
+        Go, ho, sp, ac, _ = robot_numbers(kw, 0.1)
+        np.testing.assert_allclose(Go, np.array(G, float), atol=1e-12)
+        np.testing.assert_allclose(ho.reshape(-1), np.array(h, float), atol=1e-12)
+        np.testing.assert_array_equal(Go, geo[name + "_G"])          # vs the reference's robot class
+        np.testing.assert_array_equal(ho, geo[name + "_h"])
+        np.testing.assert_allclose(sp, geo[name + "_speed_bound"].reshape(-1))
+        np.testing.assert_allclose(ac, geo[name + "_acce_bound"].reshape(-1))
+
+
+def test_downsample_decimation_indices():
+    m = np.arange(2000, dtype=np.float32).reshape(2, 1000)
+    out = po.downsample_decimation(m, 100)
+    assert out.shape == (2, 100) and out[0, 0] == 0 and out[0, 1] == 10 and out[0, -1] == 999
+    assert out[0, 98] == 988 and out[0, 97] == 978       # truncation, SURVEY 8a-2
+    assert po.downsample_decimation(m, 1000) is m
+
+
+STAGES = [("diff_n1000", "diff_1k_T10_K10", None, None), ("dyna_n300", "dyna_4k_T10_K10", None, None),
+          ("acker_n200", "acker_2k_T20_K15", None, None), ("diff_n7", "diff_1k_T10_K10", None, None),
+          ("diff_n1", "diff_1k_T10_K10", None, None), ("decimate_1000_to_100", "diff_1k_T10_K10", None, None),
+          ("polygon_n150", "diff_1k_T10_K10", POLY, "polygon_robot"), ("omni_n64", "diff_1k_T10_K10", OMNI, None)]
+
+
+@pytest.mark.parametrize("case,cfgname,robot_kw,ck", STAGES)
+def test_stage_functions_match_reference(case, cfgname, robot_kw, ck):
+    g = golden("stage_" + case)
+    cfg = CONFIGS[cfgname]
+    rk = dict(cfg.robot if robot_kw is None else robot_kw)
+    from helpers import ckpt_path
+    w = po.ObsPointNetWeights.from_checkpoint(ckpt_path(ck or cfg.checkpoint))
+    G, h = g["G"], g["h"]
+    T = g["flow"].shape[0] - 1
+    vel = g["velocities"] if bool(g["has_vel"]) else None
+    flow, Rl, pl = po.generate_point_flow(g["nom_s"], g["points"], vel, T, cfg.dt, int(g["dune_max_num"]))
+    np.testing.assert_allclose(np.stack(flow), g["flow"], atol=2e-6)
+    np.testing.assert_allclose(np.stack(Rl), g["R"], atol=1e-7)
+    np.testing.assert_array_equal(np.stack(pl), g["pts_t"])
+    mu_l, lam_l, pt_l, mind = po.dune_forward(w, G, h, flow, Rl, pl)
+    M = int(g["nrmp_max_num"])
+    # the first M sorted columns are what the planner consumes (nrmp.py:254-255)
+    k = min(M, g["mu"].shape[2])
+    np.testing.assert_allclose(np.stack(mu_l)[:, :, :k], g["mu"][:, :, :k], atol=2e-5)
+    np.testing.assert_allclose(np.stack(lam_l)[:, :, :k], g["lam"][:, :, :k], atol=5e-5)
+    np.testing.assert_allclose(np.stack(pt_l)[:, :, :k], g["sorted_pts"][:, :, :k], atol=1e-6)
+    assert abs(float(mind) - float(g["min_distance"])) < 2e-5
+    fa, fb = po.generate_coefficient_parameter_value(mu_l, lam_l, pt_l, h, T, M)
+    np.testing.assert_allclose(fa, g["fa"], atol=5e-5)
+    np.testing.assert_allclose(fb.reshape(T, M, 1), g["fb"], atol=2e-4)
+    A, B, C = po.generate_state_parameter_value(g["nom_s"], g["nom_u"], T, cfg.dt, rk["kinematics"], rk.get("wheelbase"))
+    np.testing.assert_array_equal(A, g["A"])            # bit-exact: same fp32 rounding sequence
+    np.testing.assert_array_equal(B, g["B"])
+    np.testing.assert_array_equal(C.reshape(T, 3, 1), g["C"])
+
+
+def test_obs_point_net_matches_torch_module():
+    import torch
+    from helpers import ckpt_path
+    w = po.ObsPointNetWeights.from_checkpoint(ckpt_path("diff_robot_default"))
+    net = torch.nn.Sequential(
+        torch.nn.Linear(2, 32), torch.nn.LayerNorm(32), torch.nn.Tanh(), torch.nn.Linear(32, 32), torch.nn.ReLU(),
+        torch.nn.Linear(32, 32), torch.nn.LayerNorm(32), torch.nn.Tanh(), torch.nn.Linear(32, 32), torch.nn.ReLU(),
+        torch.nn.Linear(32, 32), torch.nn.LayerNorm(32), torch.nn.Tanh(), torch.nn.Linear(32, 4), torch.nn.ReLU())
+    sd = torch.load(ckpt_path("diff_robot_default"), map_location="cpu")
+    assert len(sd) == 18 and sum(v.numel() for v in sd.values()) == 4644
+    net.load_state_dict({k.replace("MLP.", ""): v for k, v in sd.items()})
+    x = (np.random.default_rng(0).uniform(-25, 25, (4096, 2))).astype(np.float32)
+    with torch.no_grad():
+        ref = net(torch.from_numpy(x)).numpy()
+    np.testing.assert_allclose(po.obs_point_net(w, x), ref, atol=2e-5)
+
+
+PANS = [("diff_n1000_k3", "diff_1k_T10_K10", dict(iter_num=3)),
+        ("diff_n200_k10", "diff_1k_T10_K10", dict(iter_num=10, dune_max_num=200)),
+        ("dyna_n300_k4", "dyna_4k_T10_K10", dict(iter_num=4, dune_max_num=300)),
+        ("acker_n200_k4", "acker_2k_T20_K15", dict(iter_num=4, dune_max_num=200)),
+        ("diff_n7_k3", "diff_1k_T10_K10", dict(iter_num=3)),
+        ("omni_n64_k3", "diff_1k_T10_K10", dict(iter_num=3, robot_kw=OMNI)),
+        ("polygon_n150_k3", "diff_1k_T10_K10", dict(iter_num=3, robot_kw=POLY, checkpoint="polygon_robot")),
+        ("nopoints_k3", "diff_1k_T10_K10", dict(iter_num=3)),
+        ("noobs_m0_k3", "diff_1k_T10_K10", dict(iter_num=3, nrmp_max_num=0)),
+        ("default_thr_3calls", "diff_1k_T10_K10", dict(iter_num=6, iter_threshold=0.1, dune_max_num=100)),
+        ("qs_vector_k2", "diff_1k_T10_K10", dict(iter_num=2, adjust=dict(q_s=[1.0, 0.8, 0.3])))]
+
+
+@pytest.mark.parametrize("case,cfgname,over", PANS)
+def test_pan_forward_matches_reference_control_flow(case, cfgname, over):
+    """The reference's PAN.forward (with the oracle QP substituted for CvxpyLayer) vs the
+    pure-oracle loop: checks the loop, the parameter plumbing, the warm start, the stop
+    criterion and its cross-call state.  Tolerance 2e-4: both sides run the same QP solver
+    but the MLP runs through torch-CPU on one side and numpy on the other."""
+    from helpers import ckpt_path
+    g = golden("pan_" + case)
+    over = dict(over)
+    ck = over.pop("checkpoint", None)
+    o = make_oracle(CONFIGS[cfgname], robot_kw=over.pop("robot_kw", None),
+                    checkpoint=ckpt_path(ck) if ck else None, **over)
+    for c in range(int(g["calls"])):
+        pts = g[f"c{c}_points"] if f"c{c}_points" in g.files and case != "nopoints_k3" else None
+        vel = g[f"c{c}_velocities"] if bool(g[f"c{c}_has_vel"]) else None
+        s, u, d = o.forward(g[f"c{c}_nom_s"], g[f"c{c}_nom_u"], g[f"c{c}_ref_s"], g[f"c{c}_ref_us"], pts, vel)
+        assert o.iters_run == int(g[f"c{c}_iters"])
+        np.testing.assert_allclose(u, g[f"c{c}_opt_u"], atol=2e-4)
+        np.testing.assert_allclose(s, g[f"c{c}_opt_s"], atol=2e-4)
+        if d is None:
+            assert g[f"c{c}_opt_d"].size == 0
+        else:
+            np.testing.assert_allclose(d, g[f"c{c}_opt_d"], atol=2e-4)
+        if pts is not None and not o.no_obs:
+            assert abs(float(o.min_distance) - float(g[f"c{c}_min_distance"])) < 2e-5
+
+
+def _qp_problem(g, i):
+    p = f"q{i}_"
+    sc = g[p + "scalars"]
+    fa = g[p + "fa"] if g[p + "fa"].size else None
+    fb = g[p + "fb"] if g[p + "fb"].size else None
+    return NrmpProblem(g[p + "nom_s"], g[p + "qref_s"], g[p + "puref"], g[p + "A"], g[p + "B"], g[p + "C"], fa, fb,
+                       g[p + "q_s"], sc[0], sc[1], sc[2], sc[3], sc[4], sc[5], g[p + "speed_bound"],
+                       g[p + "acce_bound"], str(g[p + "kin"]))
+
+
+def test_qp_oracle_vs_highs_and_certificate():
+    """The fp64 QP oracle against (a) HiGHS' solution of the same problem, computed in the
+    build container and stored in qp_cases.npz, (b) the independent KKT certificate,
+    (c) the condensed-formulation prototype of the GPU algorithm."""
+    g = golden("qp_cases")
+    n = int(g["count"])
+    assert n >= 20
+    for i in range(n):
+        pb = _qp_problem(g, i)
+        s, u, d = solve_nrmp_qp(pb)
+        np.testing.assert_allclose(u, g[f"q{i}_u"], atol=1e-9)           # deterministic re-solve
+        # HiGHS terminates at ~1e-7 objective accuracy; along the flat (high-frequency
+        # steering) directions of this QP that is a few 1e-6..1e-5 in u.
+        np.testing.assert_allclose(u, g[f"q{i}_u_highs"], atol=5e-5)
+        assert float(g[f"q{i}_obj_oracle"]) <= float(g[f"q{i}_obj_highs"]) + 1e-9
+        cert = kkt_certificate(pb, s, u, d)
+        assert cert["dyn"] < 1e-10 and cert["feas"] < 1e-9 and cert["stat"] < 1e-6 and cert["comp"] < 1e-8, cert
+        s2, u2, d2, info = solve_condensed(pb)
+        np.testing.assert_allclose(u2, u, atol=2e-6)
+        np.testing.assert_allclose(s2, s, atol=2e-6)
