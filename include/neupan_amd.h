@@ -1,0 +1,141 @@
+/* neupan_amd.h -- C ABI of the MI355X-native PAN inner solver (libneupan_amd.so).
+ *
+ * The reference (hanruihua/NeuPAN, pure Python) has NO FFI/plugin interface; its seam for
+ * this path is the torch.nn.Module contract of `PAN` (neupan/blocks/pan.py:28-147), built
+ * at neupan/neupan.py:84 and called at neupan/neupan.py:129-131.  The entry points below
+ * are what a ctypes binding behind that class needs; each cites the reference code it
+ * replaces.  INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = ok, <0 = NPA_E_* (never throws);
+ *   - all array arguments of npa_forward_batch are DEVICE pointers owned by the caller
+ *     (torch-ROCm tensors' data_ptr()); the library allocates nothing per call;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     all work is enqueued on it, nothing synchronises;
+ *   - layouts are the reference's tensors with a leading scene (batch) axis, fp32,
+ *     C-contiguous: coordinates on the slow axis, time/points on the fast axis.
+ */
+#ifndef NEUPAN_AMD_H
+#define NEUPAN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NPA_OK 0
+#define NPA_E_ARG (-1)      /* bad argument (null pointer, size out of range)            */
+#define NPA_E_HIP (-2)      /* a HIP runtime call failed; see npa_last_error()           */
+#define NPA_E_UNSUPPORTED (-3) /* configuration outside the compiled limits (NPA_MAX_*)  */
+
+#define NPA_MAX_T 21        /* receding horizon (3T <= 64: one KKT row per lane)          */
+#define NPA_MAX_M 32        /* nrmp_max_num (points kept per horizon step)                */
+#define NPA_MAX_E 8         /* polytope edges of the robot (rows of G)                    */
+
+#define NPA_KIN_DIFF 0
+#define NPA_KIN_ACKER 1
+#define NPA_KIN_OMNI 2
+
+/* Constructor arguments of PAN (pan.py:43-56), of its adjust_kwargs (pan.py:75-82) and the
+ * robot attributes the path reads (robot.py:53-71: G, h, kinematics, L, speed_bound,
+ * acce_bound = max_acce*dt).  Unbounded speed/acceleration = INFINITY (robot.py:37-38). */
+typedef struct npa_config {
+  int32_t receding;        /* T   */
+  int32_t iter_num;        /* K: PAN iterations per forward (pan.py:128)                  */
+  int32_t dune_max_num;    /* points fed to DUNE per scene after decimation (pan.py:171)  */
+  int32_t nrmp_max_num;    /* M: nearest points kept per step (nrmp.py:254)               */
+  int32_t edge_num;        /* E = G.shape[0]                                              */
+  int32_t kinematics;      /* NPA_KIN_*                                                   */
+  float iter_threshold;    /* pan.py:243; <= 0 disables the early exit                    */
+  /* python floats in the reference (fp64): */
+  double step_time;        /* dt  */
+  double wheelbase;        /* L (acker only)                                              */
+  double speed_bound[2];
+  double acce_bound[2];
+  double ro_obs, bk;
+  /* fp32 tensors in the reference (nrmp.py:79-95, configuration/__init__.py:27): */
+  float q_s[3];            /* scalar q_s is passed replicated                             */
+  float p_u, eta, d_max, d_min;
+  float G[NPA_MAX_E][2];
+  float h[NPA_MAX_E];
+} npa_config;
+
+/* The 18 tensors of a DUNE checkpoint in state_dict order (obs_point_net.py:31-46;
+ * written by dune_train.py:266-274, loaded by dune.py:131-144), HOST pointers, fp32,
+ * torch layout: Linear weight is (out,in) row-major. */
+typedef struct npa_dune_weights {
+  const float *lin_w[6];   /* MLP.{0,3,5,8,10,13}.weight : (32,2) (32,32)x4 (E,32)        */
+  const float *lin_b[6];   /* MLP.{0,3,5,8,10,13}.bias                                    */
+  const float *ln_w[3];    /* MLP.{1,6,11}.weight (32,)                                   */
+  const float *ln_b[3];    /* MLP.{1,6,11}.bias   (32,)                                   */
+} npa_dune_weights;
+
+typedef struct npa_handle npa_handle;
+
+/* Replaces PAN.__init__ + DUNE.load_model (pan.py:43-107, dune.py:131-144).  Uploads the
+ * repacked weights (a few KiB) to the current device.  One handle per (device, config). */
+int npa_create(const npa_config *cfg, const npa_dune_weights *w, npa_handle **out);
+int npa_destroy(npa_handle *h);
+
+/* Replaces NRMP.update_adjust_parameters_value (nrmp.py:170-217). */
+int npa_set_adjust(npa_handle *h, const float q_s[3], float p_u, float eta, float d_max, float d_min);
+
+/* Bytes of caller-owned device memory npa_forward_batch needs for `batch` scenes:
+ * scratch (no meaning between calls) and state (the stop criterion's memory of the
+ * previous iterate, pan.py:100-105 / 215-243; zero it to reset a scene). */
+size_t npa_workspace_bytes(const npa_handle *h, int batch);
+size_t npa_state_bytes(const npa_handle *h, int batch);
+
+/* Replaces PAN.forward (pan.py:109-147) for `batch` independent scenes:
+ *   K x { generate_point_flow (pan.py:150-212) -> DUNE.forward (dune.py:58-127) ->
+ *         NRMP.forward (nrmp.py:114-150, robot.py:239-316, the QP of nrmp.py:263-383) ->
+ *         stop_criteria (pan.py:215-243) }.
+ * Inputs  nom_s [B][3][T+1], nom_u [B][2][T], ref_s [B][3][T+1], ref_us [B][T],
+ *         points [B][2][n_stride] (global frame), velocities same shape or NULL,
+ *         n_points [B] int32 (<= n_stride; 0 = no obstacle points for that scene) or NULL
+ *         meaning every scene has n_stride points.  Point sets larger than dune_max_num
+ *         are decimated in-kernel exactly like util.downsample_decimation (util:285-305).
+ * Outputs out_s [B][3][T+1], out_u [B][2][T], out_d [B][T] (undefined when nrmp_max_num=0),
+ *         out_min_distance [B] (DUNE.min_distance, dune.py:97-98; +inf without points),
+ *         out_iters [B] int32 iterations executed, out_nrmp_points [B][2][M] or NULL
+ *         (NRMP.obstacle_points, nrmp.py:135-138).
+ * Inputs are not modified.  Everything is enqueued on `stream`. */
+int npa_forward_batch(npa_handle *h, int batch, int n_stride,
+                      const float *nom_s, const float *nom_u, const float *ref_s, const float *ref_us,
+                      const float *points, const float *velocities, const int32_t *n_points,
+                      float *out_s, float *out_u, float *out_d, float *out_min_distance,
+                      int32_t *out_iters, float *out_nrmp_points,
+                      void *workspace, size_t workspace_bytes, void *state, size_t state_bytes,
+                      void *stream);
+
+/* Stage entry points (used by the parity tests and for profiling one stage alone).
+ * npa_dune_stage  = generate_point_flow + DUNE.forward + the top-M gather:
+ *   mu_sorted [B][T+1][M][E], lam_sorted [B][T+1][M][2], pts_sorted [B][T+1][M][2],
+ *   dist_sorted [B][T+1][M], count [B][T+1] (= min(N,M); rows >= count replicate row 0).
+ * npa_nrmp_stage  = generate_state_parameter_value + generate_coefficient_parameter_value
+ *   + the QP solve, from those arrays; writes s,u,d plus qp_info [B][4] doubles
+ *   (iterations, final merit, mu, status). */
+int npa_dune_stage(npa_handle *h, int batch, int n_stride, const float *nom_s,
+                   const float *points, const float *velocities, const int32_t *n_points,
+                   float *mu_sorted, float *lam_sorted, float *pts_sorted, float *dist_sorted,
+                   int32_t *count, void *stream);
+int npa_nrmp_stage(npa_handle *h, int batch, const float *nom_s, const float *nom_u,
+                   const float *ref_s, const float *ref_us, const float *mu_sorted,
+                   const float *lam_sorted, const float *pts_sorted, const int32_t *count,
+                   float *out_s, float *out_u, float *out_d, double *qp_info, void *stream);
+
+/* Timing hook for bench.py: enqueue HIP events around every DUNE-stage launch of
+ * subsequent npa_forward_batch calls (on the launch stream) and read back the average
+ * per-launch duration in ms.  enable=0 turns it off. */
+int npa_profile_enable(npa_handle *h, int enable);
+int npa_profile_read(npa_handle *h, double *dune_ms_avg, double *nrmp_ms_avg, int64_t *launches);
+
+const char *npa_last_error(void);
+const char *npa_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEUPAN_AMD_H */

@@ -1,0 +1,80 @@
+"""ctypes binding of libneupan_amd.so (C ABI: include/neupan_amd.h).
+
+The HIP library is the product path.  There is NO CPU fallback: if the shared library is
+missing (or cannot be loaded) every entry point raises -- build it with
+`python -m neupan_amd.build` (hipcc, gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libneupan_amd.so")
+
+NPA_MAX_T, NPA_MAX_M, NPA_MAX_E = 21, 32, 8
+KIN = {"diff": 0, "acker": 1, "omni": 2}
+
+
+class NpaConfig(C.Structure):
+    _fields_ = [
+        ("receding", C.c_int32), ("iter_num", C.c_int32), ("dune_max_num", C.c_int32),
+        ("nrmp_max_num", C.c_int32), ("edge_num", C.c_int32), ("kinematics", C.c_int32),
+        ("iter_threshold", C.c_float),
+        ("step_time", C.c_double), ("wheelbase", C.c_double),
+        ("speed_bound", C.c_double * 2), ("acce_bound", C.c_double * 2),
+        ("ro_obs", C.c_double), ("bk", C.c_double),
+        ("q_s", C.c_float * 3), ("p_u", C.c_float), ("eta", C.c_float), ("d_max", C.c_float), ("d_min", C.c_float),
+        ("G", (C.c_float * 2) * NPA_MAX_E), ("h", C.c_float * NPA_MAX_E),
+    ]
+
+
+class NpaDuneWeights(C.Structure):
+    _fields_ = [("lin_w", C.c_void_p * 6), ("lin_b", C.c_void_p * 6), ("ln_w", C.c_void_p * 3), ("ln_b", C.c_void_p * 3)]
+
+
+# every symbol include/neupan_amd.h declares: (name, restype, argtypes)
+_P, _I, _SZ = C.c_void_p, C.c_int, C.c_size_t
+SYMBOLS = {
+    "npa_create": (_I, [C.POINTER(NpaConfig), C.POINTER(NpaDuneWeights), C.POINTER(_P)]),
+    "npa_destroy": (_I, [_P]),
+    "npa_set_adjust": (_I, [_P, C.POINTER(C.c_float * 3), C.c_float, C.c_float, C.c_float, C.c_float]),
+    "npa_workspace_bytes": (_SZ, [_P, _I]),
+    "npa_state_bytes": (_SZ, [_P, _I]),
+    "npa_forward_batch": (_I, [_P, _I, _I] + [_P] * 13 + [_P, _SZ, _P, _SZ, _P]),
+    "npa_dune_stage": (_I, [_P, _I, _I] + [_P] * 9 + [_P]),
+    "npa_nrmp_stage": (_I, [_P, _I] + [_P] * 12 + [_P]),
+    "npa_profile_enable": (_I, [_P, _I]),
+    "npa_profile_read": (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "npa_last_error": (C.c_char_p, []),
+    "npa_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+class NeupanAmdError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library; raise loudly if it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NeupanAmdError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m neupan_amd.build` "
+            "(needs hipcc; cross-compiles for gfx950). neupan_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the export is missing
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().npa_last_error()
+        raise NeupanAmdError(f"{what} failed with status {status}: {msg.decode() if msg else ''}")

@@ -1,0 +1,240 @@
+// c_api.hip -- the extern "C" boundary of libneupan_amd.so (see include/neupan_amd.h).
+// Host-side only: weight repacking, workspace carving, launch sequencing.  No torch types.
+#include "../../include/neupan_amd.h"
+#include "pan_common.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+extern "C" hipError_t npa_launch_dune(const DevParams& P, const float* wpack, int batch, int n_stride,
+                                      const float* cur_s, const float* points, const float* vel,
+                                      const int* n_points, const int* flags, float* mu_sorted, float* lam_sorted,
+                                      float* pts_sorted, float* dist_sorted, int* count, hipStream_t stream);
+extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, const float* cur_s_in, const float* cur_u_in,
+                                    const float* ref_s, const float* ref_us, const float* mu_sorted,
+                                    const float* lam_sorted, const float* pts_sorted, const float* dist_sorted,
+                                    const int* count, float* cur_s_out, float* cur_u_out, float* cur_d_out,
+                                    float* out_s, float* out_u, float* out_d, float* out_min_distance,
+                                    int* out_iters, float* out_nrmp_points, int* flags, float* state,
+                                    double* qp_info, hipStream_t stream);
+extern "C" size_t npa_qp_shmem_bytes(int T, int M);
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) return fail(NPA_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+struct EventPair { hipEvent_t a, b; };
+
+struct npa_handle {
+  DevParams P;
+  float* wpack = nullptr;     // device
+  int device = 0;
+  // profiling (bench.py): HIP events on the launch stream around every stage launch
+  bool prof = false;
+  std::vector<EventPair> ev_dune, ev_qp;
+  size_t n_dune = 0, n_qp = 0;
+};
+
+extern "C" const char* npa_last_error(void) { return g_err.c_str(); }
+extern "C" const char* npa_version(void) { return "neupan_amd 0.1 (gfx950)"; }
+
+static int mdim(const DevParams& P) { return P.M > 0 ? P.M : 1; }
+
+extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_handle** out) {
+  if (!cfg || !out) return fail(NPA_E_ARG, "npa_create: null argument");
+  if (cfg->receding < 1 || cfg->receding > NPA_MAX_T) return fail(NPA_E_UNSUPPORTED, "receding outside [1,NPA_MAX_T]");
+  if (cfg->nrmp_max_num < 0 || cfg->nrmp_max_num > NPA_MAX_M) return fail(NPA_E_UNSUPPORTED, "nrmp_max_num outside [0,NPA_MAX_M]");
+  if (cfg->edge_num < 3 || cfg->edge_num > NPA_MAX_E) return fail(NPA_E_UNSUPPORTED, "edge_num outside [3,NPA_MAX_E]");
+  if (cfg->kinematics < 0 || cfg->kinematics > 2) return fail(NPA_E_ARG, "unknown kinematics");
+  if (cfg->iter_num < 1) return fail(NPA_E_ARG, "iter_num < 1");
+  if (npa_qp_shmem_bytes(cfg->receding, cfg->nrmp_max_num) > 160 * 1024) return fail(NPA_E_UNSUPPORTED, "T*M too large for LDS");
+  const bool need_w = cfg->nrmp_max_num > 0 && cfg->dune_max_num > 0;
+  if (need_w && !w) return fail(NPA_E_ARG, "DUNE weights required unless nrmp_max_num == 0 or dune_max_num == 0");
+
+  npa_handle* h = new npa_handle();
+  DevParams& P = h->P;
+  memset(&P, 0, sizeof(P));
+  P.T = cfg->receding; P.M = (cfg->dune_max_num > 0) ? cfg->nrmp_max_num : 0; P.E = cfg->edge_num;
+  P.kin = cfg->kinematics; P.K = cfg->iter_num; P.dune_max_num = cfg->dune_max_num;
+  P.iter_threshold = cfg->iter_threshold;
+  P.dt = cfg->step_time; P.dt32 = (float)cfg->step_time; P.L = cfg->wheelbase;
+  for (int k = 0; k < 2; ++k) { P.speed_bound[k] = cfg->speed_bound[k]; P.acce_bound[k] = cfg->acce_bound[k]; }
+  P.ro_obs = cfg->ro_obs; P.bk = cfg->bk;
+  for (int k = 0; k < 3; ++k) P.q_s[k] = cfg->q_s[k];
+  P.p_u = cfg->p_u; P.eta = cfg->eta; P.d_max = cfg->d_max; P.d_min = cfg->d_min;
+  for (int e = 0; e < NPA_MAX_E; ++e) { P.G[e][0] = cfg->G[e][0]; P.G[e][1] = cfg->G[e][1]; P.h[e] = cfg->h[e]; }
+
+  std::vector<float> pack(WP_TOTAL, 0.f);
+  if (need_w) {
+    const int E = P.E;
+    for (int l = 0; l < 64; ++l) pack[WP_W1 + l] = w->lin_w[0][(l & 31) * 2 + (l >> 5)];   // A[i][k] = W1[i][k]
+    for (int L = 0; L < 4; ++L)
+      for (int r = 0; r < 16; ++r)
+        for (int l = 0; l < 64; ++l)
+          pack[WP_WL + (L * 16 + r) * 64 + l] = w->lin_w[1 + L][(l & 31) * 32 + npa_feat(r, l >> 5)];
+    auto putv = [&](int slot, const float* src) { memcpy(&pack[WP_VEC + slot * 32], src, 32 * sizeof(float)); };
+    putv(V_B1, w->lin_b[0]); putv(V_G1, w->ln_w[0]); putv(V_BE1, w->ln_b[0]);
+    putv(V_B2, w->lin_b[1]);
+    putv(V_B3, w->lin_b[2]); putv(V_G2, w->ln_w[1]); putv(V_BE2, w->ln_b[1]);
+    putv(V_B4, w->lin_b[3]);
+    putv(V_B5, w->lin_b[4]); putv(V_G3, w->ln_w[2]); putv(V_BE3, w->ln_b[2]);
+    for (int e = 0; e < E; ++e) {
+      memcpy(&pack[WP_W6 + e * 32], w->lin_w[5] + e * 32, 32 * sizeof(float));
+      pack[WP_B6 + e] = w->lin_b[5][e];
+    }
+  }
+  hipError_t e = hipGetDevice(&h->device);
+  if (e == hipSuccess) e = hipMalloc(&h->wpack, WP_TOTAL * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(h->wpack, pack.data(), WP_TOTAL * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    delete h;
+    return fail(NPA_E_HIP, std::string("npa_create: ") + hipGetErrorString(e));
+  }
+  *out = h;
+  return NPA_OK;
+}
+
+extern "C" int npa_destroy(npa_handle* h) {
+  if (!h) return NPA_OK;
+  for (auto& p : h->ev_dune) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+  for (auto& p : h->ev_qp) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+  if (h->wpack) hipFree(h->wpack);
+  delete h;
+  return NPA_OK;
+}
+
+extern "C" int npa_set_adjust(npa_handle* h, const float q_s[3], float p_u, float eta, float d_max, float d_min) {
+  if (!h || !q_s) return fail(NPA_E_ARG, "npa_set_adjust: null argument");
+  for (int k = 0; k < 3; ++k) h->P.q_s[k] = q_s[k];
+  h->P.p_u = p_u; h->P.eta = eta; h->P.d_max = d_max; h->P.d_min = d_min;
+  return NPA_OK;
+}
+
+extern "C" size_t npa_workspace_bytes(const npa_handle* h, int batch) {
+  if (!h || batch < 1) return 0;
+  return npa_scratch_layout(batch, h->P.T, mdim(h->P), h->P.E).total * sizeof(float);
+}
+extern "C" size_t npa_state_bytes(const npa_handle* h, int batch) {
+  if (!h || batch < 1) return 0;
+  return (size_t)batch * npa_state_floats(h->P.T, mdim(h->P), h->P.E) * sizeof(float);
+}
+
+static EventPair* next_event(npa_handle* h, std::vector<EventPair>& pool, size_t& used) {
+  if (!h->prof) return nullptr;
+  if (used == pool.size()) {
+    if (pool.size() >= 8192) return nullptr;
+    EventPair p;
+    if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return nullptr;
+    pool.push_back(p);
+  }
+  return &pool[used++];
+}
+
+extern "C" int npa_profile_enable(npa_handle* h, int enable) {
+  if (!h) return fail(NPA_E_ARG, "null handle");
+  h->prof = enable != 0;
+  h->n_dune = h->n_qp = 0;
+  return NPA_OK;
+}
+
+extern "C" int npa_profile_read(npa_handle* h, double* dune_ms_avg, double* nrmp_ms_avg, int64_t* launches) {
+  if (!h) return fail(NPA_E_ARG, "null handle");
+  auto avg = [](std::vector<EventPair>& pool, size_t used, double* out) -> hipError_t {
+    double tot = 0;
+    for (size_t i = 0; i < used; ++i) {
+      hipError_t e = hipEventSynchronize(pool[i].b);
+      if (e != hipSuccess) return e;
+      float ms = 0;
+      e = hipEventElapsedTime(&ms, pool[i].a, pool[i].b);
+      if (e != hipSuccess) return e;
+      tot += ms;
+    }
+    if (out) *out = used ? tot / used : 0.0;
+    return hipSuccess;
+  };
+  HIP_TRY(avg(h->ev_dune, h->n_dune, dune_ms_avg));
+  HIP_TRY(avg(h->ev_qp, h->n_qp, nrmp_ms_avg));
+  if (launches) *launches = (int64_t)h->n_dune;
+  h->n_dune = h->n_qp = 0;
+  return NPA_OK;
+}
+
+extern "C" int npa_dune_stage(npa_handle* h, int batch, int n_stride, const float* nom_s, const float* points,
+                              const float* velocities, const int32_t* n_points, float* mu_sorted, float* lam_sorted,
+                              float* pts_sorted, float* dist_sorted, int32_t* count, void* stream) {
+  if (!h || batch < 1 || n_stride < 1 || !nom_s || !points || !mu_sorted || !lam_sorted || !pts_sorted ||
+      !dist_sorted || !count)
+    return fail(NPA_E_ARG, "npa_dune_stage: bad argument");
+  if (h->P.M <= 0) return fail(NPA_E_ARG, "npa_dune_stage: planner has no obstacle stage (nrmp_max_num or dune_max_num is 0)");
+  HIP_TRY(npa_launch_dune(h->P, h->wpack, batch, n_stride, nom_s, points, velocities, n_points, nullptr, mu_sorted,
+                          lam_sorted, pts_sorted, dist_sorted, count, (hipStream_t)stream));
+  return NPA_OK;
+}
+
+extern "C" int npa_nrmp_stage(npa_handle* h, int batch, const float* nom_s, const float* nom_u, const float* ref_s,
+                              const float* ref_us, const float* mu_sorted, const float* lam_sorted,
+                              const float* pts_sorted, const int32_t* count, float* out_s, float* out_u,
+                              float* out_d, double* qp_info, void* stream) {
+  if (!h || batch < 1 || !nom_s || !nom_u || !ref_s || !ref_us || !out_s || !out_u)
+    return fail(NPA_E_ARG, "npa_nrmp_stage: bad argument");
+  if (h->P.M > 0 && (!mu_sorted || !lam_sorted || !pts_sorted || !count || !out_d))
+    return fail(NPA_E_ARG, "npa_nrmp_stage: obstacle arrays required when nrmp_max_num > 0");
+  HIP_TRY(npa_launch_qp(h->P, batch, nom_s, nom_u, ref_s, ref_us, mu_sorted, lam_sorted, pts_sorted, nullptr, count,
+                        out_s, out_u, out_d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                        qp_info, (hipStream_t)stream));
+  return NPA_OK;
+}
+
+extern "C" int npa_forward_batch(npa_handle* h, int batch, int n_stride, const float* nom_s, const float* nom_u,
+                                 const float* ref_s, const float* ref_us, const float* points,
+                                 const float* velocities, const int32_t* n_points, float* out_s, float* out_u,
+                                 float* out_d, float* out_min_distance, int32_t* out_iters, float* out_nrmp_points,
+                                 void* workspace, size_t workspace_bytes, void* state, size_t state_bytes,
+                                 void* stream_) {
+  if (!h || batch < 1 || !nom_s || !nom_u || !ref_s || !ref_us || !out_s || !out_u || !workspace || !state)
+    return fail(NPA_E_ARG, "npa_forward_batch: null argument");
+  const DevParams& P = h->P;
+  if (P.M > 0 && !out_d) return fail(NPA_E_ARG, "npa_forward_batch: out_d required when nrmp_max_num > 0");
+  if (workspace_bytes < npa_workspace_bytes(h, batch)) return fail(NPA_E_ARG, "workspace too small");
+  if (state_bytes < npa_state_bytes(h, batch)) return fail(NPA_E_ARG, "state buffer too small");
+  if (points && n_stride < 1) return fail(NPA_E_ARG, "n_stride < 1");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int T = P.T;
+  const ScratchLayout L = npa_scratch_layout(batch, T, mdim(P), P.E);
+  float* ws = (float*)workspace;
+  float *cur_s = ws + L.cur_s, *cur_u = ws + L.cur_u, *cur_d = ws + L.cur_d;
+  float *mu = ws + L.mu, *lam = ws + L.lam, *pts = ws + L.pts, *dist = ws + L.dist;
+  int* count = (int*)(ws + L.count);
+  int* flags = (int*)(ws + L.flags);
+  const bool dune = P.M > 0 && points != nullptr;
+
+  HIP_TRY(hipMemcpyAsync(cur_s, nom_s, (size_t)batch * 3 * (T + 1) * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(cur_u, nom_u, (size_t)batch * 2 * T * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  HIP_TRY(hipMemsetAsync(flags, 0, (size_t)batch * 4 * sizeof(int), stream));
+  HIP_TRY(hipMemsetAsync(count, 0, (size_t)batch * (T + 1) * sizeof(int), stream));
+
+  for (int k = 0; k < P.K; ++k) {
+    if (dune) {
+      EventPair* ev = next_event(h, h->ev_dune, h->n_dune);
+      if (ev) HIP_TRY(hipEventRecord(ev->a, stream));
+      HIP_TRY(npa_launch_dune(P, h->wpack, batch, n_stride, cur_s, points, velocities, n_points, flags, mu, lam, pts,
+                              dist, count, stream));
+      if (ev) HIP_TRY(hipEventRecord(ev->b, stream));
+    }
+    EventPair* ev = next_event(h, h->ev_qp, h->n_qp);
+    if (ev) HIP_TRY(hipEventRecord(ev->a, stream));
+    HIP_TRY(npa_launch_qp(P, batch, cur_s, cur_u, ref_s, ref_us, mu, lam, pts, dist, count, cur_s, cur_u, cur_d, out_s,
+                          out_u, out_d, out_min_distance, out_iters, out_nrmp_points, flags, (float*)state, nullptr,
+                          stream));
+    if (ev) HIP_TRY(hipEventRecord(ev->b, stream));
+  }
+  return NPA_OK;
+}

@@ -1,0 +1,316 @@
+// dune.hip -- point flow + DUNE encoder + nearest-M gather, one workgroup per
+// (scene, horizon step) slice.  gfx950 (MI355X) only.
+//
+// Replaces, for every slice t of every scene (reference file:line):
+//   PAN.generate_point_flow / point_state_transform   neupan/blocks/pan.py:150-212
+//   util.downsample_decimation                        neupan/util/__init__.py:285-305
+//   ObsPointNet forward                               neupan/blocks/obs_point_net.py:31-49
+//   DUNE.forward (lam, distance, sort, gathers)       neupan/blocks/dune.py:58-127
+// Only the first M sorted columns are ever consumed downstream (nrmp.py:254-255,
+// pan.py:234-237), so instead of a full argsort the kernel keeps the slice's distances in
+// LDS, extracts the M smallest (distance, index) keys in ascending order, and re-evaluates
+// the encoder for just those M points to emit mu / lam / point / distance rows -- nothing
+// per-point ever goes to HBM.
+//
+// Mapping to the hardware
+//   * 4 waves per workgroup; a wave pushes tiles of 32 points through the MLP.  The four
+//     32x32 layers run on v_mfma_f32_32x32x2_f32 (exact fp32, 16 K-steps per layer) with the
+//     points on the N axis: lane (j = lane&31, hf = lane>>5) ends a layer holding features
+//     feat(r,hf) of point j in accumulator register r, which is precisely the B operand
+//     layout of the next layer's K-step r -- activations never leave their registers.
+//     Weight A-fragments (65 VGPRs) are loaded once per wave and reused for every tile.
+//   * bias / LayerNorm affine vectors and the 32xE output layer sit in LDS; a lane fetches
+//     its 16 features with four broadcast ds_read_b128.
+//   * LayerNorm reductions: 16 in-lane adds + one v_permlane32_swap (features of a point
+//     live in lanes j and j+32).
+//   * the 2->32 input layer is one MFMA (K=2); the 32->E output layer is VALU work
+//     (an MFMA would waste 28 of 32 rows).
+#include "pan_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define DUNE_THREADS 256
+#define DUNE_WAVES 4
+
+__device__ __forceinline__ float pair_sum(float x) {
+  // value + value of lane^32 (bitwise identical in both lanes: fp add commutes)
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ float tanh_f32(float x) {
+  // tanh(x) = 1 - 2/(exp(2x)+1); |abs err| <~ 1.5e-7, saturates correctly at +-1
+  float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+__device__ __forceinline__ void load_vec16(const float* v, int hf, float out[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float4 t = *reinterpret_cast<const float4*>(v + 8 * q + 4 * hf);
+    out[4 * q + 0] = t.x; out[4 * q + 1] = t.y; out[4 * q + 2] = t.z; out[4 * q + 3] = t.w;
+  }
+}
+
+__device__ __forceinline__ f32x16 bias_init(const float* v, int hf) {
+  float b[16];
+  load_vec16(v, hf, b);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = b[r];
+  return acc;
+}
+
+// LayerNorm(32, eps=1e-5, affine) + tanh on a point's 32 features (16 here, 16 in lane^32)
+__device__ __forceinline__ void ln_tanh(f32x16 acc, const float* g, const float* be, int hf, float a[16]) {
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s += acc[r];
+  float mean = pair_sum(s) * (1.0f / 32.0f);
+  float q = 0.f;
+  float xc[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { xc[r] = acc[r] - mean; q = fmaf(xc[r], xc[r], q); }
+  float var = pair_sum(q) * (1.0f / 32.0f);
+  float rstd = 1.0f / __fsqrt_rn(var + 1e-5f);
+  float gv[16], bv[16];
+  load_vec16(g, hf, gv);
+  load_vec16(be, hf, bv);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = tanh_f32(fmaf(xc[r] * rstd, gv[r], bv[r]));
+}
+
+__device__ __forceinline__ f32x16 layer32(const float (&w)[16], const float (&a)[16], f32x16 acc) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], a[r], acc, 0, 0, 0);
+  return acc;
+}
+
+struct WaveWeights {
+  float w1;
+  float wl[4][16];
+};
+
+// Encoder for the 32 points of a tile.  p0x/p0y: the point in the robot frame (both lanes of
+// a pair hold both).  Returns mu[e] (e<E) in BOTH lanes of the pair.
+template <int E>
+__device__ __forceinline__ void encode_tile(const WaveWeights& W, const float* vec, const float* w6,
+                                            const float* b6, float p0x, float p0y, int hf, float mu[E]) {
+  float a[16];
+  {
+    f32x16 acc = bias_init(vec + V_B1 * 32, hf);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W.w1, hf ? p0y : p0x, acc, 0, 0, 0);
+    ln_tanh(acc, vec + V_G1 * 32, vec + V_BE1 * 32, hf, a);
+  }
+  {
+    f32x16 acc = layer32(W.wl[0], a, bias_init(vec + V_B2 * 32, hf));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r], 0.f);
+  }
+  {
+    f32x16 acc = layer32(W.wl[1], a, bias_init(vec + V_B3 * 32, hf));
+    ln_tanh(acc, vec + V_G2 * 32, vec + V_BE2 * 32, hf, a);
+  }
+  {
+    f32x16 acc = layer32(W.wl[2], a, bias_init(vec + V_B4 * 32, hf));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r], 0.f);
+  }
+  {
+    f32x16 acc = layer32(W.wl[3], a, bias_init(vec + V_B5 * 32, hf));
+    ln_tanh(acc, vec + V_G3 * 32, vec + V_BE3 * 32, hf, a);
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    float wv[16];
+    load_vec16(w6 + e * 32, hf, wv);
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s = fmaf(wv[r], a[r], s);
+    mu[e] = fmaxf(pair_sum(s) + b6[e], 0.f);
+  }
+}
+
+__device__ __forceinline__ unsigned ordered_key(float d) {
+  // monotone float -> uint map; NaN sorts last
+  if (d != d) return 0xFFFFFFFEu;
+  unsigned b = __float_as_uint(d);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    unsigned long long o = __shfl_xor(v, off, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+struct SliceFrame {
+  float c, s, tx, ty;         // rotation (fp32 cos/sin of theta) and translation of the robot
+  float tstep;                // (float)t
+  float rg[2][NPA_MAX_E];     // (-R) @ G^T          (dune.py:89)
+};
+
+// source column of logical point n after decimation (util/__init__.py:300: linspace->int)
+__device__ __forceinline__ int src_index(int n, int n_raw, int n_use) {
+  if (n_use >= n_raw) return n;
+  if (n == n_use - 1) return n_raw - 1;
+  double step = (double)(n_raw - 1) / (double)(n_use - 1);
+  return (int)((double)n * step);
+}
+
+template <int E>
+__device__ __forceinline__ void point_features(const DevParams& P, const SliceFrame& F, const WaveWeights& W,
+                                               const float* vec, const float* w6, const float* b6,
+                                               const float* px_row, const float* py_row, const float* vx_row,
+                                               const float* vy_row, int src, int hf, float mu[E], float& gx,
+                                               float& gy, float& lx, float& ly, float& dist) {
+  // pan.py:182  receding_obs_points = obs_points + i * (point_velocities * dt)
+  gx = px_row[src];
+  gy = py_row[src];
+  if (vx_row) {
+    gx = __fadd_rn(gx, __fmul_rn(F.tstep, __fmul_rn(vx_row[src], P.dt32)));
+    gy = __fadd_rn(gy, __fmul_rn(F.tstep, __fmul_rn(vy_row[src], P.dt32)));
+  }
+  // pan.py:210  p0 = R.T @ (obs_points - trans)
+  float dx = __fsub_rn(gx, F.tx), dy = __fsub_rn(gy, F.ty);
+  float p0x = fmaf(F.c, dx, __fmul_rn(F.s, dy));
+  float p0y = fmaf(F.c, dy, -__fmul_rn(F.s, dx));
+  encode_tile<E>(W, vec, w6, b6, p0x, p0y, hf, mu);
+  lx = 0.f; ly = 0.f; dist = 0.f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    lx = fmaf(F.rg[0][e], mu[e], lx);                                  // dune.py:89
+    ly = fmaf(F.rg[1][e], mu[e], ly);
+    float tmp = __fsub_rn(fmaf(P.G[e][0], p0x, __fmul_rn(P.G[e][1], p0y)), P.h[e]);   // dune.py:121
+    dist = fmaf(mu[e], tmp, dist);                                     // dune.py:124
+  }
+}
+
+template <int E>
+__global__ __launch_bounds__(DUNE_THREADS) void dune_kernel(
+    DevParams P, const float* __restrict__ wpack, int n_stride, const float* __restrict__ cur_s,
+    const float* __restrict__ points, const float* __restrict__ vel, const int* __restrict__ n_points,
+    const int* __restrict__ flags, float* __restrict__ mu_sorted, float* __restrict__ lam_sorted,
+    float* __restrict__ pts_sorted, float* __restrict__ dist_sorted, int* __restrict__ count) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* vec = smem;                       // [11][32]
+  float* w6 = vec + 11 * 32;               // [8][32]
+  float* b6 = w6 + 8 * 32;                 // [8]
+  int* sel = reinterpret_cast<int*>(b6 + 8);            // [NPA_MAX_M]
+  unsigned* dkey = reinterpret_cast<unsigned*>(sel + NPA_MAX_M);   // [n_use]
+
+  const int t = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, hf = lane >> 5;
+  const int T = P.T, M = P.M;
+  if (flags && flags[b * 4 + 0]) return;   // scene already converged (pan.py:144-145)
+
+  const int n_raw = n_points ? n_points[b] : n_stride;
+  const int n_use = n_raw < P.dune_max_num ? n_raw : P.dune_max_num;
+  const size_t orow = (size_t)b * (T + 1) + t;
+  if (n_use <= 0) {
+    if (tid == 0) count[orow] = 0;
+    return;
+  }
+
+  for (int i = tid; i < 11 * 32 + 8 * 32 + 8; i += DUNE_THREADS) smem[i] = wpack[WP_VEC + i];
+  WaveWeights W;
+  W.w1 = wpack[WP_W1 + lane];
+#pragma unroll
+  for (int l = 0; l < 4; ++l)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) W.wl[l][r] = wpack[WP_WL + (l * 16 + r) * 64 + lane];
+
+  SliceFrame F;
+  {
+    const float* s = cur_s + (size_t)b * 3 * (T + 1);
+    float th = s[2 * (T + 1) + t];
+    F.tx = s[t];
+    F.ty = s[(T + 1) + t];
+    F.c = (float)cos((double)th);
+    F.s = (float)sin((double)th);
+    F.tstep = (float)t;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {     // (-R) @ G^T, R = [[c,-s],[s,c]]
+      F.rg[0][e] = fmaf(-F.c, P.G[e][0], __fmul_rn(F.s, P.G[e][1]));
+      F.rg[1][e] = fmaf(-F.s, P.G[e][0], -__fmul_rn(F.c, P.G[e][1]));
+    }
+  }
+  const float* px_row = points + (size_t)b * 2 * n_stride;
+  const float* py_row = px_row + n_stride;
+  const float* vx_row = vel ? vel + (size_t)b * 2 * n_stride : nullptr;
+  const float* vy_row = vel ? vx_row + n_stride : nullptr;
+  __syncthreads();
+
+  // ---- phase 1: distance of every point of the slice --------------------------------
+  const int ntiles = (n_use + 31) >> 5;
+  for (int tile = wave; tile < ntiles; tile += DUNE_WAVES) {
+    int n = tile * 32 + j;
+    int nc = n < n_use ? n : n_use - 1;
+    float mu[E], gx, gy, lx, ly, dist;
+    point_features<E>(P, F, W, vec, w6, b6, px_row, py_row, vx_row, vy_row, src_index(nc, n_raw, n_use), hf, mu,
+                      gx, gy, lx, ly, dist);
+    if (hf == 0 && n < n_use) dkey[n] = ordered_key(dist);
+  }
+  __syncthreads();
+
+  // ---- phase 2: the M smallest (distance, index) keys, ascending (stable ties) --------
+  const int msel = n_use < M ? n_use : M;
+  if (wave == 0) {
+    for (int m = 0; m < msel; ++m) {
+      unsigned long long best = ~0ull;
+      for (int n = lane; n < n_use; n += 64) {
+        unsigned long long k = ((unsigned long long)dkey[n] << 32) | (unsigned)n;
+        best = k < best ? k : best;
+      }
+      best = wave_min_u64(best);
+      int idx = (int)(best & 0xFFFFFFFFu);
+      if (lane == 0) { sel[m] = idx; dkey[idx] = 0xFFFFFFFFu; }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // LDS store -> later loads, same wave
+      __builtin_amdgcn_wave_barrier();
+    }
+    // ---- phase 3: re-encode the selected points and emit the sorted rows -------------
+    // rows >= msel replicate row 0, the padding rule of nrmp.py:258-259
+    int m = j < msel ? j : 0;
+    float mu[E], gx, gy, lx, ly, dist;
+    point_features<E>(P, F, W, vec, w6, b6, px_row, py_row, vx_row, vy_row, src_index(sel[m], n_raw, n_use), hf, mu,
+                      gx, gy, lx, ly, dist);
+    if (hf == 0 && j < M) {
+      size_t o = orow * M + j;
+#pragma unroll
+      for (int e = 0; e < E; ++e) mu_sorted[o * E + e] = mu[e];
+      lam_sorted[o * 2 + 0] = lx; lam_sorted[o * 2 + 1] = ly;
+      pts_sorted[o * 2 + 0] = gx; pts_sorted[o * 2 + 1] = gy;
+      dist_sorted[o] = dist;
+    }
+    if (lane == 0) count[orow] = msel;
+  }
+}
+
+// host-side launcher (called from c_api.hip)
+extern "C" hipError_t npa_launch_dune(const DevParams& P, const float* wpack, int batch, int n_stride,
+                                      const float* cur_s, const float* points, const float* vel,
+                                      const int* n_points, const int* flags, float* mu_sorted, float* lam_sorted,
+                                      float* pts_sorted, float* dist_sorted, int* count, hipStream_t stream) {
+  dim3 grid(P.T + 1, batch), block(DUNE_THREADS);
+  int n_use_max = n_stride < P.dune_max_num ? n_stride : P.dune_max_num;
+  size_t shmem = (11 * 32 + 8 * 32 + 8) * sizeof(float) + NPA_MAX_M * sizeof(int) +
+                 ((size_t)(n_use_max > 0 ? n_use_max : 1) * sizeof(unsigned) + 15) / 16 * 16;
+#define LAUNCH(EE)                                                                                         \
+  hipLaunchKernelGGL(dune_kernel<EE>, grid, block, shmem, stream, P, wpack, n_stride, cur_s, points, vel,  \
+                     n_points, flags, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count)
+  switch (P.E) {
+    case 3: LAUNCH(3); break;
+    case 4: LAUNCH(4); break;
+    case 5: LAUNCH(5); break;
+    case 6: LAUNCH(6); break;
+    case 7: LAUNCH(7); break;
+    case 8: LAUNCH(8); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef LAUNCH
+  return hipGetLastError();
+}

@@ -1,0 +1,67 @@
+// Shared device/host definitions for the PAN kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NPA_MAX_T 21
+#define NPA_MAX_M 32
+#define NPA_MAX_E 8
+
+// Kernel-argument copy of npa_config (include/neupan_amd.h), passed by value.
+struct DevParams {
+  int T, M, E, kin, K, dune_max_num;
+  float iter_threshold;
+  float dt32;                 // (float)dt, the value fp32 tensor*python-float products see
+  double dt, L;
+  double speed_bound[2], acce_bound[2];
+  double ro_obs, bk;
+  float q_s[3], p_u, eta, d_max, d_min;
+  float G[NPA_MAX_E][2];
+  float h[NPA_MAX_E];
+};
+
+// ---- packed DUNE weights (device buffer, floats) -----------------------------------------
+// MFMA A-operand fragments of v_mfma_f32_32x32x2_f32: lane l holds A[i = l&31][k = l>>5].
+// For K-step r of a 32x32 layer the two K entries are the features
+//   feat(r, hf) = (r&3) + 8*(r>>2) + 4*hf          (hf = lane>>5)
+// i.e. exactly the feature the C/D layout leaves in accumulator register r of that lane, so
+// a layer's activated output registers ARE the next layer's B operands with no data movement.
+#define WP_W1 0                                   // [64]            Linear(2,32)
+#define WP_WL (WP_W1 + 64)                        // [4][16][64]     Linear(32,32) x4
+#define WP_VEC (WP_WL + 4 * 16 * 64)              // [11][32]        per-feature vectors
+#define WP_W6 (WP_VEC + 11 * 32)                  // [8][32]         Linear(32,E) rows (zero padded)
+#define WP_B6 (WP_W6 + 8 * 32)                    // [8]
+#define WP_TOTAL (WP_B6 + 8)
+// order of the per-feature vectors
+enum { V_B1 = 0, V_G1, V_BE1, V_B2, V_B3, V_G2, V_BE2, V_B4, V_B5, V_G3, V_BE3 };
+
+__host__ __device__ inline int npa_feat(int r, int hf) { return (r & 3) + 8 * (r >> 2) + 4 * hf; }
+
+// ---- per-scene persistent state (stop criterion memory, pan.py:100-105) -------------------
+// floats: prev_s[3(T+1)] prev_u[2T] prev_mu[(T+1) M E] prev_lam[(T+1) M 2]; ints: valid, prev_n
+__host__ __device__ inline size_t npa_state_floats(int T, int M, int E) {
+  return (size_t)3 * (T + 1) + 2 * T + (size_t)(T + 1) * M * E + (size_t)(T + 1) * M * 2 + 4;
+}
+
+// ---- scratch: struct-of-arrays over the batch (offsets in 4-byte words) ---------------------
+// cur_s [B][3][T+1]  cur_u [B][2][T]  cur_d [B][T]  mu [B][T+1][M][E]  lam [B][T+1][M][2]
+// pts [B][T+1][M][2]  dist [B][T+1][M]  count [B][T+1] (int)  flags [B][4] (int: done, iters)
+struct ScratchLayout {
+  size_t cur_s, cur_u, cur_d, mu, lam, pts, dist, count, flags, total;
+};
+__host__ __device__ inline ScratchLayout npa_scratch_layout(int B, int T, int M, int E) {
+  ScratchLayout L;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o += (n + 3) & ~(size_t)3; return r; };
+  L.cur_s = take((size_t)B * 3 * (T + 1));
+  L.cur_u = take((size_t)B * 2 * T);
+  L.cur_d = take((size_t)B * T);
+  L.mu = take((size_t)B * (T + 1) * M * E);
+  L.lam = take((size_t)B * (T + 1) * M * 2);
+  L.pts = take((size_t)B * (T + 1) * M * 2);
+  L.dist = take((size_t)B * (T + 1) * M);
+  L.count = take((size_t)B * (T + 1));
+  L.flags = take((size_t)B * 4);
+  L.total = o;
+  return L;
+}

@@ -1,0 +1,379 @@
+"""`PAN` -- host-side mirror of the reference's PAN module (neupan/blocks/pan.py:28-274) over
+the HIP kernels of libneupan_amd.so.
+
+Same constructor, same `forward(nom_s, nom_u, ref_s, ref_us, obs_points, point_velocities)`,
+same attributes other reference code reads (`min_distance`, `dune_points`, `nrmp_points`,
+`nrmp_layer.adjust_parameters`, `nrmp_layer.update_adjust_parameters_value`), so it can be
+installed where `neupan.blocks.PAN` is imported (neupan/neupan.py:24, :84) -- see
+INTEGRATION.md.  New: `forward_batch` plans B independent scenes in one call, which is where
+the GPU earns its keep.
+
+torch is used for device memory and streams only; all arithmetic of the path runs in the
+HIP kernels (neupan_amd/csrc/*.hip) reached through the C ABI (include/neupan_amd.h).
+There is no CPU fallback: constructing a PAN without the built library or without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+from math import inf
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import KIN, NeupanAmdError, NpaConfig, NpaDuneWeights, check
+
+_LINEAR = (0, 3, 5, 8, 10, 13)      # Linear layers in ObsPointNet.MLP (obs_point_net.py:31-46)
+_NORM = (1, 6, 11)                  # LayerNorm layers
+
+
+def _resolve_checkpoint(path):
+    """Search order of the reference's util.file_check (util/__init__.py:58-94): as given,
+    relative to the script directory, relative to the cwd.  Raises instead of prompting."""
+    if path is None or path == "None":
+        raise FileNotFoundError("dune_checkpoint is required (this build never trains or prompts; "
+                                "reference behaviour at neupan/blocks/dune.py:184-207 is to block on input())")
+    cands = [path, os.path.join(sys.path[0], path), os.path.join(os.getcwd(), path)]
+    for c in cands:
+        if os.path.isfile(c):
+            return os.path.abspath(c)
+    raise FileNotFoundError(f"DUNE checkpoint not found: {path}")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class _NrmpFacade:
+    """The slice of `NRMP` other reference code touches (neupan/neupan.py:344-359, 377-379):
+    adjust_parameters + update_adjust_parameters_value (nrmp.py:170-217)."""
+
+    def __init__(self, pan, q_s, p_u, eta, d_max, d_min, no_obs):
+        self._pan = pan
+        self.no_obs = no_obs
+        if isinstance(q_s, (list, tuple, np.ndarray)):
+            q = np.array(q_s, dtype=np.float32).flatten()
+            if q.shape[0] != 3:
+                raise ValueError(f"q_s must be a scalar or a 3-element list/array, got {q.shape[0]} elements")
+            self.q_s = torch.tensor(q.reshape(3, 1), dtype=torch.float32)
+        else:
+            self.q_s = torch.tensor(float(q_s), dtype=torch.float32)
+        self.p_u = torch.tensor(float(p_u), dtype=torch.float32)
+        self.eta = torch.tensor(float(eta), dtype=torch.float32)
+        self.d_max = torch.tensor(float(d_max), dtype=torch.float32)
+        self.d_min = torch.tensor(float(d_min), dtype=torch.float32)
+        self.obstacle_points = None
+
+    @property
+    def adjust_parameters(self):
+        return [self.q_s, self.p_u] if self.no_obs else [self.q_s, self.p_u, self.eta, self.d_max, self.d_min]
+
+    def q_s3(self):
+        q = self.q_s.detach().reshape(-1).tolist()
+        return q * 3 if len(q) == 1 else q
+
+    def update_adjust_parameters_value(self, **kwargs):
+        if "q_s" in kwargs:
+            v = kwargs["q_s"]
+            if self.q_s.dim() == 0:
+                if isinstance(v, (list, tuple, np.ndarray)):
+                    v = v[0]          # reference prints and uses the first element (nrmp.py:191-193)
+                self.q_s = torch.tensor(float(v), dtype=torch.float32)
+            else:
+                if not isinstance(v, (list, tuple, np.ndarray)) or len(np.array(v).flatten()) != 3:
+                    raise ValueError("q_s must be a 3-element list/array for a vector-initialised planner")
+                self.q_s = torch.tensor(np.array(v, dtype=np.float32).reshape(3, 1))
+        for k in ("p_u", "eta", "d_max", "d_min"):
+            if k in kwargs:
+                setattr(self, k, torch.tensor(float(kwargs[k]), dtype=torch.float32))
+        self._pan._push_adjust()
+
+    @property
+    def points(self):
+        return self.obstacle_points
+
+
+class _DuneFacade:
+    def __init__(self, checkpoint):
+        self.abs_checkpoint_path = checkpoint
+        self.obstacle_points = None
+        self.min_distance = inf
+
+    def train_dune(self, *a, **k):
+        raise NotImplementedError("DUNE training is outside this path (reference: neupan/blocks/dune_train.py)")
+
+    @property
+    def points(self):
+        return self.obstacle_points
+
+
+class PAN(torch.nn.Module):
+    """Drop-in for neupan.blocks.PAN (constructor: pan.py:43-56)."""
+
+    def __init__(self, receding=10, step_time=0.1, robot=None, iter_num=2, dune_max_num=100, nrmp_max_num=10,
+                 dune_checkpoint=None, iter_threshold=0.1, adjust_kwargs=None, train_kwargs=None, device=None,
+                 **kwargs):
+        super().__init__()
+        if robot is None:
+            raise ValueError("robot parameter is required and cannot be None")      # dune.py:37-38
+        adjust_kwargs = dict(adjust_kwargs or {})
+        self.robot, self.T, self.dt = robot, int(receding), float(step_time)
+        self.iter_num, self.iter_threshold = int(iter_num), float(iter_threshold)
+        self.nrmp_max_num, self.dune_max_num = int(nrmp_max_num), int(dune_max_num)
+        self.no_obs = (self.nrmp_max_num == 0 or self.dune_max_num == 0)
+        self.ro_obs = float(adjust_kwargs.get("ro_obs", 400))
+        self.bk = float(adjust_kwargs.get("bk", 0.1))
+        self.nrmp_layer = _NrmpFacade(self, adjust_kwargs.get("q_s", 1.0), adjust_kwargs.get("p_u", 1.0),
+                                      adjust_kwargs.get("eta", 10.0), adjust_kwargs.get("d_max", 1.0),
+                                      adjust_kwargs.get("d_min", 0.1), self.nrmp_max_num == 0)
+
+        if not torch.cuda.is_available():
+            raise NeupanAmdError("neupan_amd.PAN needs a ROCm GPU (torch.cuda.is_available() is False); "
+                                 "there is no CPU fallback")
+        self.device = torch.device(device if device is not None else "cuda")
+        self._lib = _lib.load()
+
+        G = np.asarray(robot.G, dtype=np.float32)
+        h = np.asarray(robot.h, dtype=np.float32).reshape(-1)
+        self.E = int(G.shape[0])
+        if robot.kinematics not in KIN:
+            raise ValueError("kinematics currently only supports acker, diff or omni")
+        cfg = NpaConfig()
+        cfg.receding, cfg.iter_num = self.T, self.iter_num
+        cfg.dune_max_num, cfg.nrmp_max_num, cfg.edge_num = self.dune_max_num, self.nrmp_max_num, self.E
+        cfg.kinematics = KIN[robot.kinematics]
+        cfg.iter_threshold = self.iter_threshold
+        cfg.step_time = self.dt
+        cfg.wheelbase = float(robot.L) if getattr(robot, "L", None) is not None else 0.0
+        sb = np.asarray(robot.speed_bound, dtype=np.float64).reshape(-1)
+        ab = np.asarray(robot.acce_bound, dtype=np.float64).reshape(-1)
+        for k in range(2):
+            cfg.speed_bound[k], cfg.acce_bound[k] = sb[k], ab[k]
+        cfg.ro_obs, cfg.bk = self.ro_obs, self.bk
+        if self.E > _lib.NPA_MAX_E:
+            raise NeupanAmdError(f"robot polygon has {self.E} edges; this build supports <= {_lib.NPA_MAX_E}")
+        for e in range(self.E):
+            cfg.G[e][0], cfg.G[e][1], cfg.h[e] = float(G[e, 0]), float(G[e, 1]), float(h[e])
+        self._cfg = cfg
+        self._fill_adjust(cfg)
+
+        wts = None
+        if not self.no_obs:
+            path = _resolve_checkpoint(dune_checkpoint)
+            sd = torch.load(path, map_location="cpu")                    # dune.py:142
+            keep = []
+            wts = NpaDuneWeights()
+
+            def arr(key, shape):
+                a = np.ascontiguousarray(sd[key].detach().to(torch.float32).numpy())
+                if tuple(a.shape) != shape:
+                    raise ValueError(f"checkpoint tensor {key} has shape {a.shape}, expected {shape}")
+                keep.append(a)
+                return a.ctypes.data
+
+            shapes = [(32, 2)] + [(32, 32)] * 4 + [(self.E, 32)]
+            for i, li in enumerate(_LINEAR):
+                wts.lin_w[i] = arr(f"MLP.{li}.weight", shapes[i])
+                wts.lin_b[i] = arr(f"MLP.{li}.bias", (shapes[i][0],))
+            for i, li in enumerate(_NORM):
+                wts.ln_w[i] = arr(f"MLP.{li}.weight", (32,))
+                wts.ln_b[i] = arr(f"MLP.{li}.bias", (32,))
+            self._wkeep = keep
+            self.dune_layer = _DuneFacade(path)
+        else:
+            self.dune_layer = None
+
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self._lib.npa_create(C.byref(cfg), C.byref(wts) if wts is not None else None, C.byref(self._h)),
+                  "npa_create")
+        self._B = 0
+        self._ws = self._state = None
+        self._last = None
+        self.printed = False
+
+    # ------------------------------------------------------------------ plumbing
+    def _fill_adjust(self, cfg):
+        q = self.nrmp_layer.q_s3()
+        for k in range(3):
+            cfg.q_s[k] = q[k]
+        cfg.p_u = float(self.nrmp_layer.p_u)
+        cfg.eta, cfg.d_max, cfg.d_min = float(self.nrmp_layer.eta), float(self.nrmp_layer.d_max), float(self.nrmp_layer.d_min)
+
+    def _push_adjust(self):
+        self._fill_adjust(self._cfg)
+        q = (C.c_float * 3)(*self.nrmp_layer.q_s3())
+        check(self._lib.npa_set_adjust(self._h, C.byref(q), self._cfg.p_u, self._cfg.eta, self._cfg.d_max,
+                                       self._cfg.d_min), "npa_set_adjust")
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                self._lib.npa_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def _buffers(self, B):
+        if B != self._B:
+            wsb = self._lib.npa_workspace_bytes(self._h, B)
+            stb = self._lib.npa_state_bytes(self._h, B)
+            self._ws = torch.empty(wsb, dtype=torch.uint8, device=self.device)
+            self._state = torch.zeros(stb, dtype=torch.uint8, device=self.device)
+            self._B = B
+        return self._ws, self._state
+
+    def reset_stop_state(self):
+        """Forget the previous iterate (the reference keeps it for the life of the PAN object)."""
+        if self._state is not None:
+            self._state.zero_()
+
+    def _dev(self, t, shape=None):
+        if t is None:
+            return None
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(np.asarray(t))
+        t = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError(f"expected tensor of shape {tuple(shape)}, got {tuple(t.shape)}")
+        return t
+
+    # ------------------------------------------------------------------ batched entry
+    def forward_batch(self, nom_s, nom_u, ref_s, ref_us, points=None, velocities=None, n_points=None):
+        """Plan B independent scenes.  Shapes: nom_s (B,3,T+1) nom_u (B,2,T) ref_s (B,3,T+1)
+        ref_us (B,T) points (B,2,N)|None velocities (B,2,N)|None n_points (B,) int32|None.
+        Returns dict(opt_s, opt_u, opt_d|None, min_distance (B,), iters (B,), nrmp_points (B,2,M)|None)."""
+        T, M = self.T, self.nrmp_max_num
+        nom_s = self._dev(nom_s)
+        B = nom_s.shape[0]
+        nom_s = self._dev(nom_s, (B, 3, T + 1))
+        nom_u, ref_s, ref_us = self._dev(nom_u, (B, 2, T)), self._dev(ref_s, (B, 3, T + 1)), self._dev(ref_us, (B, T))
+        use_pts = points is not None and not self.no_obs
+        n_stride = 0
+        if use_pts:
+            points = self._dev(points)
+            if points.dim() != 3 or points.shape[0] != B or points.shape[1] != 2:
+                raise ValueError(f"points must have shape (B,2,N), got {tuple(points.shape)}")
+            n_stride = points.shape[2]
+            if n_stride == 0:
+                use_pts = False
+        if use_pts:
+            if velocities is not None:
+                velocities = self._dev(velocities, (B, 2, n_stride))
+            if n_points is not None:
+                n_points = torch.as_tensor(n_points).to(device=self.device, dtype=torch.int32).contiguous()
+            if n_stride > self.dune_max_num and not self.printed:
+                print(f"down sample the obs points from {n_stride} to {self.dune_max_num}")   # pan.py:172
+                self.printed = True
+        else:
+            points = velocities = n_points = None
+        ws, state = self._buffers(B)
+        dev = self.device
+        out_s = torch.empty((B, 3, T + 1), dtype=torch.float32, device=dev)
+        out_u = torch.empty((B, 2, T), dtype=torch.float32, device=dev)
+        out_d = torch.empty((B, 1, max(T, 1)), dtype=torch.float32, device=dev) if M > 0 and self.dune_max_num > 0 else None
+        out_md = torch.empty((B,), dtype=torch.float32, device=dev)
+        out_it = torch.zeros((B,), dtype=torch.int32, device=dev)
+        out_np = torch.zeros((B, 2, M), dtype=torch.float32, device=dev) if not self.no_obs else None
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            check(self._lib.npa_forward_batch(
+                self._h, B, max(n_stride, 1), _ptr(nom_s), _ptr(nom_u), _ptr(ref_s), _ptr(ref_us), _ptr(points),
+                _ptr(velocities), _ptr(n_points), _ptr(out_s), _ptr(out_u), _ptr(out_d), _ptr(out_md), _ptr(out_it),
+                _ptr(out_np), _ptr(ws), ws.numel(), _ptr(state), state.numel(), C.c_void_p(stream)),
+                "npa_forward_batch")
+        # keep inputs alive until the stream has consumed them
+        self._last = dict(points=points, velocities=velocities, n_points=n_points, min_distance=out_md,
+                          nrmp_points=out_np, used_points=use_pts, hold=(nom_s, nom_u, ref_s, ref_us))
+        return dict(opt_s=out_s, opt_u=out_u, opt_d=out_d, min_distance=out_md, iters=out_it, nrmp_points=out_np)
+
+    # ------------------------------------------------------------------ reference signature
+    def forward(self, nom_s, nom_u, ref_s, ref_us, obs_points=None, point_velocities=None):
+        """pan.py:109-147 for one scene: (3,T+1),(2,T),(3,T+1),(T,),(2,N)|None,(2,N)|None ->
+        (opt_s (3,T+1), opt_u (2,T), opt_d (1,T)|None)."""
+        un = lambda t: None if t is None else (t if isinstance(t, torch.Tensor) else torch.as_tensor(np.asarray(t))).unsqueeze(0)
+        out = self.forward_batch(un(nom_s), un(nom_u), un(ref_s), un(ref_us), un(obs_points), un(point_velocities))
+        d = None if self.no_obs or out["opt_d"] is None else out["opt_d"][0]
+        return out["opt_s"][0], out["opt_u"][0], d
+
+    # ------------------------------------------------------------------ attributes of the reference class
+    @property
+    def min_distance(self):
+        if self.no_obs or self._last is None or not self._last["used_points"]:
+            return inf
+        md = self._last["min_distance"]
+        return md[0] if md.shape[0] == 1 else md
+
+    @property
+    def dune_points(self):
+        """Points DUNE considered at t=0 (after decimation), numpy (2,N) -- pan.py:255-261."""
+        if self.no_obs or self._last is None or not self._last["used_points"]:
+            return None
+        p = self._last["points"][0]
+        n = p.shape[1] if self._last["n_points"] is None else int(self._last["n_points"][0])
+        p = p[:, :n].cpu().numpy()
+        if n > self.dune_max_num:
+            p = p[:, np.linspace(0, n - 1, self.dune_max_num).astype(int)]
+        return p
+
+    @property
+    def nrmp_points(self):
+        """Points NRMP considered (first M sorted points of slice 0), numpy -- pan.py:264-269."""
+        if self.no_obs or self._last is None or not self._last["used_points"]:
+            return None
+        p = self._last["points"][0]
+        n = p.shape[1] if self._last["n_points"] is None else int(self._last["n_points"][0])
+        k = min(n, self.dune_max_num, self.nrmp_max_num)
+        return self._last["nrmp_points"][0, :, :k].cpu().numpy()
+
+    # ------------------------------------------------------------------ stage access (tests, profiling)
+    def dune_stage(self, nom_s, points, velocities=None, n_points=None):
+        T, M, E = self.T, self.nrmp_max_num, self.E
+        nom_s, points = self._dev(nom_s), self._dev(points)
+        B, N = nom_s.shape[0], points.shape[2]
+        velocities = self._dev(velocities, (B, 2, N)) if velocities is not None else None
+        if n_points is not None:
+            n_points = torch.as_tensor(n_points).to(device=self.device, dtype=torch.int32).contiguous()
+        dev = self.device
+        mu = torch.zeros((B, T + 1, M, E), dtype=torch.float32, device=dev)
+        lam = torch.zeros((B, T + 1, M, 2), dtype=torch.float32, device=dev)
+        pts = torch.zeros((B, T + 1, M, 2), dtype=torch.float32, device=dev)
+        dist = torch.zeros((B, T + 1, M), dtype=torch.float32, device=dev)
+        cnt = torch.zeros((B, T + 1), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            check(self._lib.npa_dune_stage(self._h, B, N, _ptr(nom_s), _ptr(points), _ptr(velocities), _ptr(n_points),
+                                           _ptr(mu), _ptr(lam), _ptr(pts), _ptr(dist), _ptr(cnt), C.c_void_p(stream)),
+                  "npa_dune_stage")
+        torch.cuda.synchronize(dev)
+        return dict(mu=mu, lam=lam, pts=pts, dist=dist, count=cnt)
+
+    def nrmp_stage(self, nom_s, nom_u, ref_s, ref_us, stage=None):
+        T, M = self.T, self.nrmp_max_num
+        nom_s = self._dev(nom_s)
+        B = nom_s.shape[0]
+        nom_u, ref_s, ref_us = self._dev(nom_u, (B, 2, T)), self._dev(ref_s, (B, 3, T + 1)), self._dev(ref_us, (B, T))
+        dev = self.device
+        out_s = torch.empty((B, 3, T + 1), dtype=torch.float32, device=dev)
+        out_u = torch.empty((B, 2, T), dtype=torch.float32, device=dev)
+        out_d = torch.empty((B, 1, T), dtype=torch.float32, device=dev)
+        info = torch.zeros((B, 4), dtype=torch.float64, device=dev)
+        g = (lambda k: _ptr(stage[k])) if stage is not None else (lambda k: None)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            check(self._lib.npa_nrmp_stage(self._h, B, _ptr(nom_s), _ptr(nom_u), _ptr(ref_s), _ptr(ref_us), g("mu"),
+                                           g("lam"), g("pts"), g("count"), _ptr(out_s), _ptr(out_u), _ptr(out_d),
+                                           _ptr(info), C.c_void_p(stream)), "npa_nrmp_stage")
+        torch.cuda.synchronize(dev)
+        return dict(opt_s=out_s, opt_u=out_u, opt_d=out_d, info=info)
+
+    def profile(self, enable=True):
+        check(self._lib.npa_profile_enable(self._h, 1 if enable else 0), "npa_profile_enable")
+
+    def profile_read(self):
+        a, b, n = C.c_double(), C.c_double(), C.c_int64()
+        check(self._lib.npa_profile_read(self._h, C.byref(a), C.byref(b), C.byref(n)), "npa_profile_read")
+        return dict(dune_ms=a.value, nrmp_ms=b.value, launches=n.value)
