@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py -- MPC plans/s of the MI355X-native PAN inner solver on BASELINE.json configs[1]:
+1 GPU (per rank), batch = 256 synthetic scenes, diff robot, 1000 obstacle points, T = 10,
+K = 10 PAN iterations (iter_threshold = 0 so that exactly K run), fp32 DUNE + fp64 QP.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path (npa_forward_batch) over one batch of 256 scenes per
+rank, inputs already resident in HBM; with N > 1 ranks every rank plans its own 256 scenes
+(weak scaling, no data-path collective) and the control outputs are all-gathered over
+RCCL inside the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+WORKLOAD = "diff_1k_T10_K10"
+BATCH = 256
+PEAK_FP32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
+
+
+def cpu_baseline(cfg, n_scenes, u_gpu):
+    """Oracle (CPU restatement, kind='port') timed on this box's host cores, single thread,
+    on the first n_scenes scenes of the same workload; also returns the control L2 of the GPU
+    result against it (the parity half of the metric)."""
+    from helpers import make_oracle
+    from neupan_amd.scenes import make_scene
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=1)
+    except Exception:  # pragma: no cover
+        limiter = None
+    torch.set_num_threads(1)
+    errs = []
+    t0 = time.perf_counter()
+    for b in range(n_scenes):
+        sc = make_scene(cfg, b)
+        orc = make_oracle(cfg)
+        s, u, d = orc.forward(sc["nom_s"], sc["nom_u"], sc["ref_s"], sc["ref_us"], sc["points"], sc["velocities"])
+        errs.append(float(np.linalg.norm(u_gpu[b].astype(np.float64) - u)))
+    dt = time.perf_counter() - t0
+    if limiter is not None:
+        limiter.restore_original_limits() if hasattr(limiter, "restore_original_limits") else None
+    return n_scenes / dt, errs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cpu-scenes", type=int, default=24, help="scenes timed through the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from gpu_helpers import make_gpu_pan
+    from helpers import CONFIGS
+    from neupan_amd.dist import gather_controls
+    from neupan_amd.scenes import make_batch
+
+    cfg = CONFIGS[WORKLOAD]
+    T, K, N, E = cfg.T, cfg.iter_num, cfg.n_points, 4
+    pan = make_gpu_pan(cfg, device=dev)
+    batch = make_batch(cfg, rank * BATCH, BATCH)
+    args_dev = [torch.from_numpy(batch[k]).to(dev) for k in ("nom_s", "nom_u", "ref_s", "ref_us", "points")]
+    torch.cuda.synchronize(dev)
+
+    def step():
+        pan.reset_stop_state()
+        out = pan.forward_batch(*args_dev)
+        gathered = gather_controls(out["opt_u"], dist, world)       # RCCL all-gather when world > 1
+        return out, gathered
+
+    for _ in range(args.warmup):
+        out, _g = step()
+    torch.cuda.synchronize(dev)
+    pan.profile(True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, gathered = step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    prof = pan.profile_read()
+    pan.profile(False)
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    iters = out["iters"].cpu().numpy()
+    assert (iters == K).all(), "every scene must run exactly K PAN iterations inside the timed region"
+    assert gathered.shape[0] == world * BATCH
+
+    plans = BATCH * world * args.steps
+    value = plans / elapsed
+    flops_per_launch = BATCH * (T + 1) * N * (8320 + 64 * E)
+    dune_s = prof["dune_ms"] * 1e-3
+    achieved = flops_per_launch / dune_s / 1e12 if dune_s > 0 else 0.0
+
+    line = {
+        "metric": "MPC plans/sec (node), diff robot, 1k pts, T=10, K=10; ctrl L2 vs ref",
+        "value": round(value, 1), "unit": "plans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[1]: batch=256 synthetic scenes/GPU, diff robot, 1000 pts, "
+                               "T=10, K=10 (iter_threshold=0), M=10, fp32 DUNE (MFMA) + fp64 QP",
+                   "scenes_per_gpu": BATCH, "points": N, "T": T, "K": K, "M": cfg.nrmp_max_num,
+                   "parallelism": f"scene-shard x{world}, RCCL all-gather of controls"},
+        "roofline": {"bound": "mfma", "kernel": "dune_kernel<4>", "achieved": round(achieved, 3),
+                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                     "traffic": None, "flops_per_launch": flops_per_launch,
+                     "launch_ms": round(prof["dune_ms"], 4), "launches_timed": prof["launches"],
+                     "nrmp_qp_launch_ms": round(prof["nrmp_ms"], 4)},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu:
+        u_gpu = out["opt_u"].cpu().numpy()
+        cpu_rate, errs = cpu_baseline(cfg, args.cpu_scenes, u_gpu)
+        errs = np.array(errs)
+        line["cpu_baseline"] = {"value": round(cpu_rate, 3), "unit": "plans/s", "cores": 1, "kind": "port",
+                                "sample": f"first {args.cpu_scenes} scenes of the same workload, K=10 each, "
+                                          "oracle/pan_oracle.py (numpy fp32 + fp64 IPM), 1 thread"}
+        line["parity"] = {"ctrl_l2_vs_oracle_median": float(np.median(errs)), "max": float(errs.max()),
+                          "frac_le_1e-4": float((errs <= 1e-4).mean()), "scenes": int(len(errs)),
+                          "note": "oracle = reference code restated + substituted fp64 QP solver (ECOS unavailable)"}
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -62,6 +62,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch must be imported first: its wheel bundles the HIP runtime (libamdhip64) that owns
+    # the device context and the streams we are handed; loading ours after it makes the
+    # dynamic linker bind this library to that same runtime instead of a second copy.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise NeupanAmdError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m neupan_amd.build` "

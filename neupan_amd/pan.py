@@ -217,7 +217,7 @@ class PAN(torch.nn.Module):
         except Exception:
             pass
 
-    def _buffers(self, B):
+    def _get_buffers(self, B):
         if B != self._B:
             wsb = self._lib.npa_workspace_bytes(self._h, B)
             stb = self._lib.npa_state_bytes(self._h, B)
@@ -270,7 +270,7 @@ class PAN(torch.nn.Module):
                 self.printed = True
         else:
             points = velocities = n_points = None
-        ws, state = self._buffers(B)
+        ws, state = self._get_buffers(B)
         dev = self.device
         out_s = torch.empty((B, 3, T + 1), dtype=torch.float32, device=dev)
         out_u = torch.empty((B, 2, T), dtype=torch.float32, device=dev)
