@@ -123,7 +123,10 @@ def main():
 
     plans = BATCH * world * args.steps
     value = plans / elapsed
-    flops_per_launch = BATCH * (T + 1) * N * (8320 + 64 * E)
+    # dense flops per (point x horizon slice) = 8320 + 64 E; a launch covers
+    # one sub-batch of scenes (the C API pipelines the batch in sub-batches), all T+1 slices.
+    total_flops = args.steps * K * BATCH * (T + 1) * N * (8320 + 64 * E)
+    flops_per_launch = total_flops / max(prof["launches"], 1)
     dune_s = prof["dune_ms"] * 1e-3
     achieved = flops_per_launch / dune_s / 1e12 if dune_s > 0 else 0.0
 
@@ -138,7 +141,7 @@ def main():
                    "parallelism": f"scene-shard x{world}, RCCL all-gather of controls"},
         "roofline": {"bound": "mfma", "kernel": "dune_kernel<4>", "achieved": round(achieved, 3),
                      "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                     "traffic": None, "flops_per_launch": flops_per_launch,
+                     "traffic": None, "flops_per_launch": int(flops_per_launch),
                      "launch_ms": round(prof["dune_ms"], 4), "launches_timed": prof["launches"],
                      "nrmp_qp_launch_ms": round(prof["nrmp_ms"], 4)},
     }

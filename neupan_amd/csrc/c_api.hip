@@ -5,17 +5,18 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
 #include <vector>
 
-extern "C" hipError_t npa_launch_dune(const DevParams& P, const float* wpack, int batch, int n_stride,
+extern "C" hipError_t npa_launch_dune(const DevParams& P, const float* wpack, int batch, int scene0, int n_stride,
                                       const float* cur_s, const float* points, const float* vel,
                                       const int* n_points, const int* flags, float* mu_sorted, float* lam_sorted,
                                       float* pts_sorted, float* dist_sorted, int* count, hipStream_t stream);
-extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, const float* cur_s_in, const float* cur_u_in,
-                                    const float* ref_s, const float* ref_us, const float* mu_sorted,
+extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, const float* cur_s_in,
+                                    const float* cur_u_in, const float* ref_s, const float* ref_us, const float* mu_sorted,
                                     const float* lam_sorted, const float* pts_sorted, const float* dist_sorted,
                                     const int* count, float* cur_s_out, float* cur_u_out, float* cur_d_out,
                                     float* out_s, float* out_u, float* out_d, float* out_min_distance,
@@ -37,6 +38,12 @@ struct npa_handle {
   DevParams P;
   float* wpack = nullptr;     // device
   int device = 0;
+  // sub-batch pipelining: DUNE launches stay in order on the caller's stream, each
+  // sub-batch's QP chain runs on its own helper stream so it overlaps the other
+  // sub-batches' DUNE launches (the QP is latency bound and occupies one wave per scene)
+  int n_sub = 2;
+  hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> sync_ev;
   // profiling (bench.py): HIP events on the launch stream around every stage launch
   bool prof = false;
   std::vector<EventPair> ev_dune, ev_qp;
@@ -91,7 +98,13 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
       pack[WP_B6 + e] = w->lin_b[5][e];
     }
   }
+  if (const char* env = getenv("NPA_PIPELINE")) {
+    int v = atoi(env);
+    if (v >= 1 && v <= 4) h->n_sub = v;
+  }
   hipError_t e = hipGetDevice(&h->device);
+  for (int i = 0; i < h->n_sub && h->n_sub > 1 && e == hipSuccess; ++i)
+    e = hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc(&h->wpack, WP_TOTAL * sizeof(float));
   if (e == hipSuccess) e = hipMemcpy(h->wpack, pack.data(), WP_TOTAL * sizeof(float), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -106,6 +119,8 @@ extern "C" int npa_destroy(npa_handle* h) {
   if (!h) return NPA_OK;
   for (auto& p : h->ev_dune) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto& p : h->ev_qp) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+  for (auto& ev : h->sync_ev) hipEventDestroy(ev);
+  for (int i = 0; i < 4; ++i) if (h->aux[i]) hipStreamDestroy(h->aux[i]);
   if (h->wpack) hipFree(h->wpack);
   delete h;
   return NPA_OK;
@@ -174,7 +189,7 @@ extern "C" int npa_dune_stage(npa_handle* h, int batch, int n_stride, const floa
       !dist_sorted || !count)
     return fail(NPA_E_ARG, "npa_dune_stage: bad argument");
   if (h->P.M <= 0) return fail(NPA_E_ARG, "npa_dune_stage: planner has no obstacle stage (nrmp_max_num or dune_max_num is 0)");
-  HIP_TRY(npa_launch_dune(h->P, h->wpack, batch, n_stride, nom_s, points, velocities, n_points, nullptr, mu_sorted,
+  HIP_TRY(npa_launch_dune(h->P, h->wpack, batch, 0, n_stride, nom_s, points, velocities, n_points, nullptr, mu_sorted,
                           lam_sorted, pts_sorted, dist_sorted, count, (hipStream_t)stream));
   return NPA_OK;
 }
@@ -187,7 +202,7 @@ extern "C" int npa_nrmp_stage(npa_handle* h, int batch, const float* nom_s, cons
     return fail(NPA_E_ARG, "npa_nrmp_stage: bad argument");
   if (h->P.M > 0 && (!mu_sorted || !lam_sorted || !pts_sorted || !count || !out_d))
     return fail(NPA_E_ARG, "npa_nrmp_stage: obstacle arrays required when nrmp_max_num > 0");
-  HIP_TRY(npa_launch_qp(h->P, batch, nom_s, nom_u, ref_s, ref_us, mu_sorted, lam_sorted, pts_sorted, nullptr, count,
+  HIP_TRY(npa_launch_qp(h->P, batch, 0, nom_s, nom_u, ref_s, ref_us, mu_sorted, lam_sorted, pts_sorted, nullptr, count,
                         out_s, out_u, out_d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                         qp_info, (hipStream_t)stream));
   return NPA_OK;
@@ -221,20 +236,47 @@ extern "C" int npa_forward_batch(npa_handle* h, int batch, int n_stride, const f
   HIP_TRY(hipMemsetAsync(flags, 0, (size_t)batch * 4 * sizeof(int), stream));
   HIP_TRY(hipMemsetAsync(count, 0, (size_t)batch * (T + 1) * sizeof(int), stream));
 
-  for (int k = 0; k < P.K; ++k) {
-    if (dune) {
-      EventPair* ev = next_event(h, h->ev_dune, h->n_dune);
-      if (ev) HIP_TRY(hipEventRecord(ev->a, stream));
-      HIP_TRY(npa_launch_dune(P, h->wpack, batch, n_stride, cur_s, points, velocities, n_points, flags, mu, lam, pts,
-                              dist, count, stream));
-      if (ev) HIP_TRY(hipEventRecord(ev->b, stream));
-    }
-    EventPair* ev = next_event(h, h->ev_qp, h->n_qp);
-    if (ev) HIP_TRY(hipEventRecord(ev->a, stream));
-    HIP_TRY(npa_launch_qp(P, batch, cur_s, cur_u, ref_s, ref_us, mu, lam, pts, dist, count, cur_s, cur_u, cur_d, out_s,
-                          out_u, out_d, out_min_distance, out_iters, out_nrmp_points, flags, (float*)state, nullptr,
-                          stream));
-    if (ev) HIP_TRY(hipEventRecord(ev->b, stream));
+  // sub-batches [lo_i, hi_i): DUNE(i,k) on `stream` in (k, i) order, QP(i,k) on aux[i]
+  int nsub = (h->n_sub > 1 && dune && batch >= 16 * h->n_sub) ? h->n_sub : 1;
+  auto lo = [&](int i) { return (int)((long long)batch * i / nsub); };
+  const size_t need_ev = (size_t)2 * nsub * P.K + 1;
+  while (h->sync_ev.size() < need_ev) {
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    h->sync_ev.push_back(ev);
   }
+  auto ev_d = [&](int i, int k) { return h->sync_ev[1 + (size_t)2 * (k * nsub + i)]; };
+  auto ev_q = [&](int i, int k) { return h->sync_ev[1 + (size_t)2 * (k * nsub + i) + 1]; };
+  if (nsub > 1) {
+    HIP_TRY(hipEventRecord(h->sync_ev[0], stream));                 // inputs staged
+    for (int i = 0; i < nsub; ++i) HIP_TRY(hipStreamWaitEvent(h->aux[i], h->sync_ev[0], 0));
+  }
+  for (int k = 0; k < P.K; ++k) {
+    for (int i = 0; i < nsub; ++i) {
+      const int s0 = lo(i), nb = lo(i + 1) - lo(i);
+      hipStream_t qs = nsub > 1 ? h->aux[i] : stream;
+      if (dune) {
+        if (nsub > 1 && k > 0) HIP_TRY(hipStreamWaitEvent(stream, ev_q(i, k - 1), 0));
+        EventPair* ev = next_event(h, h->ev_dune, h->n_dune);
+        if (ev) HIP_TRY(hipEventRecord(ev->a, stream));
+        HIP_TRY(npa_launch_dune(P, h->wpack, nb, s0, n_stride, cur_s, points, velocities, n_points, flags, mu, lam,
+                                pts, dist, count, stream));
+        if (ev) HIP_TRY(hipEventRecord(ev->b, stream));
+        if (nsub > 1) {
+          HIP_TRY(hipEventRecord(ev_d(i, k), stream));
+          HIP_TRY(hipStreamWaitEvent(qs, ev_d(i, k), 0));
+        }
+      }
+      EventPair* ev = next_event(h, h->ev_qp, h->n_qp);
+      if (ev) HIP_TRY(hipEventRecord(ev->a, qs));
+      HIP_TRY(npa_launch_qp(P, nb, s0, cur_s, cur_u, ref_s, ref_us, mu, lam, pts, dist, count, cur_s, cur_u, cur_d,
+                            out_s, out_u, out_d, out_min_distance, out_iters, out_nrmp_points, flags, (float*)state,
+                            nullptr, qs));
+      if (ev) HIP_TRY(hipEventRecord(ev->b, qs));
+      if (nsub > 1) HIP_TRY(hipEventRecord(ev_q(i, k), qs));
+    }
+  }
+  if (nsub > 1)
+    for (int i = 0; i < nsub; ++i) HIP_TRY(hipStreamWaitEvent(stream, ev_q(i, P.K - 1), 0));   // join
   return NPA_OK;
 }

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(DUNE_THREADS) void dune_kernel(
     DevParams P, const float* __restrict__ wpack, int n_stride, const float* __restrict__ cur_s,
     const float* __restrict__ points, const float* __restrict__ vel, const int* __restrict__ n_points,
     const int* __restrict__ flags, float* __restrict__ mu_sorted, float* __restrict__ lam_sorted,
-    float* __restrict__ pts_sorted, float* __restrict__ dist_sorted, int* __restrict__ count) {
+    float* __restrict__ pts_sorted, float* __restrict__ dist_sorted, int* __restrict__ count, int scene0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* vec = smem;                       // [11][32]
   float* w6 = vec + 11 * 32;               // [8][32]
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(DUNE_THREADS) void dune_kernel(
   int* sel = reinterpret_cast<int*>(b6 + 8);            // [NPA_MAX_M]
   unsigned* dkey = reinterpret_cast<unsigned*>(sel + NPA_MAX_M);   // [n_use]
 
-  const int t = blockIdx.x, b = blockIdx.y;
+  const int t = blockIdx.x, b = blockIdx.y + scene0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, hf = lane >> 5;
   const int T = P.T, M = P.M;
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(DUNE_THREADS) void dune_kernel(
 }
 
 // host-side launcher (called from c_api.hip)
-extern "C" hipError_t npa_launch_dune(const DevParams& P, const float* wpack, int batch, int n_stride,
+extern "C" hipError_t npa_launch_dune(const DevParams& P, const float* wpack, int batch, int scene0, int n_stride,
                                       const float* cur_s, const float* points, const float* vel,
                                       const int* n_points, const int* flags, float* mu_sorted, float* lam_sorted,
                                       float* pts_sorted, float* dist_sorted, int* count, hipStream_t stream) {
@@ -301,7 +301,7 @@ extern "C" hipError_t npa_launch_dune(const DevParams& P, const float* wpack, in
                  ((size_t)(n_use_max > 0 ? n_use_max : 1) * sizeof(unsigned) + 15) / 16 * 16;
 #define LAUNCH(EE)                                                                                         \
   hipLaunchKernelGGL(dune_kernel<EE>, grid, block, shmem, stream, P, wpack, n_stride, cur_s, points, vel,  \
-                     n_points, flags, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count)
+                     n_points, flags, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count, scene0)
   switch (P.E) {
     case 3: LAUNCH(3); break;
     case 4: LAUNCH(4); break;

@@ -13,117 +13,136 @@
 //        - eta sum d + ro/2 sum_{t,j} max(0, -(fa_tj . s_xy(t+1) - fb_tj - d_t))^2
 //   s.t. s(t+1) = A_t s(t) + B_t u(t) + C_t, s(0) = nom_s(0), |u| <= speed, |du| <= acce,
 //        max(d_min,0) <= d <= d_max.
-// Solved on x = (u, d): states eliminated through the linearised dynamics
-// (s(t) = Phi_t u + c_t), hinge rows carried through their stationarity e = lam_f/ro (no
-// epigraph variables), Mehrotra predictor-corrector, dense Cholesky of the 3T x 3T reduced
-// KKT matrix.  The algorithm is transliterated in oracle/condensed_ipm.py, which the tests
-// check against the uncondensed fp64 oracle and HiGHS.
 //
-// Why one wave: the solve is a serial chain of small dense steps (latency bound); scenes are
-// independent, so parallelism comes from the batch -- one 64-lane wave per scene, rows of
-// the KKT system owned by lanes, matrices in LDS, cross-lane broadcast by v_readlane.
+// Algorithm (transliterated in oracle/condensed_ipm.py, which the tests check against the
+// uncondensed fp64 oracle and HiGHS): states eliminated through the linearised dynamics
+// (s(t+1) = Phi_t u + c_t), hinge rows carried through their own stationarity condition
+// e = lam_f/ro (no epigraph variables), Mehrotra predictor-corrector on x = (u, d).  Each
+// Newton system is reduced once more by eliminating d (its block of the KKT matrix is
+// diagonal), which leaves a dense SPD 2T x 2T system in u:
+//      K' = H + C_u' D C_u + sum_t Phi_xy(t)' S'_t Phi_xy(t),   S'_t = S_t - v_t v_t'/kappa_t
+// factored by a left-looking Cholesky with one matrix row per lane.
+//
+// Why one wave per scene: the solve is a serial chain of small dense steps (latency bound);
+// scenes are independent, so throughput comes from the batch.  Matrices live in LDS with odd
+// leading dimensions (conflict-free row-per-lane access), cross-lane broadcast is v_readlane,
+// wave reductions are DPP (quad_perm / row_mirror) + 4 readlanes, and every division in a
+// serial loop is replaced by a reciprocal computed once per iteration.
 #include "pan_common.h"
+#include <cstdlib>
 
 #define QP_THREADS 64
 #define QP_MAX_IT 40
 
-__device__ __forceinline__ double shfl_xor_f64(double v, int off) { return __shfl_xor(v, off, 64); }
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += shfl_xor_f64(v, off);
-  return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = fmax(v, shfl_xor_f64(v, off));
-  return v;
-}
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = fmin(v, shfl_xor_f64(v, off));
-  return v;
-}
+// ---- small device helpers -------------------------------------------------------------------
 __device__ __forceinline__ double readlane_f64(double v, int l) {
   unsigned lo = __builtin_amdgcn_readlane((unsigned)__double2loint(v), l);
   unsigned hi = __builtin_amdgcn_readlane((unsigned)__double2hiint(v), l);
   return __hiloint2double((int)hi, (int)lo);
 }
-#define LSYNC() __syncthreads()
-
-struct CRow {
-  int ia, ib;       // x index with coefficient sa, second index (or -1) with coefficient -sa
-  double sa;
-  double bound;
-  bool act;
-};
-
-// linear inequality rows  C x <= c  (robot.py:232-233, nrmp.py:375-376 + nonneg nrmp.py:264)
-__device__ __forceinline__ CRow crow(const DevParams& P, int i) {
-  const int T = P.T, nu = 2 * T;
-  CRow r;
-  r.ib = -1;
-  if (i < 4 * T) {                       // |u| <= speed_bound
-    int v = i >> 1;
-    r.ia = v; r.sa = (i & 1) ? -1.0 : 1.0; r.bound = P.speed_bound[v & 1];
-  } else if (i < 8 * T - 4) {            // |u(t+1)-u(t)| <= acce_bound
-    int q = i - 4 * T, v = q >> 1;
-    r.ia = v + 2; r.ib = v; r.sa = (q & 1) ? -1.0 : 1.0; r.bound = P.acce_bound[v & 1];
-  } else {                               // max(d_min,0) <= d <= d_max
-    int q = i - (8 * T - 4), t = q >> 1;
-    r.ia = nu + t; r.sa = (q & 1) ? -1.0 : 1.0;
-    r.bound = (q & 1) ? -fmax((double)P.d_min, 0.0) : (double)P.d_max;
-  }
-  r.act = isfinite(r.bound);
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+struct OpSum { __device__ static double f(double a, double b) { return a + b; } };
+struct OpMax { __device__ static double f(double a, double b) { return fmax(a, b); } };
+struct OpMin { __device__ static double f(double a, double b) { return fmin(a, b); } };
+// full-wave reduction; every lane returns the same bits (the combination tree is symmetric)
+template <class Op>
+__device__ __forceinline__ double wave_reduce(double v) {
+  v = Op::f(v, dpp_f64<0xB1>(v));     // quad_perm [1,0,3,2]
+  v = Op::f(v, dpp_f64<0x4E>(v));     // quad_perm [2,3,0,1]
+  v = Op::f(v, dpp_f64<0x141>(v));    // row_half_mirror
+  v = Op::f(v, dpp_f64<0x140>(v));    // row_mirror -> every lane holds its 16-lane row total
+  double a = readlane_f64(v, 0), b = readlane_f64(v, 16), c = readlane_f64(v, 32), d = readlane_f64(v, 48);
+  return Op::f(Op::f(a, b), Op::f(c, d));
+}
+__device__ __forceinline__ double fast_rcp(double x) {      // ~1 ulp; x finite, nonzero
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
   return r;
 }
+__device__ __forceinline__ double fast_rsqrt(double x) {    // x > 0
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  return y;
+}
+#define LSYNC() __syncthreads()
 
+// TT > 0: horizon known at compile time -> the reduced KKT matrix, its Cholesky factor (rows and
+// columns) and the columns of Phi live in registers, one matrix row per lane, every loop over
+// the horizon is unrolled and all broadcasts are v_readlane (no LDS round trip on the serial
+// chain).  TT == 0: generic horizon, same algorithm with the matrices in LDS.
+template <int TT>
 __global__ __launch_bounds__(QP_THREADS) void nrmp_qp_kernel(
-    DevParams P, const float* cur_s_in, const float* cur_u_in,
-    const float* __restrict__ ref_s, const float* __restrict__ ref_us, const float* __restrict__ mu_sorted,
-    const float* __restrict__ lam_sorted, const float* __restrict__ pts_sorted,
-    const float* __restrict__ dist_sorted, const int* __restrict__ count, float* cur_s_out,
-    float* cur_u_out, float* __restrict__ cur_d_out, float* __restrict__ out_s,
+    DevParams P, const float* cur_s_in, const float* cur_u_in, const float* __restrict__ ref_s,
+    const float* __restrict__ ref_us, const float* __restrict__ mu_sorted, const float* __restrict__ lam_sorted,
+    const float* __restrict__ pts_sorted, const float* __restrict__ dist_sorted, const int* __restrict__ count,
+    float* cur_s_out, float* cur_u_out, float* __restrict__ cur_d_out, float* __restrict__ out_s,
     float* __restrict__ out_u, float* __restrict__ out_d, float* __restrict__ out_min_distance,
     int* __restrict__ out_iters, float* __restrict__ out_nrmp_points, int* __restrict__ flags,
-    float* __restrict__ state, double* __restrict__ qp_info) {
+    float* __restrict__ state, double* __restrict__ qp_info, int scene0) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int b = blockIdx.x, lane = threadIdx.x;
+  const int b = blockIdx.x + scene0, lane = threadIdx.x;
   if (flags && flags[b * 4 + 0]) return;
 
-  const int T = P.T, M = P.M, E = P.E, nu = 2 * T;
+  const int T = TT > 0 ? TT : P.T, M = P.M, E = P.E, nu = 2 * T;
+  constexpr int NU = TT > 0 ? 2 * TT : 1, T3 = TT > 0 ? 3 * TT : 1;
   const bool obs = M > 0;
-  const int n = obs ? 3 * T : 2 * T;
-  const int mc = obs ? 10 * T - 4 : 8 * T - 4;
+  const int mcu = 8 * T - 4;                  // rows on u: 4T speed + 4T-4 rate
   const int mf = obs ? T * M : 0;
-  const int ld = n + 1;                       // padded leading dimension of K
-  const double ro = P.ro_obs;
+  const int ldp = nu + 1, ldk = nu + 1;       // odd leading dimensions
+  const int npair = nu * (nu + 1) / 2;
+  const double ro = P.ro_obs, iro = 1.0 / ro;
+  const double dmin0 = fmax((double)P.d_min, 0.0), dmaxv = (double)P.d_max;
 
   // ---- LDS carve (doubles) -----------------------------------------------------------
-  double* Phi = sm;                           // [T][3][nu]   s(t+1) = Phi[t] u + cv[t]
-  double* cv = Phi + (size_t)T * 3 * nu;      // [T][3]
-  double* Hm = cv + T * 3;                    // [nu][nu]     constant Hessian block
-  double* Km = Hm + (size_t)nu * nu;          // [n][ld]
-  double* g = Km + (size_t)n * ld;            // [n]
-  double* x = g + n;                          // [n]
-  double* xbest = x + n;                      // [n]
-  double* dx = xbest + n;                     // [n]
-  double* vecn = dx + n;                      // [n] scratch (rhs)
-  double* Abc = vecn + n;                     // [T][14]: A02 A12 | B(3x2) | C(3) | pad
-  double* sxy = Abc + T * 14;                 // [T][2]  scratch: Phi_xy u (+c)
-  double* St = sxy + T * 2;                   // [T][6]  S00 S01 S11 v0 v1 sigma
-  double* zt = St + T * 6;                    // [T][3]  z0 z1 zsig
-  double* fa = zt + T * 3;                    // [mf][2]
-  double* ff = fa + (size_t)mf * 2;           // [mf]   f = fb - fa . c_xy(t+1)
-  double* lf = ff + mf;                       // [mf]
+  double* Phi = sm;                           // [T][3][ldp]  s(t+1) = Phi[t] u + cv[t]
+  double* Yt = Phi + (size_t)T * 3 * ldp;     // [T][2][ldp]  S'_t Phi_xy(t)
+  double* Hm = Yt + (size_t)T * 2 * ldp;      // [nu][ldk]    constant Hessian block (lower)
+  double* Km = Hm + (size_t)nu * ldk;         // [nu][ldk]
+  double* cv = Km + (size_t)nu * ldk;         // [T][3]
+  double* lin = cv + T * 3;                   // [T][3]  state-cost gradient at u = 0
+  double* s3 = lin + T * 3;                   // [T][3]  Phi x   /  Phi dx
+  double* q3 = s3 + T * 3;                    // [T][3]  operand of Phi'
+  double* Abc = q3 + T * 3;                   // [T][12]
+  double* St = Abc + T * 12;                  // [T][8]  S'00 S'01 S'11 v0 v1 sigma 1/kappa r1d
+  double* xu = St + T * 8;                    // [nu]
+  double* xd = xu + nu;                       // [T]
+  double* xbest = xd + T;                     // [nu+T]
+  double* dxu = xbest + nu + T;               // [nu]
+  double* dxd = dxu + nu;                     // [T]
+  double* invd = dxd + T;                     // [nu]   1/L_kk
+  double* rhsd = invd + nu;                   // [T]
+  double* fa0 = rhsd + T;                     // [mf] ...
+  double* fa1 = fa0 + mf;
+  double* ff = fa1 + mf;
+  double* lf = ff + mf;
   double* wf = lf + mf;
   double* dlf = wf + mf;
   double* dwf = dlf + mf;
-  double* tf = dwf + mf;                      // scratch per hinge row
-  double* lc = tf + mf;                       // [mc]
-  double* wc = lc + mc;
-  double* dlc = wc + mc;
-  double* dwc = dlc + mc;
-  double* tc = dwc + mc;
+  double* r3 = dwf + mf;
+  double* iwf = r3 + mf;                      // 1/(wf + lf/ro)
+  double* lc = iwf + mf;                      // [mcu] ...
+  double* wc = lc + mcu;
+  double* dlc = wc + mcu;
+  double* dwc = dlc + mcu;
+  double* r2 = dwc + mcu;
+  double* iwc = r2 + mcu;                     // 1/wc
+  double* cb = iwc + mcu;                     // bound (or 0 when inactive)
+  double* ld_ = cb + mcu;                     // [2T] d rows: index 2t (d<=dmax), 2t+1 (-d<=-dmin0)
+  double* wd = ld_ + 2 * T;
+  double* dld = wd + 2 * T;
+  double* dwd = dld + 2 * T;
+  double* r2d = dwd + 2 * T;
+  double* iwd = r2d + 2 * T;
+  unsigned char* pa = reinterpret_cast<unsigned char*>(iwd + 2 * T);   // [npair]
+  unsigned char* pc = pa + ((npair + 7) & ~7);
+  unsigned char* cact = pc + ((npair + 7) & ~7);                       // [mcu] 1 = bound finite
 
   const float* s_in = cur_s_in + (size_t)b * 3 * (T + 1);
   const float* u_in = cur_u_in + (size_t)b * 2 * T;
@@ -134,7 +153,7 @@ __global__ __launch_bounds__(QP_THREADS) void nrmp_qp_kernel(
   for (int t = lane; t < T; t += QP_THREADS) {
     float phi = s_in[2 * (T + 1) + t], v = u_in[t], psi = u_in[T + t];
     const float dt32 = P.dt32;
-    double* o = Abc + t * 14;
+    double* o = Abc + t * 12;
     float A02 = 0.f, A12 = 0.f, B00, B01 = 0.f, B10, B11 = 0.f, B20 = 0.f, B21 = 0.f, C0, C1, C2 = 0.f;
     if (P.kin == 2) {                      // omni: phi := u[1]
       double sp = sin((double)psi), cp = cos((double)psi);
@@ -164,20 +183,34 @@ __global__ __launch_bounds__(QP_THREADS) void nrmp_qp_kernel(
     o[2] = B00; o[3] = B01; o[4] = B10; o[5] = B11; o[6] = B20; o[7] = B21;
     o[8] = C0; o[9] = C1; o[10] = C2;
   }
+  // pair table (a >= c), activity of the u rows, their bounds
+  for (int p = lane; p < npair; p += QP_THREADS) {
+    int a = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
+    while ((a + 1) * (a + 2) / 2 <= p) ++a;
+    while (a * (a + 1) / 2 > p) --a;
+    pa[p] = (unsigned char)a; pc[p] = (unsigned char)(p - a * (a + 1) / 2);
+  }
+  for (int i = lane; i < mcu; i += QP_THREADS) {
+    int v = (i < 4 * T) ? (i >> 1) : ((i - 4 * T) >> 1);
+    double bd = (i < 4 * T) ? P.speed_bound[v & 1] : P.acce_bound[v & 1];
+    bool act = isfinite(bd);
+    cact[i] = act ? 1 : 0;
+    cb[i] = act ? bd : 0.0;
+  }
   LSYNC();
 
   // ---- Phi recursion: Phi[t] = A_t Phi[t-1] + [B_t at cols 2t,2t+1]; A = I + e0 A02 e2' + e1 A12 e2'
   for (int t = 0; t < T; ++t) {
-    const double* o = Abc + t * 14;
-    double* Pt = Phi + (size_t)t * 3 * nu;
-    const double* Pp = Pt - 3 * nu;
+    const double* o = Abc + t * 12;
+    double* Pt = Phi + (size_t)t * 3 * ldp;
+    const double* Pp = Pt - 3 * ldp;
     for (int c = lane; c < nu; c += QP_THREADS) {
       double p0 = 0, p1 = 0, p2 = 0;
-      if (t > 0) { p0 = Pp[c]; p1 = Pp[nu + c]; p2 = Pp[2 * nu + c]; }
+      if (t > 0) { p0 = Pp[c]; p1 = Pp[ldp + c]; p2 = Pp[2 * ldp + c]; }
       double n0 = p0 + o[0] * p2, n1 = p1 + o[1] * p2, n2 = p2;
       if (c == 2 * t) { n0 += o[2]; n1 += o[4]; n2 += o[6]; }
       if (c == 2 * t + 1) { n0 += o[3]; n1 += o[5]; n2 += o[7]; }
-      Pt[c] = n0; Pt[nu + c] = n1; Pt[2 * nu + c] = n2;
+      Pt[c] = n0; Pt[ldp + c] = n1; Pt[2 * ldp + c] = n2;
     }
     if (lane == 0) {
       double c0, c1, c2;
@@ -190,42 +223,35 @@ __global__ __launch_bounds__(QP_THREADS) void nrmp_qp_kernel(
     LSYNC();
   }
 
-  // ---- cost: H (constant block), g --------------------------------------------------------
-  const double qs0 = P.q_s[0], qs1 = P.q_s[1], qs2 = P.q_s[2];
+  // ---- cost: H (constant block), state-cost gradient at u=0 ---------------------------------
   const double m2 = (P.kin == 2) ? 0.0 : 1.0;            // omni: theta row not in the state cost
-  const double W0 = 2.0 * qs0 * qs0 + P.bk, W1 = 2.0 * qs1 * qs1 + P.bk, W2 = 2.0 * m2 * qs2 * qs2 + P.bk;
+  const double W0 = 2.0 * (double)P.q_s[0] * (double)P.q_s[0] + P.bk;
+  const double W1 = 2.0 * (double)P.q_s[1] * (double)P.q_s[1] + P.bk;
+  const double W2 = 2.0 * m2 * (double)P.q_s[2] * (double)P.q_s[2] + P.bk;
   const double pu = P.p_u;
-  for (int idx = lane; idx < nu * nu; idx += QP_THREADS) {
-    int a = idx / nu, c = idx - a * nu;
+  for (int p = lane; p < npair; p += QP_THREADS) {
+    int a = pa[p], c = pc[p];
     double acc = 0;
-    int t0 = (a > c ? a : c) >> 1;
-    for (int t = t0; t < T; ++t) {
-      const double* Pt = Phi + (size_t)t * 3 * nu;
-      acc += W0 * Pt[a] * Pt[c] + W1 * Pt[nu + a] * Pt[nu + c] + W2 * Pt[2 * nu + a] * Pt[2 * nu + c];
+    for (int t = a >> 1; t < T; ++t) {
+      const double* Pt = Phi + (size_t)t * 3 * ldp;
+      acc += W0 * Pt[a] * Pt[c] + W1 * Pt[ldp + a] * Pt[ldp + c] + W2 * Pt[2 * ldp + a] * Pt[2 * ldp + c];
     }
     if (a == c && !(a & 1)) acc += 2.0 * pu * pu;
-    Hm[idx] = acc;
+    Hm[a * ldk + c] = acc;
+    Hm[c * ldk + a] = acc;
   }
-  for (int a = lane; a < n; a += QP_THREADS) {
-    double acc = 0;
-    if (a < nu) {
-      for (int t = a >> 1; t < T; ++t) {
-        const double* Pt = Phi + (size_t)t * 3 * nu;
-        const double* c = cv + t * 3;
-        // gamma_a = q_s * ref_s is an fp32 product in the reference (nrmp.py:158)
-        double r0 = (double)__fmul_rn(P.q_s[0], rs[t + 1]);
-        double r1 = (double)__fmul_rn(P.q_s[1], rs[(T + 1) + t + 1]);
-        double r2 = (double)__fmul_rn(P.q_s[2], rs[2 * (T + 1) + t + 1]);
-        double l0 = 2.0 * qs0 * (qs0 * c[0] - r0) + P.bk * (c[0] - (double)s_in[t + 1]);
-        double l1 = 2.0 * qs1 * (qs1 * c[1] - r1) + P.bk * (c[1] - (double)s_in[(T + 1) + t + 1]);
-        double l2 = 2.0 * m2 * qs2 * (qs2 * c[2] - r2) + P.bk * (c[2] - (double)s_in[2 * (T + 1) + t + 1]);
-        acc += Pt[a] * l0 + Pt[nu + a] * l1 + Pt[2 * nu + a] * l2;
-      }
-      if (!(a & 1)) acc += -2.0 * pu * (double)__fmul_rn(P.p_u, rus[a >> 1]);
-    } else {
-      acc = -(double)P.eta;
-    }
-    g[a] = acc;
+  // fast path: column `lane` of Phi (all T steps, 3 state rows) in registers
+  double phic[T3];
+  if constexpr (TT > 0) {
+#pragma unroll
+    for (int q = 0; q < T3; ++q) phic[q] = (lane < NU) ? Phi[(size_t)q * ldp + lane] : 0.0;
+  }
+  for (int q = lane; q < 3 * T; q += QP_THREADS) {
+    int t = q / 3, k = q - 3 * t;
+    double qk = P.q_s[k], mk = (k == 2) ? m2 : 1.0, c = cv[q];
+    // gamma_a = q_s * ref_s is an fp32 product in the reference (nrmp.py:158)
+    double r = (double)__fmul_rn(P.q_s[k], rs[k * (T + 1) + t + 1]);
+    lin[q] = 2.0 * mk * qk * (qk * c - r) + P.bk * (c - (double)s_in[k * (T + 1) + t + 1]);
   }
 
   // ---- hinge rows: fa = lam', fb = lam'.p + mu'.h in fp32 (nrmp.py:244-259), slice t+1 ----
@@ -240,284 +266,416 @@ __global__ __launch_bounds__(QP_THREADS) void nrmp_qp_kernel(
       for (int e = 0; e < E; ++e) mh = fmaf(mu_sorted[row * E + e], P.h[e], mh);
       a0 = l0; a1 = l1; fb = (double)__fadd_rn(tmp, mh);
     }
-    fa[i * 2] = a0; fa[i * 2 + 1] = a1;
+    fa0[i] = a0; fa1[i] = a1;
     ff[i] = fb - (a0 * cv[t * 3] + a1 * cv[t * 3 + 1]);
   }
 
-  // ---- starting point ------------------------------------------------------------------
-  for (int a = lane; a < n; a += QP_THREADS)
-    x[a] = (a < nu) ? 0.0 : 0.5 * (fmax((double)P.d_min, 0.0) + (double)P.d_max);
-  LSYNC();
-  for (int a = lane; a < n; a += QP_THREADS) xbest[a] = x[a];
-  for (int i = lane; i < mc; i += QP_THREADS) {
-    CRow r = crow(P, i);
-    double cx = r.sa * x[r.ia] - (r.ib >= 0 ? r.sa * x[r.ib] : 0.0);
-    lc[i] = r.act ? 1.0 : 0.0;
-    wc[i] = r.act ? fmax(r.bound - cx, 1.0) : 1.0;
+  // ---- starting point: u = 0, d mid-range, unit multipliers, slacks >= 1 --------------------
+  const double d0 = 0.5 * (dmin0 + dmaxv);
+  for (int a = lane; a < nu; a += QP_THREADS) { xu[a] = 0.0; xbest[a] = 0.0; }
+  for (int t = lane; t < T; t += QP_THREADS) {
+    xd[t] = d0; xbest[nu + t] = d0; dxd[t] = 0.0;
+    ld_[2 * t] = 1.0; ld_[2 * t + 1] = 1.0;
+    wd[2 * t] = fmax(dmaxv - d0, 1.0); wd[2 * t + 1] = fmax(d0 - dmin0, 1.0);
   }
-  for (int i = lane; i < mf; i += QP_THREADS) {
-    int t = i / M;
-    lf[i] = 1.0;
-    wf[i] = fmax(-x[nu + t] - ff[i] + 1.0 / ro, 1.0);     // F x - f + lf/ro at u = 0
-  }
-  double gmax = 0, cmax = 0;
-  for (int a = lane; a < n; a += QP_THREADS) gmax = fmax(gmax, fabs(g[a]));
-  for (int i = lane; i < mc; i += QP_THREADS) { CRow r = crow(P, i); if (r.act) cmax = fmax(cmax, fabs(r.bound)); }
-  const double scale_d = 1.0 + wave_max(gmax), scale_p = 1.0 + wave_max(cmax);
+  double cmax = fmax(fabs(dmaxv), fabs(dmin0));
   int m_act = 0;
-  for (int i = lane; i < mc; i += QP_THREADS) m_act += crow(P, i).act ? 1 : 0;
-  const double m_tot = fmax(wave_sum((double)m_act) + (double)mf, 1.0);
+  for (int i = lane; i < mcu; i += QP_THREADS) {
+    bool act = cact[i];
+    lc[i] = act ? 1.0 : 0.0;
+    wc[i] = act ? fmax(cb[i], 1.0) : 1.0;
+    dlc[i] = 0; dwc[i] = 0;
+    if (act) { cmax = fmax(cmax, fabs(cb[i])); ++m_act; }
+  }
+  LSYNC();
+  for (int i = lane; i < mf; i += QP_THREADS) {
+    lf[i] = 1.0;
+    wf[i] = fmax(-d0 - ff[i] + iro, 1.0);     // F x - f + lf/ro at u = 0
+  }
+  double gmax = obs ? (double)P.eta : 0.0;
+  // g_u = Phi' lin - 2 p_u gamma_b on the speed entries
+  for (int a = lane; a < nu; a += QP_THREADS) {
+    double acc = 0;
+    for (int t = a >> 1; t < T; ++t) {
+      const double* Pt = Phi + (size_t)t * 3 * ldp;
+      acc += Pt[a] * lin[t * 3] + Pt[ldp + a] * lin[t * 3 + 1] + Pt[2 * ldp + a] * lin[t * 3 + 2];
+    }
+    if (!(a & 1)) acc += -2.0 * pu * (double)__fmul_rn(P.p_u, rus[a >> 1]);
+    gmax = fmax(gmax, fabs(acc));
+  }
+  const double scale_d = 1.0 + wave_reduce<OpMax>(gmax), scale_p = 1.0 + wave_reduce<OpMax>(cmax);
+  const double m_tot = fmax(wave_reduce<OpSum>((double)m_act) + (double)mf + (obs ? 2.0 * T : 0.0), 1.0);
+  const double inv_m = 1.0 / m_tot;
+  const double pub = (lane < nu && !(lane & 1)) ? -2.0 * pu * (double)__fmul_rn(P.p_u, rus[lane >> 1]) : 0.0;
   LSYNC();
 
   double best_merit = 1e300, last_mu = 0;
   int best_it = 0, stall = 0, status = 0, it = 0;
 
+  // y = Phi v for all three state rows: out3[t][k] = sum_a Phi[t][k][a] v[a]
+  auto phi_mul = [&](const double* v, double* out3) {
+    for (int q = lane; q < 3 * T; q += QP_THREADS) {
+      int t = q / 3, k = q - 3 * t;
+      const double* Pr = Phi + ((size_t)t * 3 + k) * ldp;
+      double a0 = 0, a1 = 0;
+      if constexpr (TT > 0) {          // Phi[t][k][c] is stored as 0 beyond column 2t+1
+#pragma unroll
+        for (int c = 0; c < NU; c += 2) { a0 = fma(Pr[c], v[c], a0); a1 = fma(Pr[c + 1], v[c + 1], a1); }
+      } else {
+        const int cend = 2 * (t + 1);
+        for (int c = 0; c < cend; c += 2) { a0 = fma(Pr[c], v[c], a0); a1 = fma(Pr[c + 1], v[c + 1], a1); }
+      }
+      out3[q] = a0 + a1;
+    }
+  };
+  // w_a = sum_{t,k} Phi[t][k][a] in3[t][k]   (returned for a = lane, 0 for lane >= nu)
+  auto phi_tmul = [&](const double* in3) -> double {
+    double acc = 0;
+    if (lane < nu) {
+      const int a = lane;
+      for (int t = a >> 1; t < T; ++t) {
+        const double* Pt = Phi + (size_t)t * 3 * ldp;
+        acc += Pt[a] * in3[t * 3] + Pt[ldp + a] * in3[t * 3 + 1] + Pt[2 * ldp + a] * in3[t * 3 + 2];
+      }
+    }
+    return acc;
+  };
+  // fast path: the same product with the operand (q0,q1,q2)[t] held by lane t
+  auto phi_tmul_reg = [&](double q0, double q1, double q2, bool use2) -> double {
+    double acc0 = 0, acc1 = 0;
+    if constexpr (TT > 0) {
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        acc0 = fma(phic[3 * t], readlane_f64(q0, t), acc0);
+        acc1 = fma(phic[3 * t + 1], readlane_f64(q1, t), acc1);
+        if (use2) acc0 = fma(phic[3 * t + 2], readlane_f64(q2, t), acc0);
+      }
+    }
+    return acc0 + acc1;
+  };
+  // C_u' y for variable a (y indexed like the u rows)
+  auto ct_mul = [&](const double* y, int a) -> double {
+    int t = a >> 1;
+    double acc = y[2 * a] - y[2 * a + 1];
+    if (t >= 1) { int q = 4 * T + 2 * (a - 2); acc += y[q] - y[q + 1]; }
+    if (t <= T - 2) { int q = 4 * T + 2 * a; acc -= y[q] - y[q + 1]; }
+    return acc;
+  };
+
   for (it = 0; it <= QP_MAX_IT; ++it) {
-    // ---- residuals ---------------------------------------------------------------------
-    // s_xy(t+1) - c = Phi_xy[t] u
-    for (int q = lane; q < 2 * T; q += QP_THREADS) {
-      int t = q >> 1, k = q & 1;
-      const double* Pr = Phi + (size_t)t * 3 * nu + k * nu;
-      double acc = 0;
-      for (int c = 0; c < 2 * (t + 1); ++c) acc += Pr[c] * x[c];
-      sxy[q] = acc;
-    }
+    // ================= residuals =================
+    phi_mul(xu, s3);
     LSYNC();
-    double gap = 0, r3max = 0, r2max = 0;
-    for (int i = lane; i < mf; i += QP_THREADS) {       // tf := r3 = F x - f + lf/ro - wf
+    double gap = 0, rpmax = 0;
+    for (int i = lane; i < mf; i += QP_THREADS) {
       int t = i / M;
-      double r3 = fa[i * 2] * sxy[2 * t] + fa[i * 2 + 1] * sxy[2 * t + 1] - x[nu + t] - ff[i] + lf[i] / ro - wf[i];
-      tf[i] = r3;
-      r3max = fmax(r3max, fabs(r3));
-      gap += lf[i] * wf[i];
+      double l = lf[i], w = wf[i];
+      double r = fa0[i] * s3[t * 3] + fa1[i] * s3[t * 3 + 1] - xd[t] - ff[i] + l * iro - w;
+      r3[i] = r;
+      iwf[i] = fast_rcp(w + l * iro);
+      rpmax = fmax(rpmax, fabs(r));
+      gap += l * w;
     }
-    for (int i = lane; i < mc; i += QP_THREADS) {       // tc := r2 = C x + wc - c
-      CRow r = crow(P, i);
-      double r2 = 0;
-      if (r.act) {
-        double cx = r.sa * x[r.ia] - (r.ib >= 0 ? r.sa * x[r.ib] : 0.0);
-        r2 = cx + wc[i] - r.bound;
+    for (int i = lane; i < mcu; i += QP_THREADS) {
+      double r = 0;
+      if (cact[i]) {
+        int v = (i < 4 * T) ? (i >> 1) : ((i - 4 * T) >> 1);
+        double sg = (i & 1) ? -1.0 : 1.0;
+        double cx = (i < 4 * T) ? sg * xu[v] : sg * (xu[v + 2] - xu[v]);
+        r = cx + wc[i] - cb[i];
         gap += lc[i] * wc[i];
       }
-      tc[i] = r2;
-      r2max = fmax(r2max, fabs(r2));
+      r2[i] = r;
+      iwc[i] = fast_rcp(wc[i]);
+      rpmax = fmax(rpmax, fabs(r));
+    }
+    for (int i = lane; i < 2 * T && obs; i += QP_THREADS) {
+      int t = i >> 1;
+      double r = (i & 1) ? (-xd[t] + wd[i] + dmin0) : (xd[t] + wd[i] - dmaxv);
+      r2d[i] = r;
+      iwd[i] = fast_rcp(wd[i]);
+      rpmax = fmax(rpmax, fabs(r));
+      gap += ld_[i] * wd[i];
     }
     LSYNC();
-    // z_t = sum_j lf fa ; zsig = sum_j lf     (for F' lf)
-    for (int t = lane; t < T && obs; t += QP_THREADS) {
-      double z0 = 0, z1 = 0, zs = 0;
-      for (int j = 0; j < M; ++j) { int i = t * M + j; z0 += lf[i] * fa[i * 2]; z1 += lf[i] * fa[i * 2 + 1]; zs += lf[i]; }
-      zt[t * 3] = z0; zt[t * 3 + 1] = z1; zt[t * 3 + 2] = zs;
-    }
-    LSYNC();
-    double r1max = 0;
-    for (int a = lane; a < n; a += QP_THREADS) {        // vecn := r1 = H x + g + C' lc - F' lf
-      double acc = g[a];
-      if (a < nu) {
-        for (int c = 0; c < nu; ++c) acc += Hm[a * nu + c] * x[c];
-        if (obs)
-          for (int t = a >> 1; t < T; ++t) {
-            const double* Pt = Phi + (size_t)t * 3 * nu;
-            acc -= Pt[a] * zt[t * 3] + Pt[nu + a] * zt[t * 3 + 1];
-          }
-        int t = a >> 1;
-        acc += lc[2 * a] - lc[2 * a + 1];                                   // speed rows
-        if (t >= 1) { int q = 4 * T + 2 * (a - 2); acc += lc[q] - lc[q + 1]; }       // rate rows, +x_a
-        if (t <= T - 2) { int q = 4 * T + 2 * a; acc -= lc[q] - lc[q + 1]; }         // rate rows, -x_a
-      } else {
-        int t = a - nu;
-        acc += zt[t * 3 + 2];
-        int q = 8 * T - 4 + 2 * t;
-        acc += lc[q] - lc[q + 1];
+    // per-step sums over the M hinge rows (lane = t)
+    double r1dmax = 0;
+    double S0r = 0, S1r = 0, S2r = 0, v0r = 0, v1r = 0, ikr = 0, r1dr = 0, q0r = 0, q1r = 0, q2r = 0;
+    for (int t = lane; t < T; t += QP_THREADS) {
+      double z0 = 0, z1 = 0, zs = 0, s00 = 0, s01 = 0, s11 = 0, v0 = 0, v1 = 0, sg = 0;
+#pragma unroll 5
+      for (int j = 0; j < M; ++j) {
+        int i = t * M + j;
+        double l = lf[i], a0 = fa0[i], a1 = fa1[i];
+        double D = l * iwf[i];
+        z0 += l * a0; z1 += l * a1; zs += l;
+        s00 += D * a0 * a0; s01 += D * a0 * a1; s11 += D * a1 * a1; v0 += D * a0; v1 += D * a1; sg += D;
       }
-      vecn[a] = acc;
-      r1max = fmax(r1max, fabs(acc));
+      double kap = sg, r1d = 0;
+      if (obs) {
+        kap += ld_[2 * t] * iwd[2 * t] + ld_[2 * t + 1] * iwd[2 * t + 1];
+        r1d = -(double)P.eta + ld_[2 * t] - ld_[2 * t + 1] + zs;       // g_d + C'lam - F'lam
+      }
+      double ik = obs ? fast_rcp(kap) : 0.0;
+      double* S = St + t * 8;
+      S[0] = s00 - v0 * v0 * ik; S[1] = s01 - v0 * v1 * ik; S[2] = s11 - v1 * v1 * ik;
+      S[3] = v0; S[4] = v1; S[5] = sg; S[6] = ik; S[7] = r1d;
+      // operand of Phi' for r1_u:  W .* (Phi x) + lin - [z; 0]
+      q3[t * 3 + 0] = W0 * s3[t * 3 + 0] + lin[t * 3 + 0] - z0;
+      q3[t * 3 + 1] = W1 * s3[t * 3 + 1] + lin[t * 3 + 1] - z1;
+      q3[t * 3 + 2] = W2 * s3[t * 3 + 2] + lin[t * 3 + 2];
+      r1dmax = fmax(r1dmax, fabs(r1d));
+      S0r = S[0]; S1r = S[1]; S2r = S[2]; v0r = v0; v1r = v1; ikr = ik; r1dr = r1d;
+      q0r = q3[t * 3 + 0]; q1r = q3[t * 3 + 1]; q2r = q3[t * 3 + 2];
     }
-    const double mu = wave_sum(gap) / m_tot;
-    const double merit = fmax(fmax(wave_max(r1max) / scale_d, wave_max(fmax(r2max, r3max)) / scale_p), mu);
+    LSYNC();
+    double r1u = (TT > 0) ? phi_tmul_reg(q0r, q1r, q2r, true) : phi_tmul(q3);   // lane a < nu
+    if (lane < nu) {
+      const int a = lane;
+      if (!(a & 1)) r1u += 2.0 * pu * pu * xu[a] + pub;
+      r1u += ct_mul(lc, a);
+    }
+    const double mu = wave_reduce<OpSum>(gap) * inv_m;
+    const double r1max = wave_reduce<OpMax>(fmax(lane < nu ? fabs(r1u) : 0.0, r1dmax));
+    const double rpm = wave_reduce<OpMax>(rpmax);
+    const double merit = fmax(fmax(r1max / scale_d, rpm / scale_p), mu);
     last_mu = mu;
     if (!(merit == merit) || !(merit < 1e300)) { status = 2; break; }
     if (merit < best_merit) {
       best_merit = merit; best_it = it; stall = 0;
-      for (int a = lane; a < n; a += QP_THREADS) xbest[a] = x[a];
+      for (int a = lane; a < nu; a += QP_THREADS) xbest[a] = xu[a];
+      for (int t = lane; t < T; t += QP_THREADS) xbest[nu + t] = xd[t];
     } else {
       ++stall;
     }
     if (merit <= 1e-12 || stall >= 3 || it == QP_MAX_IT || mu < 1e-15) break;
-    LSYNC();
 
-    // ---- reduced KKT matrix K = H + C' Dc C + F' Df F ------------------------------------
-    for (int t = lane; t < T && obs; t += QP_THREADS) {
-      double s00 = 0, s01 = 0, s11 = 0, v0 = 0, v1 = 0, sg = 0;
-      for (int j = 0; j < M; ++j) {
-        int i = t * M + j;
-        double D = lf[i] / (wf[i] + lf[i] / ro);
-        double a0 = fa[i * 2], a1 = fa[i * 2 + 1];
-        s00 += D * a0 * a0; s01 += D * a0 * a1; s11 += D * a1 * a1; v0 += D * a0; v1 += D * a1; sg += D;
-      }
-      double* S = St + t * 6;
-      S[0] = s00; S[1] = s01; S[2] = s11; S[3] = v0; S[4] = v1; S[5] = sg;
-    }
-    LSYNC();
-    for (int idx = lane; idx < n * n; idx += QP_THREADS) {
-      int a = idx / n, c = idx - a * n;
-      if (c > a) continue;                           // lower triangle
-      double acc = 0;
-      if (a < nu) {                                  // uu block
-        acc = Hm[a * nu + c];
-        if (obs)
-          for (int t = a >> 1; t < T; ++t) {
-            const double* Pt = Phi + (size_t)t * 3 * nu;
-            const double* S = St + t * 6;
-            double ya = S[0] * Pt[a] + S[1] * Pt[nu + a], yb = S[1] * Pt[a] + S[2] * Pt[nu + a];
-            acc += ya * Pt[c] + yb * Pt[nu + c];
-          }
-        if (a == c) {
-          int t = a >> 1;
-          double dsum = lc[2 * a] / wc[2 * a] + lc[2 * a + 1] / wc[2 * a + 1];
-          if (t >= 1) { int q = 4 * T + 2 * (a - 2); dsum += lc[q] / wc[q] + lc[q + 1] / wc[q + 1]; }
-          if (t <= T - 2) { int q = 4 * T + 2 * a; dsum += lc[q] / wc[q] + lc[q + 1] / wc[q + 1]; }
-          acc += dsum;
-        } else if (a == c + 2) {                     // rate rows couple u_k(t+1), u_k(t)
-          int q = 4 * T + 2 * c;
-          acc -= lc[q] / wc[q] + lc[q + 1] / wc[q + 1];
-        }
-      } else {
-        int t = a - nu;
-        if (c < nu) {                                // du block: -Phi_xy[t][:,c] . v_t
-          if ((c >> 1) <= t) {
-            const double* Pt = Phi + (size_t)t * 3 * nu;
-            acc = -(Pt[c] * St[t * 6 + 3] + Pt[nu + c] * St[t * 6 + 4]);
-          }
-        } else if (c == a) {
-          int q = 8 * T - 4 + 2 * t;
-          acc = St[t * 6 + 5] + lc[q] / wc[q] + lc[q + 1] / wc[q + 1];
-        }
-      }
-      Km[a * ld + c] = acc;
-    }
-    LSYNC();
-
-    // ---- Cholesky K = L L' (left-looking, lane = row) -------------------------------------
+    // ================= reduced KKT matrix, Cholesky =================
+    double arow[NU], bcol[NU];          // fast path: row `lane` of K' -> L, column `lane` of L
+    double myinv = 1.0;
     bool chol_ok = true;
-    for (int k = 0; k < n; ++k) {
-      const double* Lk = Km + (size_t)k * ld;
-      double piv = 0;
-      for (int i = k + lane; i < n; i += QP_THREADS) {
-        const double* Li = Km + (size_t)i * ld;
-        double acc0 = Li[k], acc1 = 0;
-        int p = 0;
-        for (; p + 1 < k; p += 2) { acc0 -= Li[p] * Lk[p]; acc1 -= Li[p + 1] * Lk[p + 1]; }
-        if (p < k) acc0 -= Li[p] * Lk[p];
-        double v = acc0 + acc1;
-        if (i == k) piv = v;
-        Km[(size_t)i * ld + k] = v;                  // raw column, scaled below
+    if constexpr (TT > 0) {
+      // Y[tk][c] = S'_t[k][:] Phi_xy[t][:, c]  (lane = column c), staged in LDS for broadcast reads
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        double s0 = readlane_f64(S0r, t), s1 = readlane_f64(S1r, t), s2 = readlane_f64(S2r, t);
+        if (lane < NU) {
+          Yt[(size_t)(2 * t) * NU + lane] = s0 * phic[3 * t] + s1 * phic[3 * t + 1];
+          Yt[(size_t)(2 * t + 1) * NU + lane] = s1 * phic[3 * t] + s2 * phic[3 * t + 1];
+        }
       }
-      piv = readlane_f64(piv, 0);                    // row k is owned by lane 0 of this sweep
+      const int ar = lane < NU ? lane : 0;
+#pragma unroll
+      for (int c = 0; c < NU; ++c) arow[c] = Hm[ar * ldk + c];
+      // band terms of C_u' D C_u for this row
+      double dsum = 0, doff = 0;
+      {
+        const int a = ar, t = a >> 1;
+        dsum = lc[2 * a] * iwc[2 * a] + lc[2 * a + 1] * iwc[2 * a + 1];
+        if (t >= 1) { int q = 4 * T + 2 * (a - 2); double v = lc[q] * iwc[q] + lc[q + 1] * iwc[q + 1]; dsum += v; doff = v; }
+        if (t <= T - 2) { int q = 4 * T + 2 * a; dsum += lc[q] * iwc[q] + lc[q + 1] * iwc[q + 1]; }
+      }
+      LSYNC();
+      // K'[a][c] += sum_{t,k} Phi[t][k][a] Y[t][k][c]; Y[tk][c] = 0 for c > 2t+1
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const double pv = phic[3 * t + k];
+          const double* Y = Yt + (size_t)(2 * t + k) * NU;
+#pragma unroll
+          for (int c = 0; c < 2 * t + 2; ++c) arow[c] = fma(pv, Y[c], arow[c]);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < NU; ++c) {
+        arow[c] += (c == lane) ? dsum : 0.0;
+        arow[c] -= (c + 2 == lane) ? doff : 0.0;
+      }
+      // right-looking Cholesky, row i in lane i: after step k, arow[k] = L[i][k]
+#pragma unroll
+      for (int k = 0; k < NU; ++k) {
+        double piv = readlane_f64(arow[k], k);
+        if (!(piv > 0.0)) chol_ok = false;
+        double rinv = fast_rsqrt(piv);
+        double l = arow[k] * rinv;
+        arow[k] = l;
+        if (lane == k) myinv = rinv;
+#pragma unroll
+        for (int j = k + 1; j < NU; ++j) arow[j] = fma(-l, readlane_f64(l, j), arow[j]);
+      }
+      // columns of L through LDS (transpose): bcol[k] = L[k][lane]
+      if (lane < NU) {
+#pragma unroll
+        for (int c = 0; c < NU; ++c) Km[(size_t)lane * ldk + c] = arow[c];
+      }
+      LSYNC();
+#pragma unroll
+      for (int k = 0; k < NU; ++k) bcol[k] = Km[(size_t)k * ldk + ar];
+    } else {
+    for (int q = lane; q < 2 * T * nu; q += QP_THREADS) {        // Y[t][k][c] = S'_t[k][:] Phi_xy[t][:, c]
+      int tk = q / nu, c = q - tk * nu, t = tk >> 1, k = tk & 1;
+      const double* Pt = Phi + (size_t)t * 3 * ldp;
+      const double* S = St + t * 8;
+      Yt[(size_t)tk * ldp + c] = (c <= 2 * t + 1) ? S[k] * Pt[c] + S[k + 1] * Pt[ldp + c] : 0.0;
+    }
+    LSYNC();
+    for (int p = lane; p < npair; p += QP_THREADS) {
+      int a = pa[p], c = pc[p];
+      double acc0 = Hm[a * ldk + c], acc1 = 0;
+#pragma unroll 4
+      for (int t = a >> 1; t < T; ++t) {
+        const double* Pt = Phi + (size_t)t * 3 * ldp;
+        const double* Y = Yt + (size_t)t * 2 * ldp;
+        acc0 = fma(Pt[a], Y[c], acc0);
+        acc1 = fma(Pt[ldp + a], Y[ldp + c], acc1);
+      }
+      double acc = acc0 + acc1;
+      if (a == c) {
+        int t = a >> 1;
+        double dsum = lc[2 * a] * iwc[2 * a] + lc[2 * a + 1] * iwc[2 * a + 1];
+        if (t >= 1) { int q = 4 * T + 2 * (a - 2); dsum += lc[q] * iwc[q] + lc[q + 1] * iwc[q + 1]; }
+        if (t <= T - 2) { int q = 4 * T + 2 * a; dsum += lc[q] * iwc[q] + lc[q + 1] * iwc[q + 1]; }
+        acc += dsum;
+      } else if (a == c + 2) {                       // rate rows couple u_k(t+1), u_k(t)
+        int q = 4 * T + 2 * c;
+        acc -= lc[q] * iwc[q] + lc[q + 1] * iwc[q + 1];
+      }
+      Km[a * ldk + c] = acc;
+    }
+    LSYNC();
+    // Cholesky K' = L L' (left-looking, lane = row, matrix in LDS)
+    for (int k = 0; k < nu; ++k) {
+      double v = 0;
+      if (lane >= k && lane < nu) {
+        const double* Li = Km + (size_t)lane * ldk;
+        const double* Lk = Km + (size_t)k * ldk;
+        double a0 = Li[k], a1 = 0;
+        int p = 0;
+#pragma unroll 4
+        for (; p + 1 < k; p += 2) { a0 = fma(-Li[p], Lk[p], a0); a1 = fma(-Li[p + 1], Lk[p + 1], a1); }
+        if (p < k) a0 = fma(-Li[p], Lk[p], a0);
+        v = a0 + a1;
+      }
+      double piv = readlane_f64(v, k);
       if (!(piv > 0.0)) { chol_ok = false; break; }
-      double inv = 1.0 / sqrt(piv);
+      double rinv = fast_rsqrt(piv);
+      if (lane >= k && lane < nu) Km[(size_t)lane * ldk + k] = v * rinv;       // L[k][k] = sqrt(piv)
+      if (lane == k) invd[k] = rinv;
       LSYNC();
-      for (int i = k + lane; i < n; i += QP_THREADS) Km[(size_t)i * ld + k] *= inv;   // L[k][k] = sqrt(piv)
-      LSYNC();
+    }
+    if (chol_ok) myinv = invd[lane < nu ? lane : 0];
     }
     if (!chol_ok) { status = 3; break; }
 
-    // ---- predictor / corrector -----------------------------------------------------------
-    double sigma_mu = 0;
-    double alpha = 1.0;
+    // ================= predictor / corrector =================
+    double sigma_mu = 0, alpha = 1.0;
     for (int pass = 0; pass < 2; ++pass) {
-      // per-row terms of the rhs:  tcw = (lc r2 - r4c)/wc ; tfw = (r4f + lf r3)/(wf + lf/ro)
-      // pass 0: r4 = lam w ; pass 1: r4 = lam w + dw dl - sigma mu.  r2 in tc, r3 in tf.
-      for (int t = lane; t < T && obs; t += QP_THREADS) {
+      // per-row weights of the rhs, staged in dwf/dwc/dwd (overwritten by the directions below)
+      //   tfw = (r4f + lf r3)/(wf + lf/ro) ; tcw = (lc r2 - r4c)/wc ; r4 = lam w [+ dw dl - sigma mu]
+      for (int i = lane; i < mf; i += QP_THREADS) {
+        double r4 = lf[i] * wf[i] + (pass ? dwf[i] * dlf[i] - sigma_mu : 0.0);
+        dwf[i] = (r4 + lf[i] * r3[i]) * iwf[i];
+      }
+      for (int i = lane; i < mcu; i += QP_THREADS) {
+        double r4 = lc[i] * wc[i] + (pass ? dwc[i] * dlc[i] - sigma_mu : 0.0);
+        dwc[i] = cact[i] ? (lc[i] * r2[i] - r4) * iwc[i] : 0.0;
+      }
+      for (int i = lane; i < 2 * T && obs; i += QP_THREADS) {
+        double r4 = ld_[i] * wd[i] + (pass ? dwd[i] * dld[i] - sigma_mu : 0.0);
+        dwd[i] = (ld_[i] * r2d[i] - r4) * iwd[i];
+      }
+      LSYNC();
+      double pq0 = 0, pq1 = 0, rdr = 0;
+      for (int t = lane; t < T; t += QP_THREADS) {
         double z0 = 0, z1 = 0, zs = 0;
-        for (int j = 0; j < M; ++j) {
-          int i = t * M + j;
-          double r4 = lf[i] * wf[i] + (pass ? dwf[i] * dlf[i] - sigma_mu : 0.0);
-          double w = (r4 + lf[i] * tf[i]) / (wf[i] + lf[i] / ro);
-          z0 += w * fa[i * 2]; z1 += w * fa[i * 2 + 1]; zs += w;
+#pragma unroll 5
+        for (int j = 0; j < M; ++j) { int i = t * M + j; double w = dwf[i]; z0 += w * fa0[i]; z1 += w * fa1[i]; zs += w; }
+        double rd = 0;
+        if (obs) rd = -r1dr - (dwd[2 * t] - dwd[2 * t + 1]) + zs;          // rhs of the d rows
+        double e = rd * ikr;                                                // rhs_d / kappa
+        rdr = rd;
+        pq0 = -(z0 - v0r * e);
+        pq1 = -(z1 - v1r * e);
+        if constexpr (TT == 0) { q3[t * 3 + 0] = pq0; q3[t * 3 + 1] = pq1; q3[t * 3 + 2] = 0.0; }
+      }
+      double rr;
+      if constexpr (TT > 0) {
+        rr = phi_tmul_reg(pq0, pq1, 0.0, false);
+        if (lane < nu) rr += -r1u - ct_mul(dwc, lane);
+        // forward substitution L y = rhs, backward L' dx = y; lane i owns entry i, L in registers
+#pragma unroll
+        for (int k = 0; k < NU; ++k) {
+          double yk = readlane_f64(rr * myinv, k);
+          rr = (lane == k) ? yk : ((lane > k) ? fma(-arow[k], yk, rr) : rr);
         }
-        zt[t * 3] = z0; zt[t * 3 + 1] = z1; zt[t * 3 + 2] = zs;
-      }
-      LSYNC();
-      auto tcw = [&](int q) -> double {
-        double wq = wc[q];
-        double r4 = lc[q] * wq + (pass ? dwc[q] * dlc[q] - sigma_mu : 0.0);
-        return (lc[q] == 0.0 && !crow(P, q).act) ? 0.0 : (lc[q] * tc[q] - r4) / wq;
-      };
-      double rr = 0;                                 // rhs entry owned by this lane (row = lane; n <= 64)
-      if (lane < n) {
-        const int a = lane;
-        double acc = -vecn[a];
-        if (a < nu) {
-          if (obs)
-            for (int t = a >> 1; t < T; ++t) {         // - F' tfw, F row = [fa.Phi_xy, -e_t]
-              const double* Pt = Phi + (size_t)t * 3 * nu;
-              acc -= Pt[a] * zt[t * 3] + Pt[nu + a] * zt[t * 3 + 1];
-            }
-          int t = a >> 1;
-          acc -= tcw(2 * a) - tcw(2 * a + 1);
-          if (t >= 1) { int q = 4 * T + 2 * (a - 2); acc -= tcw(q) - tcw(q + 1); }
-          if (t <= T - 2) { int q = 4 * T + 2 * a; acc += tcw(q) - tcw(q + 1); }
-        } else {
-          int t = a - nu;
-          acc += zt[t * 3 + 2];
-          int q = 8 * T - 4 + 2 * t;
-          acc -= tcw(q) - tcw(q + 1);
+#pragma unroll
+        for (int k = NU - 1; k >= 0; --k) {
+          double xk = readlane_f64(rr * myinv, k);
+          rr = (lane == k) ? xk : ((lane < k) ? fma(-bcol[k], xk, rr) : rr);
         }
-        rr = acc;
+      } else {
+        LSYNC();
+        rr = phi_tmul(q3);
+        if (lane < nu) rr += -r1u - ct_mul(dwc, lane);
+        for (int k = 0; k < nu; ++k) {
+          double yk = readlane_f64(rr * myinv, k);
+          if (lane == k) rr = yk;
+          if (lane > k && lane < nu) rr = fma(-Km[(size_t)lane * ldk + k], yk, rr);
+        }
+        for (int k = nu - 1; k >= 0; --k) {
+          double xk = readlane_f64(rr * myinv, k);
+          if (lane == k) rr = xk;
+          if (lane < k) rr = fma(-Km[(size_t)k * ldk + lane], xk, rr);
+        }
       }
-      // forward substitution L y = rhs (lane i owns entry i; y_k broadcast by v_readlane)
-      for (int k = 0; k < n; ++k) {
-        double yk = readlane_f64(rr, k) / Km[(size_t)k * ld + k];
-        if (lane == k) rr = yk;
-        if (lane > k && lane < n) rr -= Km[(size_t)lane * ld + k] * yk;
-      }
-      // backward substitution L' dx = y
-      for (int k = n - 1; k >= 0; --k) {
-        double xk = readlane_f64(rr, k) / Km[(size_t)k * ld + k];
-        if (lane == k) rr = xk;
-        if (lane < k) rr -= Km[(size_t)k * ld + lane] * xk;
-      }
-      if (lane < n) dx[lane] = rr;
+      if (lane < nu) dxu[lane] = rr;
       LSYNC();
-      // directions of the multipliers / slacks, and the step length
-      for (int q = lane; q < 2 * T; q += QP_THREADS) {
-        int t = q >> 1, k = q & 1;
-        const double* Pr = Phi + (size_t)t * 3 * nu + k * nu;
-        double acc = 0;
-        for (int c = 0; c < 2 * (t + 1); ++c) acc += Pr[c] * dx[c];
-        sxy[q] = acc;
-      }
+      phi_mul(dxu, s3);
       LSYNC();
+      for (int t = lane; t < T && obs; t += QP_THREADS)
+        dxd[t] = (rdr + v0r * s3[t * 3] + v1r * s3[t * 3 + 1]) * ikr;
+      LSYNC();
+      // directions of multipliers / slacks and the step to the boundary
       double amax = 1.0, gap_aff = 0;
       for (int i = lane; i < mf; i += QP_THREADS) {
         int t = i / M;
-        double Fdx = fa[i * 2] * sxy[2 * t] + fa[i * 2 + 1] * sxy[2 * t + 1] - dx[nu + t];
-        double r4 = lf[i] * wf[i] + (pass ? dwf[i] * dlf[i] - sigma_mu : 0.0);
-        double dl = -(r4 + lf[i] * tf[i] + lf[i] * Fdx) / (wf[i] + lf[i] / ro);
-        double dw = Fdx + dl / ro + tf[i];
-        if (dl < 0) amax = fmin(amax, -lf[i] / dl);
-        if (dw < 0) amax = fmin(amax, -wf[i] / dw);
+        double l = lf[i], w = wf[i];
+        double Fdx = fa0[i] * s3[t * 3] + fa1[i] * s3[t * 3 + 1] - dxd[t];
+        double dl = -(dwf[i] + l * Fdx * iwf[i]);             // -(r4 + l r3 + l Fdx)/(w + l/ro)
+        double dw = Fdx + dl * iro + r3[i];
+        if (dl < 0) amax = fmin(amax, -l * fast_rcp(dl));
+        if (dw < 0) amax = fmin(amax, -w * fast_rcp(dw));
         dlf[i] = dl; dwf[i] = dw;
       }
-      for (int i = lane; i < mc; i += QP_THREADS) {
-        CRow r = crow(P, i);
+      for (int i = lane; i < mcu; i += QP_THREADS) {
         double dl = 0, dw = 0;
-        if (r.act) {
-          double Cdx = r.sa * dx[r.ia] - (r.ib >= 0 ? r.sa * dx[r.ib] : 0.0);
-          double r4 = lc[i] * wc[i] + (pass ? dwc[i] * dlc[i] - sigma_mu : 0.0);
-          dw = -tc[i] - Cdx;
-          dl = (-r4 - lc[i] * dw) / wc[i];
-          if (dl < 0) amax = fmin(amax, -lc[i] / dl);
-          if (dw < 0) amax = fmin(amax, -wc[i] / dw);
+        if (cact[i]) {
+          int v = (i < 4 * T) ? (i >> 1) : ((i - 4 * T) >> 1);
+          double sg = (i & 1) ? -1.0 : 1.0;
+          double Cdx = (i < 4 * T) ? sg * dxu[v] : sg * (dxu[v + 2] - dxu[v]);
+          dl = dwc[i] + lc[i] * Cdx * iwc[i];                   // (lc r2 - r4 + lc Cdx)/wc
+          dw = -r2[i] - Cdx;
+          if (dl < 0) amax = fmin(amax, -lc[i] * fast_rcp(dl));
+          if (dw < 0) amax = fmin(amax, -wc[i] * fast_rcp(dw));
         }
         dlc[i] = dl; dwc[i] = dw;
       }
-      amax = wave_min(amax);
+      for (int i = lane; i < 2 * T && obs; i += QP_THREADS) {
+        int t = i >> 1;
+        double Cdx = (i & 1) ? -dxd[t] : dxd[t];
+        double dl = dwd[i] + ld_[i] * Cdx * iwd[i];
+        double dw = -r2d[i] - Cdx;
+        if (dl < 0) amax = fmin(amax, -ld_[i] * fast_rcp(dl));
+        if (dw < 0) amax = fmin(amax, -wd[i] * fast_rcp(dw));
+        dld[i] = dl; dwd[i] = dw;
+      }
+      amax = wave_reduce<OpMin>(amax);
       if (pass == 0) {
         for (int i = lane; i < mf; i += QP_THREADS) gap_aff += (lf[i] + amax * dlf[i]) * (wf[i] + amax * dwf[i]);
-        for (int i = lane; i < mc; i += QP_THREADS) gap_aff += (lc[i] + amax * dlc[i]) * (wc[i] + amax * dwc[i]);
-        double mu_aff = wave_sum(gap_aff) / m_tot;
+        for (int i = lane; i < mcu; i += QP_THREADS) gap_aff += (lc[i] + amax * dlc[i]) * (wc[i] + amax * dwc[i]);
+        for (int i = lane; i < 2 * T && obs; i += QP_THREADS) gap_aff += (ld_[i] + amax * dld[i]) * (wd[i] + amax * dwd[i]);
+        double mu_aff = wave_reduce<OpSum>(gap_aff) * inv_m;
         double sg = mu_aff / mu;
         sigma_mu = sg * sg * sg * mu;
       } else {
@@ -525,9 +683,11 @@ __global__ __launch_bounds__(QP_THREADS) void nrmp_qp_kernel(
       }
       LSYNC();
     }
-    for (int a = lane; a < n; a += QP_THREADS) x[a] += alpha * dx[a];
+    for (int a = lane; a < nu; a += QP_THREADS) xu[a] += alpha * dxu[a];
+    for (int t = lane; t < T && obs; t += QP_THREADS) xd[t] += alpha * dxd[t];
     for (int i = lane; i < mf; i += QP_THREADS) { lf[i] += alpha * dlf[i]; wf[i] += alpha * dwf[i]; }
-    for (int i = lane; i < mc; i += QP_THREADS) { lc[i] += alpha * dlc[i]; wc[i] += alpha * dwc[i]; }
+    for (int i = lane; i < mcu; i += QP_THREADS) { lc[i] += alpha * dlc[i]; wc[i] += alpha * dwc[i]; }
+    for (int i = lane; i < 2 * T && obs; i += QP_THREADS) { ld_[i] += alpha * dld[i]; wd[i] += alpha * dwd[i]; }
     LSYNC();
   }
   LSYNC();
@@ -535,22 +695,16 @@ __global__ __launch_bounds__(QP_THREADS) void nrmp_qp_kernel(
   // ---- write the solution (fp64 -> fp32, nrmp.py:145-148) ------------------------------------
   float* so = cur_s_out + (size_t)b * 3 * (T + 1);
   float* uo = cur_u_out + (size_t)b * 2 * T;
+  phi_mul(xbest, s3);
+  LSYNC();
+  float* stage = reinterpret_cast<float*>(Km);       // cur_s_out may alias cur_s_in
   for (int q = lane; q < 3 * (T + 1); q += QP_THREADS) {
     int k = q / (T + 1), t = q - k * (T + 1);
-    double v;
-    if (t == 0) v = s_in[k * (T + 1)];
-    else {
-      const double* Pr = Phi + (size_t)(t - 1) * 3 * nu + k * nu;
-      v = cv[(t - 1) * 3 + k];
-      for (int c = 0; c < 2 * t; ++c) v += Pr[c] * xbest[c];
-    }
-    float fv = (float)v;
-    // staged in LDS: cur_s_out may alias cur_s_in, which other lanes are still reading
-    reinterpret_cast<float*>(Km)[q] = fv;
+    stage[q] = (t == 0) ? s_in[k * (T + 1)] : (float)(s3[(t - 1) * 3 + k] + cv[(t - 1) * 3 + k]);
   }
   LSYNC();
   for (int q = lane; q < 3 * (T + 1); q += QP_THREADS) {
-    float fv = reinterpret_cast<float*>(Km)[q];
+    float fv = stage[q];
     so[q] = fv;
     if (out_s) out_s[(size_t)b * 3 * (T + 1) + q] = fv;
   }
@@ -571,7 +725,7 @@ __global__ __launch_bounds__(QP_THREADS) void nrmp_qp_kernel(
   }
 
   // ---- per-forward outputs of the last executed iteration -------------------------------------
-  const int cnt0 = count ? count[(size_t)b * (T + 1)] : 0;
+  const int cnt0 = (obs && count) ? count[(size_t)b * (T + 1)] : 0;
   if (out_min_distance && lane == 0)
     out_min_distance[b] = (obs && cnt0 > 0) ? dist_sorted[(size_t)b * (T + 1) * M] : __builtin_inff();
   if (out_nrmp_points && obs)
@@ -582,21 +736,26 @@ __global__ __launch_bounds__(QP_THREADS) void nrmp_qp_kernel(
 
   // ---- stop criterion (pan.py:215-243); state persists across forward calls ---------------------
   if (state && flags) {
-    const size_t nsf = npa_state_floats(T, M > 0 ? M : 1, E);
+    const int Ms = M > 0 ? M : 1;
+    const size_t nsf = npa_state_floats(T, Ms, E);
     float* st = state + (size_t)b * nsf;
     float* ps = st;
     float* pu_ = ps + 3 * (T + 1);
     float* pmu = pu_ + 2 * T;
-    float* plam = pmu + (size_t)(T + 1) * (M > 0 ? M : 1) * E;
-    int* pint = reinterpret_cast<int*>(plam + (size_t)(T + 1) * (M > 0 ? M : 1) * 2);
+    float* plam = pmu + (size_t)(T + 1) * Ms * E;
+    int* pint = reinterpret_cast<int*>(plam + (size_t)(T + 1) * Ms * 2);
     const int valid = pint[0], prev_n = pint[1];
     const bool have = obs && cnt0 > 0;
     double acc_s = 0, acc_u = 0, acc_mu = 0, acc_lam = 0;
     int eff = 0;
     if (valid) {
       if (!have || prev_n == 0) {
-        for (int q = lane; q < 3 * (T + 1); q += QP_THREADS) { double d = (double)so[q] - (double)ps[q]; acc_s += d * d; }
-        for (int q = lane; q < 2 * T; q += QP_THREADS) { double d = (double)uo[q] - (double)pu_[q]; acc_u += d * d; }
+        for (int q = lane; q < 3 * (T + 1); q += QP_THREADS) { double d = (double)stage[q] - (double)ps[q]; acc_s += d * d; }
+        for (int q = lane; q < 2 * T; q += QP_THREADS) {
+          int k = q / T, t = q - k * T;
+          double d = (double)(float)xbest[2 * t + k] - (double)pu_[q];
+          acc_u += d * d;
+        }
       } else {
         eff = cnt0 < prev_n ? cnt0 : prev_n;
         for (int q = lane; q < (T + 1) * eff; q += QP_THREADS) {
@@ -608,11 +767,11 @@ __global__ __launch_bounds__(QP_THREADS) void nrmp_qp_kernel(
         }
       }
     }
-    acc_s = wave_sum(acc_s); acc_u = wave_sum(acc_u); acc_mu = wave_sum(acc_mu); acc_lam = wave_sum(acc_lam);
-    LSYNC();
+    acc_s = wave_reduce<OpSum>(acc_s); acc_u = wave_reduce<OpSum>(acc_u);
+    acc_mu = wave_reduce<OpSum>(acc_mu); acc_lam = wave_reduce<OpSum>(acc_lam);
     // remember the current iterate
-    for (int q = lane; q < 3 * (T + 1); q += QP_THREADS) ps[q] = so[q];
-    for (int q = lane; q < 2 * T; q += QP_THREADS) pu_[q] = uo[q];
+    for (int q = lane; q < 3 * (T + 1); q += QP_THREADS) ps[q] = stage[q];
+    for (int q = lane; q < 2 * T; q += QP_THREADS) { int k = q / T, t = q - k * T; pu_[q] = (float)xbest[2 * t + k]; }
     if (have)
       for (int q = lane; q < (T + 1) * M; q += QP_THREADS) {
         size_t row = (size_t)b * (T + 1) * M + q;
@@ -641,28 +800,37 @@ __global__ __launch_bounds__(QP_THREADS) void nrmp_qp_kernel(
 
 extern "C" size_t npa_qp_shmem_bytes(int T, int M) {
   const bool obs = M > 0;
-  size_t nu = 2 * T, n = obs ? 3 * T : 2 * T, mc = obs ? 10 * T - 4 : 8 * T - 4, mf = obs ? (size_t)T * M : 0;
-  size_t d = (size_t)T * 3 * nu + T * 3 + nu * nu + n * (n + 1) + 5 * n + T * 14 + T * 2 + T * 6 + T * 3 + mf * 2 +
-             6 * mf + 5 * mc;
-  return d * sizeof(double);
+  size_t nu = 2 * T, ldp = nu + 1, mcu = 8 * T - 4, mf = obs ? (size_t)T * M : 0, npair = nu * (nu + 1) / 2;
+  size_t d = (size_t)T * 3 * ldp + (size_t)T * 2 * ldp + 2 * nu * ldp + 4 * (T * 3) + T * 12 + T * 8 + nu + T +
+             (nu + T) + nu + T + nu + T + 9 * mf + 7 * mcu + 6 * 2 * T;
+  size_t bytes = d * sizeof(double) + 2 * ((npair + 7) & ~(size_t)7) + ((mcu + 7) & ~(size_t)7);
+  return (bytes + 15) & ~(size_t)15;
 }
 
-extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, const float* cur_s_in, const float* cur_u_in,
-                                    const float* ref_s, const float* ref_us, const float* mu_sorted,
-                                    const float* lam_sorted, const float* pts_sorted, const float* dist_sorted,
-                                    const int* count, float* cur_s_out, float* cur_u_out, float* cur_d_out,
-                                    float* out_s, float* out_u, float* out_d, float* out_min_distance,
-                                    int* out_iters, float* out_nrmp_points, int* flags, float* state,
-                                    double* qp_info, hipStream_t stream) {
+extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, const float* cur_s_in,
+                                    const float* cur_u_in, const float* ref_s, const float* ref_us,
+                                    const float* mu_sorted, const float* lam_sorted, const float* pts_sorted,
+                                    const float* dist_sorted, const int* count, float* cur_s_out, float* cur_u_out,
+                                    float* cur_d_out, float* out_s, float* out_u, float* out_d,
+                                    float* out_min_distance, int* out_iters, float* out_nrmp_points, int* flags,
+                                    float* state, double* qp_info, hipStream_t stream) {
   size_t shmem = npa_qp_shmem_bytes(P.T, P.M);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<10>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<20>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(nrmp_qp_kernel, dim3(batch), dim3(QP_THREADS), shmem, stream, P, cur_s_in, cur_u_in, ref_s,
-                     ref_us, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count, cur_s_out, cur_u_out, cur_d_out,
-                     out_s, out_u, out_d, out_min_distance, out_iters, out_nrmp_points, flags, state, qp_info);
+  static const bool force_generic = getenv("NPA_QP_GENERIC") != nullptr;
+#define QP_LAUNCH(TTV)                                                                                        \
+  hipLaunchKernelGGL(nrmp_qp_kernel<TTV>, dim3(batch), dim3(QP_THREADS), shmem, stream, P, cur_s_in, cur_u_in, \
+                     ref_s, ref_us, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count, cur_s_out, cur_u_out, \
+                     cur_d_out, out_s, out_u, out_d, out_min_distance, out_iters, out_nrmp_points, flags, state, \
+                     qp_info, scene0)
+  if (P.T == 10 && !force_generic) QP_LAUNCH(10);
+  else if (P.T == 20 && !force_generic) QP_LAUNCH(20);
+  else QP_LAUNCH(0);
+#undef QP_LAUNCH
   return hipGetLastError();
 }

@@ -62,15 +62,22 @@ def test_dune_stage_vs_reference_vectors(case, cfgname, robot_kw, ck, over):
 @pytest.mark.parametrize("cfgname,nscn,npts,over", [("diff_1k_T10_K10", 6, 300, {}),
                                                      ("acker_2k_T20_K15", 4, 200, {}),
                                                      ("dyna_4k_T10_K10", 4, 200, {}),
-                                                     ("diff_1k_T10_K10", 3, 64, dict(robot_kw=OMNI))])
+                                                     ("diff_1k_T10_K10", 3, 64, dict(robot_kw=OMNI)),
+                                                     # T=8 / T=13 exercise the generic (LDS-resident) QP kernel,
+                                                     # T=10 / T=20 the register-resident instantiations
+                                                     ("diff_1k_T10_K10", 3, 150, dict(T=8)),
+                                                     ("diff_1k_T10_K10", 2, 150, dict(T=13))])
 def test_nrmp_stage_vs_oracle(cfgname, nscn, npts, over):
     """npa_nrmp_stage (A/B/C + fa/fb + QP) fed with the ORACLE's sorted DUNE output, vs the
     oracle's uncondensed fp64 solve of the same problem.  Tolerance 2e-5 on u (fp32 output)."""
     import torch
     from gpu_helpers import make_gpu_pan
+    import dataclasses
     cfg = CONFIGS[cfgname]
     over = dict(over)
     rk = over.pop("robot_kw", None)
+    if "T" in over:
+        cfg = dataclasses.replace(cfg, T=over.pop("T"))
     pan = make_gpu_pan(cfg, robot_kw=rk, dune_max_num=npts)
     orc = make_oracle(cfg, robot_kw=rk, dune_max_num=npts, iter_num=1)
     T, M, E = pan.T, pan.nrmp_max_num, pan.E
