@@ -115,8 +115,8 @@ int npa_forward_batch(npa_handle *h, int batch, int n_stride,
  *   mu_sorted [B][T+1][M][E], lam_sorted [B][T+1][M][2], pts_sorted [B][T+1][M][2],
  *   dist_sorted [B][T+1][M], count [B][T+1] (= min(N,M); rows >= count replicate row 0).
  * npa_nrmp_stage  = generate_state_parameter_value + generate_coefficient_parameter_value
- *   + the QP solve, from those arrays; writes s,u,d plus qp_info [B][4] doubles
- *   (iterations, final merit, mu, status). */
+ *   + the QP solve, from those arrays; writes s,u,d plus qp_info [B][16] doubles
+ *   (best iteration, final merit, mu, status, iterations run; rest reserved for profiling builds). */
 int npa_dune_stage(npa_handle *h, int batch, int n_stride, const float *nom_s,
                    const float *points, const float *velocities, const int32_t *n_points,
                    float *mu_sorted, float *lam_sorted, float *pts_sorted, float *dist_sorted,

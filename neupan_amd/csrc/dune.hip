@@ -68,16 +68,20 @@ __device__ __forceinline__ void ln_tanh(f32x16 acc, const float* g, const float*
   for (int r = 0; r < 16; ++r) s += acc[r];
   float mean = pair_sum(s) * (1.0f / 32.0f);
   float q = 0.f;
-  float xc[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { xc[r] = acc[r] - mean; q = fmaf(xc[r], xc[r], q); }
+  for (int r = 0; r < 16; ++r) { a[r] = acc[r] - mean; q = fmaf(a[r], a[r], q); }
   float var = pair_sum(q) * (1.0f / 32.0f);
   float rstd = 1.0f / __fsqrt_rn(var + 1e-5f);
-  float gv[16], bv[16];
-  load_vec16(g, hf, gv);
-  load_vec16(be, hf, bv);
+  // affine vectors fetched four features at a time (keeps the live register set small)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) a[r] = tanh_f32(fmaf(xc[r] * rstd, gv[r], bv[r]));
+  for (int qd = 0; qd < 4; ++qd) {
+    float4 gv = *reinterpret_cast<const float4*>(g + 8 * qd + 4 * hf);
+    float4 bv = *reinterpret_cast<const float4*>(be + 8 * qd + 4 * hf);
+    a[4 * qd + 0] = tanh_f32(fmaf(a[4 * qd + 0] * rstd, gv.x, bv.x));
+    a[4 * qd + 1] = tanh_f32(fmaf(a[4 * qd + 1] * rstd, gv.y, bv.y));
+    a[4 * qd + 2] = tanh_f32(fmaf(a[4 * qd + 2] * rstd, gv.z, bv.z));
+    a[4 * qd + 3] = tanh_f32(fmaf(a[4 * qd + 3] * rstd, gv.w, bv.w));
+  }
 }
 
 __device__ __forceinline__ f32x16 layer32(const float (&w)[16], const float (&a)[16], f32x16 acc) {
@@ -190,7 +194,7 @@ __device__ __forceinline__ void point_features(const DevParams& P, const SliceFr
 }
 
 template <int E>
-__global__ __launch_bounds__(DUNE_THREADS) void dune_kernel(
+__global__ __launch_bounds__(DUNE_THREADS, 4) void dune_kernel(
     DevParams P, const float* __restrict__ wpack, int n_stride, const float* __restrict__ cur_s,
     const float* __restrict__ points, const float* __restrict__ vel, const int* __restrict__ n_points,
     const int* __restrict__ flags, float* __restrict__ mu_sorted, float* __restrict__ lam_sorted,

@@ -31,8 +31,20 @@
 #include "pan_common.h"
 #include <cstdlib>
 
-#define QP_THREADS 64
+#define QP_THREADS 64          // lanes cooperating on one scene (one wavefront)
+#define QP_WAVES 4             // scenes per workgroup: one wave on each SIMD of a CU, so the
+                               // register-hungry QP waves displace as few DUNE workgroups as possible
 #define QP_MAX_IT 40
+// qp_info layout per scene (doubles): [0] best iteration [1] merit [2] mu [3] status [4] iterations
+// run, then (only when built with -DNPA_QP_PROF) accumulated s_memtime cycles of the solve's phases
+#define QP_INFO_STRIDE 16
+#ifdef NPA_QP_PROF
+#define PROF_DECL unsigned long long pt_ = __builtin_amdgcn_s_memtime(), pacc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define PROF(i) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); pacc_[i] += n_ - pt_; pt_ = n_; } while (0)
+#else
+#define PROF_DECL
+#define PROF(i) do { } while (0)
+#endif
 
 // ---- small device helpers -------------------------------------------------------------------
 __device__ __forceinline__ double readlane_f64(double v, int l) {
@@ -71,26 +83,41 @@ __device__ __forceinline__ double fast_rsqrt(double x) {    // x > 0
   y = y * fma(-0.5 * x * y, y, 1.5);
   return y;
 }
-#define LSYNC() __syncthreads()
+// wave-local ordering of LDS traffic between lanes (the waves of a workgroup are independent
+// scenes with different iteration counts: no workgroup barrier may be used)
+#define LSYNC()                                              \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   \
+    __builtin_amdgcn_wave_barrier();                         \
+  } while (0)
 
 // TT > 0: horizon known at compile time -> the reduced KKT matrix, its Cholesky factor (rows and
 // columns) and the columns of Phi live in registers, one matrix row per lane, every loop over
 // the horizon is unrolled and all broadcasts are v_readlane (no LDS round trip on the serial
 // chain).  TT == 0: generic horizon, same algorithm with the matrices in LDS.
-template <int TT>
-__global__ __launch_bounds__(QP_THREADS) void nrmp_qp_kernel(
+template <int TT, int MM>
+__global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
     DevParams P, const float* cur_s_in, const float* cur_u_in, const float* __restrict__ ref_s,
     const float* __restrict__ ref_us, const float* __restrict__ mu_sorted, const float* __restrict__ lam_sorted,
     const float* __restrict__ pts_sorted, const float* __restrict__ dist_sorted, const int* __restrict__ count,
     float* cur_s_out, float* cur_u_out, float* __restrict__ cur_d_out, float* __restrict__ out_s,
     float* __restrict__ out_u, float* __restrict__ out_d, float* __restrict__ out_min_distance,
     int* __restrict__ out_iters, float* __restrict__ out_nrmp_points, int* __restrict__ flags,
-    float* __restrict__ state, double* __restrict__ qp_info, int scene0) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int b = blockIdx.x + scene0, lane = threadIdx.x;
+    float* __restrict__ state, double* __restrict__ qp_info, int scene0, int nscene, int wave_doubles, int wpg) {
+  extern __shared__ __attribute__((aligned(16))) double sm_all[];
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (blockIdx.x * wpg + wv >= nscene) return;
+  const int b = blockIdx.x * wpg + wv + scene0;
+  double* sm = sm_all + (size_t)wv * wave_doubles;
   if (flags && flags[b * 4 + 0]) return;
+  // this wave is a long dependent chain that shares its SIMD with throughput-bound DUNE waves of
+  // the other sub-batches: win the issue arbitration, it needs few slots but needs them promptly
+  __builtin_amdgcn_s_setprio(3);
 
-  const int T = TT > 0 ? TT : P.T, M = P.M, E = P.E, nu = 2 * T;
+  // with TT and MM fixed every LDS offset below folds to an immediate (one base register)
+  PROF_DECL
+  const int T = TT > 0 ? TT : P.T, M = (TT > 0 && MM > 0) ? MM : P.M, E = P.E, nu = 2 * T;
   constexpr int NU = TT > 0 ? 2 * TT : 1, T3 = TT > 0 ? 3 * TT : 1;
   const bool obs = M > 0;
   const int mcu = 8 * T - 4;                  // rows on u: 4T speed + 4T-4 rate
@@ -240,6 +267,8 @@ __global__ __launch_bounds__(QP_THREADS) void nrmp_qp_kernel(
     Hm[a * ldk + c] = acc;
     Hm[c * ldk + a] = acc;
   }
+  // fast path: this lane's entries of H that receive the band terms of C_u' D C_u
+  double hdiag = 0, hoff = 0;
   // fast path: column `lane` of Phi (all T steps, 3 state rows) in registers
   double phic[T3];
   if constexpr (TT > 0) {
@@ -308,6 +337,12 @@ __global__ __launch_bounds__(QP_THREADS) void nrmp_qp_kernel(
   const double inv_m = 1.0 / m_tot;
   const double pub = (lane < nu && !(lane & 1)) ? -2.0 * pu * (double)__fmul_rn(P.p_u, rus[lane >> 1]) : 0.0;
   LSYNC();
+  if constexpr (TT > 0) {
+    if (lane < NU) {
+      hdiag = Hm[lane * ldk + lane];
+      hoff = lane >= 2 ? Hm[lane * ldk + lane - 2] : 0.0;
+    }
+  }
 
   double best_merit = 1e300, last_mu = 0;
   int best_it = 0, stall = 0, status = 0, it = 0;
@@ -362,6 +397,7 @@ __global__ __launch_bounds__(QP_THREADS) void nrmp_qp_kernel(
     return acc;
   };
 
+  PROF(0);
   for (it = 0; it <= QP_MAX_IT; ++it) {
     // ================= residuals =================
     phi_mul(xu, s3);
@@ -449,6 +485,7 @@ __global__ __launch_bounds__(QP_THREADS) void nrmp_qp_kernel(
       ++stall;
     }
     if (merit <= 1e-12 || stall >= 3 || it == QP_MAX_IT || mu < 1e-15) break;
+    PROF(1);
 
     // ================= reduced KKT matrix, Cholesky =================
     double arow[NU], bcol[NU];          // fast path: row `lane` of K' -> L, column `lane` of L
@@ -465,17 +502,20 @@ __global__ __launch_bounds__(QP_THREADS) void nrmp_qp_kernel(
         }
       }
       const int ar = lane < NU ? lane : 0;
-#pragma unroll
-      for (int c = 0; c < NU; ++c) arow[c] = Hm[ar * ldk + c];
-      // band terms of C_u' D C_u for this row
-      double dsum = 0, doff = 0;
-      {
-        const int a = ar, t = a >> 1;
-        dsum = lc[2 * a] * iwc[2 * a] + lc[2 * a + 1] * iwc[2 * a + 1];
+      // band terms of C_u' D C_u for this row go through the LDS copy of H (entries [a][a], [a][a-2]):
+      // no per-column lane masks are needed to place them in the register row
+      if (lane < NU) {
+        const int a = lane, t = a >> 1;
+        double dsum = lc[2 * a] * iwc[2 * a] + lc[2 * a + 1] * iwc[2 * a + 1], doff = 0;
         if (t >= 1) { int q = 4 * T + 2 * (a - 2); double v = lc[q] * iwc[q] + lc[q + 1] * iwc[q + 1]; dsum += v; doff = v; }
         if (t <= T - 2) { int q = 4 * T + 2 * a; dsum += lc[q] * iwc[q] + lc[q + 1] * iwc[q + 1]; }
+        Hm[a * ldk + a] = hdiag + dsum;
+        if (t >= 1) Hm[a * ldk + a - 2] = hoff - doff;
       }
       LSYNC();
+#pragma unroll
+      for (int c = 0; c < NU; ++c) arow[c] = Hm[ar * ldk + c];
+      PROF(2);
       // K'[a][c] += sum_{t,k} Phi[t][k][a] Y[t][k][c]; Y[tk][c] = 0 for c > 2t+1
 #pragma unroll
       for (int t = 0; t < TT; ++t) {
@@ -487,12 +527,9 @@ __global__ __launch_bounds__(QP_THREADS) void nrmp_qp_kernel(
           for (int c = 0; c < 2 * t + 2; ++c) arow[c] = fma(pv, Y[c], arow[c]);
         }
       }
-#pragma unroll
-      for (int c = 0; c < NU; ++c) {
-        arow[c] += (c == lane) ? dsum : 0.0;
-        arow[c] -= (c + 2 == lane) ? doff : 0.0;
-      }
-      // right-looking Cholesky, row i in lane i: after step k, arow[k] = L[i][k]
+      PROF(3);
+      // right-looking Cholesky, row i in lane i: after step k, arow[k] = L[i][k] (entries above the
+      // diagonal fill with unused garbage)
 #pragma unroll
       for (int k = 0; k < NU; ++k) {
         double piv = readlane_f64(arow[k], k);
@@ -500,16 +537,20 @@ __global__ __launch_bounds__(QP_THREADS) void nrmp_qp_kernel(
         double rinv = fast_rsqrt(piv);
         double l = arow[k] * rinv;
         arow[k] = l;
-        if (lane == k) myinv = rinv;
+        invd[k] = rinv;                      // uniform value, every lane stores it
 #pragma unroll
         for (int j = k + 1; j < NU; ++j) arow[j] = fma(-l, readlane_f64(l, j), arow[j]);
       }
-      // columns of L through LDS (transpose): bcol[k] = L[k][lane]
+      // keep the strictly lower part only (the substitutions below then need no lane predicates),
+      // and fetch the columns of L through LDS: bcol[k] = L[k][lane] for k > lane, else 0
+#pragma unroll
+      for (int c = 0; c < NU; ++c) arow[c] = (c < lane) ? arow[c] : 0.0;
       if (lane < NU) {
 #pragma unroll
         for (int c = 0; c < NU; ++c) Km[(size_t)lane * ldk + c] = arow[c];
       }
       LSYNC();
+      myinv = invd[ar];
 #pragma unroll
       for (int k = 0; k < NU; ++k) bcol[k] = Km[(size_t)k * ldk + ar];
     } else {
@@ -567,6 +608,7 @@ __global__ __launch_bounds__(QP_THREADS) void nrmp_qp_kernel(
     if (chol_ok) myinv = invd[lane < nu ? lane : 0];
     }
     if (!chol_ok) { status = 3; break; }
+    PROF(4);
 
     // ================= predictor / corrector =================
     double sigma_mu = 0, alpha = 1.0;
@@ -600,20 +642,17 @@ __global__ __launch_bounds__(QP_THREADS) void nrmp_qp_kernel(
         if constexpr (TT == 0) { q3[t * 3 + 0] = pq0; q3[t * 3 + 1] = pq1; q3[t * 3 + 2] = 0.0; }
       }
       double rr;
+      PROF(5);
       if constexpr (TT > 0) {
         rr = phi_tmul_reg(pq0, pq1, 0.0, false);
         if (lane < nu) rr += -r1u - ct_mul(dwc, lane);
         // forward substitution L y = rhs, backward L' dx = y; lane i owns entry i, L in registers
 #pragma unroll
-        for (int k = 0; k < NU; ++k) {
-          double yk = readlane_f64(rr * myinv, k);
-          rr = (lane == k) ? yk : ((lane > k) ? fma(-arow[k], yk, rr) : rr);
-        }
+        for (int k = 0; k < NU; ++k) rr = fma(-arow[k], readlane_f64(rr * myinv, k), rr);
+        rr *= myinv;                         // y
 #pragma unroll
-        for (int k = NU - 1; k >= 0; --k) {
-          double xk = readlane_f64(rr * myinv, k);
-          rr = (lane == k) ? xk : ((lane < k) ? fma(-bcol[k], xk, rr) : rr);
-        }
+        for (int k = NU - 1; k >= 0; --k) rr = fma(-bcol[k], readlane_f64(rr * myinv, k), rr);
+        rr *= myinv;                         // dx_u
       } else {
         LSYNC();
         rr = phi_tmul(q3);
@@ -631,6 +670,7 @@ __global__ __launch_bounds__(QP_THREADS) void nrmp_qp_kernel(
       }
       if (lane < nu) dxu[lane] = rr;
       LSYNC();
+      PROF(6);
       phi_mul(dxu, s3);
       LSYNC();
       for (int t = lane; t < T && obs; t += QP_THREADS)
@@ -682,6 +722,7 @@ __global__ __launch_bounds__(QP_THREADS) void nrmp_qp_kernel(
         alpha = fmin(1.0, 0.995 * amax);
       }
       LSYNC();
+      PROF(7);
     }
     for (int a = lane; a < nu; a += QP_THREADS) xu[a] += alpha * dxu[a];
     for (int t = lane; t < T && obs; t += QP_THREADS) xd[t] += alpha * dxd[t];
@@ -689,6 +730,7 @@ __global__ __launch_bounds__(QP_THREADS) void nrmp_qp_kernel(
     for (int i = lane; i < mcu; i += QP_THREADS) { lc[i] += alpha * dlc[i]; wc[i] += alpha * dwc[i]; }
     for (int i = lane; i < 2 * T && obs; i += QP_THREADS) { ld_[i] += alpha * dld[i]; wd[i] += alpha * dwd[i]; }
     LSYNC();
+    PROF(8);
   }
   LSYNC();
 
@@ -721,7 +763,12 @@ __global__ __launch_bounds__(QP_THREADS) void nrmp_qp_kernel(
       if (out_d) out_d[(size_t)b * T + t] = fv;
     }
   if (qp_info && lane == 0) {
-    qp_info[b * 4 + 0] = best_it; qp_info[b * 4 + 1] = best_merit; qp_info[b * 4 + 2] = last_mu; qp_info[b * 4 + 3] = status;
+    double* qi = qp_info + (size_t)b * QP_INFO_STRIDE;
+    qi[0] = best_it; qi[1] = best_merit; qi[2] = last_mu; qi[3] = status; qi[4] = it;
+#ifdef NPA_QP_PROF
+    PROF(9);
+    for (int i = 0; i < 10; ++i) qi[5 + i] = (double)pacc_[i];
+#endif
   }
 
   // ---- per-forward outputs of the last executed iteration -------------------------------------
@@ -814,23 +861,29 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
                                     float* cur_d_out, float* out_s, float* out_u, float* out_d,
                                     float* out_min_distance, int* out_iters, float* out_nrmp_points, int* flags,
                                     float* state, double* qp_info, hipStream_t stream) {
-  size_t shmem = npa_qp_shmem_bytes(P.T, P.M);
+  const size_t wave_bytes = npa_qp_shmem_bytes(P.T, P.M);
+  // as many scenes per workgroup as LDS allows (<= QP_WAVES)
+  int wpg = (int)((160 * 1024) / wave_bytes);
+  wpg = wpg < 1 ? 1 : (wpg > QP_WAVES ? QP_WAVES : wpg);
+  const size_t shmem = wave_bytes * wpg;
+  const int wave_doubles = (int)(wave_bytes / sizeof(double));
+  const int nblocks = (batch + wpg - 1) / wpg;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<10>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<20>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<10, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<20, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   static const bool force_generic = getenv("NPA_QP_GENERIC") != nullptr;
-#define QP_LAUNCH(TTV)                                                                                        \
-  hipLaunchKernelGGL(nrmp_qp_kernel<TTV>, dim3(batch), dim3(QP_THREADS), shmem, stream, P, cur_s_in, cur_u_in, \
+#define QP_LAUNCH(TTV, MMV)                                                                                      \
+  hipLaunchKernelGGL((nrmp_qp_kernel<TTV, MMV>), dim3(nblocks), dim3(QP_THREADS * wpg), shmem, stream, P, cur_s_in, cur_u_in, \
                      ref_s, ref_us, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count, cur_s_out, cur_u_out, \
                      cur_d_out, out_s, out_u, out_d, out_min_distance, out_iters, out_nrmp_points, flags, state, \
-                     qp_info, scene0)
-  if (P.T == 10 && !force_generic) QP_LAUNCH(10);
-  else if (P.T == 20 && !force_generic) QP_LAUNCH(20);
-  else QP_LAUNCH(0);
+                     qp_info, scene0, batch, wave_doubles, wpg)
+  if (P.T == 10 && P.M == 10 && !force_generic) QP_LAUNCH(10, 10);
+  else if (P.T == 20 && P.M == 10 && !force_generic) QP_LAUNCH(20, 10);
+  else QP_LAUNCH(0, 0);
 #undef QP_LAUNCH
   return hipGetLastError();
 }

@@ -360,7 +360,7 @@ class PAN(torch.nn.Module):
         out_s = torch.empty((B, 3, T + 1), dtype=torch.float32, device=dev)
         out_u = torch.empty((B, 2, T), dtype=torch.float32, device=dev)
         out_d = torch.empty((B, 1, T), dtype=torch.float32, device=dev)
-        info = torch.zeros((B, 4), dtype=torch.float64, device=dev)
+        info = torch.zeros((B, 16), dtype=torch.float64, device=dev)
         g = (lambda k: _ptr(stage[k])) if stage is not None else (lambda k: None)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
