@@ -1,0 +1,84 @@
+"""CPU tests of the drop-in boundary: the shared library builds/loads here (hipcc cross-compiles
+without a GPU) and exports every symbol include/neupan_amd.h declares; struct layouts agree;
+the host-side mirror refuses to run without a GPU instead of falling back."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from neupan_amd import build
+    build.build(force=False, verbose=False)
+    from neupan_amd import _lib
+    return _lib.load()
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "neupan_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(npa_[a-z_]+)\s*\(", txt)))
+
+
+def test_header_symbols_are_exported_and_bound(lib):
+    from neupan_amd import _lib
+    names = declared_symbols()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/neupan_amd.h but not exported"
+        assert n in _lib.SYMBOLS, f"{n} has no ctypes prototype in neupan_amd/_lib.py"
+    assert b"gfx950" in lib.npa_version()
+
+
+def test_config_struct_layout_matches_header():
+    from neupan_amd._lib import NpaConfig, NpaDuneWeights, NPA_MAX_E
+    # 6 int32 + float (+pad) -> 32 bytes, 8 doubles, 7 floats, G[8][2], h[8]
+    assert C.sizeof(NpaConfig) == 32 + 8 * 8 + 7 * 4 + NPA_MAX_E * 2 * 4 + NPA_MAX_E * 4 + 4
+    assert NpaConfig.step_time.offset == 32 and NpaConfig.q_s.offset == 96
+    assert C.sizeof(NpaDuneWeights) == 18 * 8
+    hdr = open(os.path.join(ROOT, "include", "neupan_amd.h")).read()
+    for name, val in (("NPA_MAX_T", 21), ("NPA_MAX_M", 32), ("NPA_MAX_E", 8)):
+        assert re.search(rf"#define {name} {val}\b", hdr)
+
+
+def test_argument_validation_without_gpu(lib):
+    from neupan_amd._lib import NpaConfig
+    h = C.c_void_p()
+    assert lib.npa_create(None, None, C.byref(h)) == -1            # NPA_E_ARG
+    cfg = NpaConfig()
+    cfg.receding, cfg.iter_num, cfg.nrmp_max_num, cfg.dune_max_num, cfg.edge_num = 64, 1, 10, 100, 4
+    assert lib.npa_create(C.byref(cfg), None, C.byref(h)) == -3    # NPA_E_UNSUPPORTED (T > NPA_MAX_T)
+    assert b"receding" in lib.npa_last_error()
+    assert lib.npa_workspace_bytes(None, 4) == 0 and lib.npa_destroy(None) == 0
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from neupan_amd._lib import NeupanAmdError
+    from neupan_amd.pan import PAN
+    from neupan_amd.robot import Robot
+    rb = Robot(10, 0.1, kinematics="diff", length=1.6, width=2.0, max_speed=[8, 1], max_acce=[8, 3])
+    with pytest.raises(NeupanAmdError):
+        PAN(10, 0.1, rb, dune_checkpoint=os.path.join(ROOT, "tests/golden/checkpoints/diff_robot_default_model_5000.pth"))
+
+
+def test_robot_mirror_matches_reference_geometry():
+    from helpers import golden
+    from neupan_amd.robot import Robot, halfplanes_from_vertices
+    geo = golden("geometry")
+    rb = Robot(10, 0.1, kinematics="acker", length=4.6, width=1.6, wheelbase=3, max_speed=[8, 3], max_acce=[8, 0.5])
+    np.testing.assert_array_equal(rb.G, geo["acker_G"]); np.testing.assert_array_equal(rb.h, geo["acker_h"])
+    assert rb.speed_bound[1, 0] == 1.57 and abs(rb.acce_bound[1, 0] - 0.05) < 1e-15      # robot.py:63-69
+    G, h = halfplanes_from_vertices(np.array([[-0.8, -1.0], [-1.8, 1.0], [1.8, 1.0], [0.8, -1.0]]).T)  # CW input
+    np.testing.assert_array_equal(G, geo["polygon_G"]); np.testing.assert_array_equal(h, geo["polygon_h"])
+    with pytest.raises(ValueError):
+        halfplanes_from_vertices(np.array([[0, 0], [2, 0], [1, 0.2], [2, 2], [0, 2]]).T)   # non-convex
+    with pytest.raises(ValueError):
+        Robot(10, 0.1)                                                                      # robot.py:46-47
