@@ -87,6 +87,9 @@ int npa_set_adjust(npa_handle *h, const float q_s[3], float p_u, float eta, floa
  * previous iterate, pan.py:100-105 / 215-243; zero it to reset a scene). */
 size_t npa_workspace_bytes(const npa_handle *h, int batch);
 size_t npa_state_bytes(const npa_handle *h, int batch);
+/* Byte offset inside the workspace of the per-scene QP diagnostics written by the last NRMP launch
+ * of npa_forward_batch: [B][16] doubles (best iteration, merit, mu, status, iterations run, ...). */
+size_t npa_workspace_qp_info_offset(const npa_handle *h, int batch);
 
 /* Replaces PAN.forward (pan.py:109-147) for `batch` independent scenes:
  *   K x { generate_point_flow (pan.py:150-212) -> DUNE.forward (dune.py:58-127) ->
@@ -109,6 +112,22 @@ int npa_forward_batch(npa_handle *h, int batch, int n_stride,
                       int32_t *out_iters, float *out_nrmp_points,
                       void *workspace, size_t workspace_bytes, void *state, size_t state_bytes,
                       void *stream);
+
+/* npa_forward_batch == npa_forward_begin + iter_num x npa_forward_iter(k) + npa_forward_end.
+ * The split lets a host interleave the PAN iterations of several independent batches (one handle
+ * each) on ONE stream: the DUNE launches of all batches stay ordered on `stream`, each batch's QP
+ * chain runs on that handle's helper stream (qp_on_helper_stream != 0) and overlaps the other
+ * batches' DUNE launches.  Same arguments as npa_forward_batch; buffers must stay valid until
+ * the work enqueued by npa_forward_end has completed. */
+int npa_forward_begin(npa_handle *h, int batch, int n_stride,
+                      const float *nom_s, const float *nom_u, const float *ref_s, const float *ref_us,
+                      const float *points, const float *velocities, const int32_t *n_points,
+                      float *out_s, float *out_u, float *out_d, float *out_min_distance,
+                      int32_t *out_iters, float *out_nrmp_points,
+                      void *workspace, size_t workspace_bytes, void *state, size_t state_bytes,
+                      void *stream, int qp_on_helper_stream);
+int npa_forward_iter(npa_handle *h, int k);
+int npa_forward_end(npa_handle *h);
 
 /* Stage entry points (used by the parity tests and for profiling one stage alone).
  * npa_dune_stage  = generate_point_flow + DUNE.forward + the top-M gather:

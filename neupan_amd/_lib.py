@@ -41,7 +41,11 @@ SYMBOLS = {
     "npa_set_adjust": (_I, [_P, C.POINTER(C.c_float * 3), C.c_float, C.c_float, C.c_float, C.c_float]),
     "npa_workspace_bytes": (_SZ, [_P, _I]),
     "npa_state_bytes": (_SZ, [_P, _I]),
+    "npa_workspace_qp_info_offset": (_SZ, [_P, _I]),
     "npa_forward_batch": (_I, [_P, _I, _I] + [_P] * 13 + [_P, _SZ, _P, _SZ, _P]),
+    "npa_forward_begin": (_I, [_P, _I, _I] + [_P] * 13 + [_P, _SZ, _P, _SZ, _P, _I]),
+    "npa_forward_iter": (_I, [_P, _I]),
+    "npa_forward_end": (_I, [_P]),
     "npa_dune_stage": (_I, [_P, _I, _I] + [_P] * 9 + [_P]),
     "npa_nrmp_stage": (_I, [_P, _I] + [_P] * 12 + [_P]),
     "npa_profile_enable": (_I, [_P, _I]),

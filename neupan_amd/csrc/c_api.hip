@@ -11,7 +11,7 @@
 #include <string>
 #include <vector>
 
-extern "C" hipError_t npa_launch_dune(const DevParams& P, const float* wpack, int batch, int scene0, int n_stride,
+extern "C" hipError_t npa_launch_dune(const DevParams& P, const float* wpack, int batch, int scene0, int t0, int n_stride,
                                       const float* cur_s, const float* points, const float* vel,
                                       const int* n_points, const int* flags, float* mu_sorted, float* lam_sorted,
                                       float* pts_sorted, float* dist_sorted, int* count, hipStream_t stream);
@@ -21,7 +21,7 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
                                     const int* count, float* cur_s_out, float* cur_u_out, float* cur_d_out,
                                     float* out_s, float* out_u, float* out_d, float* out_min_distance,
                                     int* out_iters, float* out_nrmp_points, int* flags, float* state,
-                                    double* qp_info, hipStream_t stream);
+                                    double* qp_info, double* warm, hipStream_t stream);
 extern "C" size_t npa_qp_shmem_bytes(int T, int M);
 
 static thread_local std::string g_err;
@@ -42,6 +42,7 @@ struct npa_handle {
   // sub-batch's QP chain runs on its own helper stream so it overlaps the other
   // sub-batches' DUNE launches (the QP is latency bound and occupies one wave per scene)
   int n_sub = 2;
+  bool warm_start = true;     // IPM warm start across the PAN iterations of one forward call
   hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> sync_ev;
   // profiling (bench.py): HIP events on the launch stream around every stage launch
@@ -87,12 +88,17 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
       for (int r = 0; r < 16; ++r)
         for (int l = 0; l < 64; ++l)
           pack[WP_WL + (L * 16 + r) * 64 + l] = w->lin_w[1 + L][(l & 31) * 32 + npa_feat(r, l >> 5)];
-    auto putv = [&](int slot, const float* src) { memcpy(&pack[WP_VEC + slot * 32], src, 32 * sizeof(float)); };
-    putv(V_B1, w->lin_b[0]); putv(V_G1, w->ln_w[0]); putv(V_BE1, w->ln_b[0]);
-    putv(V_B2, w->lin_b[1]);
-    putv(V_B3, w->lin_b[2]); putv(V_G2, w->ln_w[1]); putv(V_BE2, w->ln_b[1]);
-    putv(V_B4, w->lin_b[3]);
-    putv(V_B5, w->lin_b[4]); putv(V_G3, w->ln_w[2]); putv(V_BE3, w->ln_b[2]);
+    auto putv = [&](int slot, const float* src, float scale) {
+      for (int i = 0; i < 32; ++i) pack[WP_VEC + slot * 32 + i] = src[i] * scale;
+    };
+    // the LayerNorm affine feeds tanh only: pre-scale gamma/beta by 2*log2(e) so the kernel's
+    // tanh is exp2 + rcp + fma with no extra multiply (dune.hip: tanh_scaled)
+    const float k2 = 2.885390081777927f;
+    putv(V_B1, w->lin_b[0], 1.f); putv(V_G1, w->ln_w[0], k2); putv(V_BE1, w->ln_b[0], k2);
+    putv(V_B2, w->lin_b[1], 1.f);
+    putv(V_B3, w->lin_b[2], 1.f); putv(V_G2, w->ln_w[1], k2); putv(V_BE2, w->ln_b[1], k2);
+    putv(V_B4, w->lin_b[3], 1.f);
+    putv(V_B5, w->lin_b[4], 1.f); putv(V_G3, w->ln_w[2], k2); putv(V_BE3, w->ln_b[2], k2);
     for (int e = 0; e < E; ++e) {
       memcpy(&pack[WP_W6 + e * 32], w->lin_w[5] + e * 32, 32 * sizeof(float));
       pack[WP_B6 + e] = w->lin_b[5][e];
@@ -102,8 +108,9 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
     int v = atoi(env);
     if (v >= 1 && v <= 4) h->n_sub = v;
   }
+  if (const char* env = getenv("NPA_QP_WARM")) h->warm_start = atoi(env) != 0;
   hipError_t e = hipGetDevice(&h->device);
-  for (int i = 0; i < h->n_sub && h->n_sub > 1 && e == hipSuccess; ++i)
+  for (int i = 0; i < (h->n_sub > 1 ? h->n_sub : 1) && e == hipSuccess; ++i)
     e = hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc(&h->wpack, WP_TOTAL * sizeof(float));
   if (e == hipSuccess) e = hipMemcpy(h->wpack, pack.data(), WP_TOTAL * sizeof(float), hipMemcpyHostToDevice);
@@ -115,8 +122,10 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
   return NPA_OK;
 }
 
+static void drop_pending(npa_handle* h);
 extern "C" int npa_destroy(npa_handle* h) {
   if (!h) return NPA_OK;
+  drop_pending(h);
   for (auto& p : h->ev_dune) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto& p : h->ev_qp) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto& ev : h->sync_ev) hipEventDestroy(ev);
@@ -136,6 +145,10 @@ extern "C" int npa_set_adjust(npa_handle* h, const float q_s[3], float p_u, floa
 extern "C" size_t npa_workspace_bytes(const npa_handle* h, int batch) {
   if (!h || batch < 1) return 0;
   return npa_scratch_layout(batch, h->P.T, mdim(h->P), h->P.E).total * sizeof(float);
+}
+extern "C" size_t npa_workspace_qp_info_offset(const npa_handle* h, int batch) {
+  if (!h || batch < 1) return 0;
+  return npa_scratch_layout(batch, h->P.T, mdim(h->P), h->P.E).qp_info * sizeof(float);
 }
 extern "C" size_t npa_state_bytes(const npa_handle* h, int batch) {
   if (!h || batch < 1) return 0;
@@ -189,7 +202,7 @@ extern "C" int npa_dune_stage(npa_handle* h, int batch, int n_stride, const floa
       !dist_sorted || !count)
     return fail(NPA_E_ARG, "npa_dune_stage: bad argument");
   if (h->P.M <= 0) return fail(NPA_E_ARG, "npa_dune_stage: planner has no obstacle stage (nrmp_max_num or dune_max_num is 0)");
-  HIP_TRY(npa_launch_dune(h->P, h->wpack, batch, 0, n_stride, nom_s, points, velocities, n_points, nullptr, mu_sorted,
+  HIP_TRY(npa_launch_dune(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr, mu_sorted,
                           lam_sorted, pts_sorted, dist_sorted, count, (hipStream_t)stream));
   return NPA_OK;
 }
@@ -204,7 +217,138 @@ extern "C" int npa_nrmp_stage(npa_handle* h, int batch, const float* nom_s, cons
     return fail(NPA_E_ARG, "npa_nrmp_stage: obstacle arrays required when nrmp_max_num > 0");
   HIP_TRY(npa_launch_qp(h->P, batch, 0, nom_s, nom_u, ref_s, ref_us, mu_sorted, lam_sorted, pts_sorted, nullptr, count,
                         out_s, out_u, out_d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                        qp_info, (hipStream_t)stream));
+                        qp_info, nullptr, (hipStream_t)stream));
+  return NPA_OK;
+}
+
+// ---- forward = begin + K x iter + end ------------------------------------------------------------
+// The split exists so that a host can interleave the PAN iterations of several independent
+// batches (one handle each) on ONE stream: DUNE launches of all batches stay ordered there, each
+// batch's QP chain runs on that handle's helper stream(s) and overlaps the other batches' DUNE
+// launches (neupan_amd.pan.forward_interleaved).  npa_forward_batch is the single-batch form.
+struct PendingCall {
+  bool active = false;
+  int batch = 0, n_stride = 0, nsub = 1;
+  const float *ref_s = nullptr, *ref_us = nullptr, *points = nullptr, *velocities = nullptr;
+  const int32_t* n_points = nullptr;
+  float *out_s = nullptr, *out_u = nullptr, *out_d = nullptr, *out_md = nullptr, *out_np = nullptr;
+  int32_t* out_iters = nullptr;
+  float* ws = nullptr;
+  float* state = nullptr;
+  hipStream_t stream = nullptr;
+  bool dune = false, qp_aux = false;
+};
+static std::mutex g_pending_mu;
+static std::vector<std::pair<npa_handle*, PendingCall>> g_pending;
+static PendingCall* pending_of(npa_handle* h, bool create) {
+  for (auto& p : g_pending) if (p.first == h) return &p.second;
+  if (!create) return nullptr;
+  g_pending.emplace_back(h, PendingCall());
+  return &g_pending.back().second;
+}
+
+extern "C" int npa_forward_begin(npa_handle* h, int batch, int n_stride, const float* nom_s, const float* nom_u,
+                                 const float* ref_s, const float* ref_us, const float* points,
+                                 const float* velocities, const int32_t* n_points, float* out_s, float* out_u,
+                                 float* out_d, float* out_min_distance, int32_t* out_iters, float* out_nrmp_points,
+                                 void* workspace, size_t workspace_bytes, void* state, size_t state_bytes,
+                                 void* stream_, int qp_on_helper_stream) {
+  if (!h || batch < 1 || !nom_s || !nom_u || !ref_s || !ref_us || !out_s || !out_u || !workspace || !state)
+    return fail(NPA_E_ARG, "npa_forward_begin: null argument");
+  const DevParams& P = h->P;
+  if (P.M > 0 && !out_d) return fail(NPA_E_ARG, "npa_forward_begin: out_d required when nrmp_max_num > 0");
+  if (workspace_bytes < npa_workspace_bytes(h, batch)) return fail(NPA_E_ARG, "workspace too small");
+  if (state_bytes < npa_state_bytes(h, batch)) return fail(NPA_E_ARG, "state buffer too small");
+  if (points && n_stride < 1) return fail(NPA_E_ARG, "n_stride < 1");
+  std::lock_guard<std::mutex> lock(g_pending_mu);
+  PendingCall* pc = pending_of(h, true);
+  if (pc->active) return fail(NPA_E_ARG, "npa_forward_begin: previous forward on this handle not ended");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int T = P.T;
+  const ScratchLayout L = npa_scratch_layout(batch, T, mdim(P), P.E);
+  float* ws = (float*)workspace;
+  HIP_TRY(hipMemcpyAsync(ws + L.cur_s, nom_s, (size_t)batch * 3 * (T + 1) * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(ws + L.cur_u, nom_u, (size_t)batch * 2 * T * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  HIP_TRY(hipMemsetAsync(ws + L.flags, 0, (size_t)batch * 4 * sizeof(int), stream));
+  HIP_TRY(hipMemsetAsync(ws + L.count, 0, (size_t)batch * (T + 1) * sizeof(int), stream));
+  pc->batch = batch; pc->n_stride = n_stride; pc->ref_s = ref_s; pc->ref_us = ref_us; pc->points = points;
+  pc->velocities = velocities; pc->n_points = n_points; pc->out_s = out_s; pc->out_u = out_u; pc->out_d = out_d;
+  pc->out_md = out_min_distance; pc->out_iters = out_iters; pc->out_np = out_nrmp_points; pc->ws = ws;
+  pc->state = (float*)state; pc->stream = stream;
+  pc->dune = P.M > 0 && points != nullptr;
+  // sub-batches [lo_i, hi_i): DUNE(i,k) on `stream` in (k, i) order, QP(i,k) on aux[i]
+  pc->nsub = (h->n_sub > 1 && pc->dune && batch >= 16 * h->n_sub) ? h->n_sub : 1;
+  pc->qp_aux = pc->dune && (pc->nsub > 1 || (qp_on_helper_stream && h->aux[0]));
+  const size_t need_ev = (size_t)2 * pc->nsub * P.K + 1;
+  while (h->sync_ev.size() < need_ev) {
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    h->sync_ev.push_back(ev);
+  }
+  if (pc->qp_aux) {
+    HIP_TRY(hipEventRecord(h->sync_ev[0], stream));                 // inputs staged
+    for (int i = 0; i < pc->nsub; ++i) HIP_TRY(hipStreamWaitEvent(h->aux[i], h->sync_ev[0], 0));
+  }
+  pc->active = true;
+  return NPA_OK;
+}
+
+extern "C" int npa_forward_iter(npa_handle* h, int k) {
+  if (!h) return fail(NPA_E_ARG, "npa_forward_iter: null handle");
+  std::lock_guard<std::mutex> lock(g_pending_mu);
+  PendingCall* pc = pending_of(h, false);
+  if (!pc || !pc->active) return fail(NPA_E_ARG, "npa_forward_iter: no forward in progress on this handle");
+  const DevParams& P = h->P;
+  if (k < 0 || k >= P.K) return fail(NPA_E_ARG, "npa_forward_iter: iteration index out of range");
+  const int T = P.T, batch = pc->batch, nsub = pc->nsub;
+  const ScratchLayout L = npa_scratch_layout(batch, T, mdim(P), P.E);
+  float* ws = pc->ws;
+  float *cur_s = ws + L.cur_s, *cur_u = ws + L.cur_u, *cur_d = ws + L.cur_d;
+  float *mu = ws + L.mu, *lam = ws + L.lam, *pts = ws + L.pts, *dist = ws + L.dist;
+  int* count = (int*)(ws + L.count);
+  int* flags = (int*)(ws + L.flags);
+  double* warm = (double*)(ws + L.warm);
+  double* qp_info = (double*)(ws + L.qp_info);
+  hipStream_t stream = pc->stream;
+  auto lo = [&](int i) { return (int)((long long)batch * i / nsub); };
+  auto ev_d = [&](int i, int kk) { return h->sync_ev[1 + (size_t)2 * (kk * nsub + i)]; };
+  auto ev_q = [&](int i, int kk) { return h->sync_ev[1 + (size_t)2 * (kk * nsub + i) + 1]; };
+  for (int i = 0; i < nsub; ++i) {
+    const int s0 = lo(i), nb = lo(i + 1) - lo(i);
+    hipStream_t qs = pc->qp_aux ? h->aux[i] : stream;
+    if (pc->dune) {
+      if (pc->qp_aux && k > 0) HIP_TRY(hipStreamWaitEvent(stream, ev_q(i, k - 1), 0));
+      EventPair* ev = next_event(h, h->ev_dune, h->n_dune);
+      if (ev) HIP_TRY(hipEventRecord(ev->a, stream));
+      HIP_TRY(npa_launch_dune(P, h->wpack, nb, s0, k == 0 ? 0 : 1, pc->n_stride, cur_s, pc->points, pc->velocities,
+                              pc->n_points, flags, mu, lam, pts, dist, count, stream));
+      if (ev) HIP_TRY(hipEventRecord(ev->b, stream));
+      if (pc->qp_aux) {
+        HIP_TRY(hipEventRecord(ev_d(i, k), stream));
+        HIP_TRY(hipStreamWaitEvent(qs, ev_d(i, k), 0));
+      }
+    }
+    EventPair* ev = next_event(h, h->ev_qp, h->n_qp);
+    if (ev) HIP_TRY(hipEventRecord(ev->a, qs));
+    HIP_TRY(npa_launch_qp(P, nb, s0, cur_s, cur_u, pc->ref_s, pc->ref_us, mu, lam, pts, dist, count, cur_s, cur_u,
+                          cur_d, pc->out_s, pc->out_u, pc->out_d, pc->out_md, pc->out_iters, pc->out_np, flags,
+                          pc->state, qp_info, h->warm_start ? warm : nullptr, qs));
+    if (ev) HIP_TRY(hipEventRecord(ev->b, qs));
+    if (pc->qp_aux) HIP_TRY(hipEventRecord(ev_q(i, k), qs));
+  }
+  return NPA_OK;
+}
+
+extern "C" int npa_forward_end(npa_handle* h) {
+  if (!h) return fail(NPA_E_ARG, "npa_forward_end: null handle");
+  std::lock_guard<std::mutex> lock(g_pending_mu);
+  PendingCall* pc = pending_of(h, false);
+  if (!pc || !pc->active) return fail(NPA_E_ARG, "npa_forward_end: no forward in progress on this handle");
+  const int nsub = pc->nsub, K = h->P.K;
+  if (pc->qp_aux)                                                       // join the helper streams
+    for (int i = 0; i < nsub; ++i)
+      HIP_TRY(hipStreamWaitEvent(pc->stream, h->sync_ev[1 + (size_t)2 * ((K - 1) * nsub + i) + 1], 0));
+  pc->active = false;
   return NPA_OK;
 }
 
@@ -214,69 +358,19 @@ extern "C" int npa_forward_batch(npa_handle* h, int batch, int n_stride, const f
                                  float* out_d, float* out_min_distance, int32_t* out_iters, float* out_nrmp_points,
                                  void* workspace, size_t workspace_bytes, void* state, size_t state_bytes,
                                  void* stream_) {
-  if (!h || batch < 1 || !nom_s || !nom_u || !ref_s || !ref_us || !out_s || !out_u || !workspace || !state)
-    return fail(NPA_E_ARG, "npa_forward_batch: null argument");
-  const DevParams& P = h->P;
-  if (P.M > 0 && !out_d) return fail(NPA_E_ARG, "npa_forward_batch: out_d required when nrmp_max_num > 0");
-  if (workspace_bytes < npa_workspace_bytes(h, batch)) return fail(NPA_E_ARG, "workspace too small");
-  if (state_bytes < npa_state_bytes(h, batch)) return fail(NPA_E_ARG, "state buffer too small");
-  if (points && n_stride < 1) return fail(NPA_E_ARG, "n_stride < 1");
-  hipStream_t stream = (hipStream_t)stream_;
-  const int T = P.T;
-  const ScratchLayout L = npa_scratch_layout(batch, T, mdim(P), P.E);
-  float* ws = (float*)workspace;
-  float *cur_s = ws + L.cur_s, *cur_u = ws + L.cur_u, *cur_d = ws + L.cur_d;
-  float *mu = ws + L.mu, *lam = ws + L.lam, *pts = ws + L.pts, *dist = ws + L.dist;
-  int* count = (int*)(ws + L.count);
-  int* flags = (int*)(ws + L.flags);
-  const bool dune = P.M > 0 && points != nullptr;
+  int rc = npa_forward_begin(h, batch, n_stride, nom_s, nom_u, ref_s, ref_us, points, velocities, n_points, out_s,
+                             out_u, out_d, out_min_distance, out_iters, out_nrmp_points, workspace, workspace_bytes,
+                             state, state_bytes, stream_, 0);
+  if (rc != NPA_OK) return rc;
+  for (int k = 0; k < h->P.K; ++k) {
+    rc = npa_forward_iter(h, k);
+    if (rc != NPA_OK) { npa_forward_end(h); return rc; }
+  }
+  return npa_forward_end(h);
+}
 
-  HIP_TRY(hipMemcpyAsync(cur_s, nom_s, (size_t)batch * 3 * (T + 1) * sizeof(float), hipMemcpyDeviceToDevice, stream));
-  HIP_TRY(hipMemcpyAsync(cur_u, nom_u, (size_t)batch * 2 * T * sizeof(float), hipMemcpyDeviceToDevice, stream));
-  HIP_TRY(hipMemsetAsync(flags, 0, (size_t)batch * 4 * sizeof(int), stream));
-  HIP_TRY(hipMemsetAsync(count, 0, (size_t)batch * (T + 1) * sizeof(int), stream));
-
-  // sub-batches [lo_i, hi_i): DUNE(i,k) on `stream` in (k, i) order, QP(i,k) on aux[i]
-  int nsub = (h->n_sub > 1 && dune && batch >= 16 * h->n_sub) ? h->n_sub : 1;
-  auto lo = [&](int i) { return (int)((long long)batch * i / nsub); };
-  const size_t need_ev = (size_t)2 * nsub * P.K + 1;
-  while (h->sync_ev.size() < need_ev) {
-    hipEvent_t ev;
-    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    h->sync_ev.push_back(ev);
-  }
-  auto ev_d = [&](int i, int k) { return h->sync_ev[1 + (size_t)2 * (k * nsub + i)]; };
-  auto ev_q = [&](int i, int k) { return h->sync_ev[1 + (size_t)2 * (k * nsub + i) + 1]; };
-  if (nsub > 1) {
-    HIP_TRY(hipEventRecord(h->sync_ev[0], stream));                 // inputs staged
-    for (int i = 0; i < nsub; ++i) HIP_TRY(hipStreamWaitEvent(h->aux[i], h->sync_ev[0], 0));
-  }
-  for (int k = 0; k < P.K; ++k) {
-    for (int i = 0; i < nsub; ++i) {
-      const int s0 = lo(i), nb = lo(i + 1) - lo(i);
-      hipStream_t qs = nsub > 1 ? h->aux[i] : stream;
-      if (dune) {
-        if (nsub > 1 && k > 0) HIP_TRY(hipStreamWaitEvent(stream, ev_q(i, k - 1), 0));
-        EventPair* ev = next_event(h, h->ev_dune, h->n_dune);
-        if (ev) HIP_TRY(hipEventRecord(ev->a, stream));
-        HIP_TRY(npa_launch_dune(P, h->wpack, nb, s0, n_stride, cur_s, points, velocities, n_points, flags, mu, lam,
-                                pts, dist, count, stream));
-        if (ev) HIP_TRY(hipEventRecord(ev->b, stream));
-        if (nsub > 1) {
-          HIP_TRY(hipEventRecord(ev_d(i, k), stream));
-          HIP_TRY(hipStreamWaitEvent(qs, ev_d(i, k), 0));
-        }
-      }
-      EventPair* ev = next_event(h, h->ev_qp, h->n_qp);
-      if (ev) HIP_TRY(hipEventRecord(ev->a, qs));
-      HIP_TRY(npa_launch_qp(P, nb, s0, cur_s, cur_u, ref_s, ref_us, mu, lam, pts, dist, count, cur_s, cur_u, cur_d,
-                            out_s, out_u, out_d, out_min_distance, out_iters, out_nrmp_points, flags, (float*)state,
-                            nullptr, qs));
-      if (ev) HIP_TRY(hipEventRecord(ev->b, qs));
-      if (nsub > 1) HIP_TRY(hipEventRecord(ev_q(i, k), qs));
-    }
-  }
-  if (nsub > 1)
-    for (int i = 0; i < nsub; ++i) HIP_TRY(hipStreamWaitEvent(stream, ev_q(i, P.K - 1), 0));   // join
-  return NPA_OK;
+static void drop_pending(npa_handle* h) {
+  std::lock_guard<std::mutex> lock(g_pending_mu);
+  for (size_t i = 0; i < g_pending.size(); ++i)
+    if (g_pending[i].first == h) { g_pending.erase(g_pending.begin() + i); break; }
 }

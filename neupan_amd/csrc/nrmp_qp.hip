@@ -35,6 +35,7 @@
 #define QP_WAVES 4             // scenes per workgroup: one wave on each SIMD of a CU, so the
                                // register-hungry QP waves displace as few DUNE workgroups as possible
 #define QP_MAX_IT 40
+#define QP_WARM_DELTA 0.1
 // qp_info layout per scene (doubles): [0] best iteration [1] merit [2] mu [3] status [4] iterations
 // run, then (only when built with -DNPA_QP_PROF) accumulated s_memtime cycles of the solve's phases
 #define QP_INFO_STRIDE 16
@@ -77,6 +78,8 @@ __device__ __forceinline__ double fast_rcp(double x) {      // ~1 ulp; x finite,
   r = fma(fma(-x, r, 1.0), r, r);
   return r;
 }
+// step-to-the-boundary ratios only need a few digits (the step is scaled by 0.995 anyway)
+__device__ __forceinline__ double rough_rcp(double x) { return __builtin_amdgcn_rcp(x); }
 __device__ __forceinline__ double fast_rsqrt(double x) {    // x > 0
   double y = __builtin_amdgcn_rsq(x);
   y = y * fma(-0.5 * x * y, y, 1.5);
@@ -103,7 +106,8 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
     float* cur_s_out, float* cur_u_out, float* __restrict__ cur_d_out, float* __restrict__ out_s,
     float* __restrict__ out_u, float* __restrict__ out_d, float* __restrict__ out_min_distance,
     int* __restrict__ out_iters, float* __restrict__ out_nrmp_points, int* __restrict__ flags,
-    float* __restrict__ state, double* __restrict__ qp_info, int scene0, int nscene, int wave_doubles, int wpg) {
+    float* __restrict__ state, double* __restrict__ qp_info, double* __restrict__ warm, int scene0, int nscene,
+    int wave_doubles, int wpg) {
   extern __shared__ __attribute__((aligned(16))) double sm_all[];
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -269,12 +273,6 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
   }
   // fast path: this lane's entries of H that receive the band terms of C_u' D C_u
   double hdiag = 0, hoff = 0;
-  // fast path: column `lane` of Phi (all T steps, 3 state rows) in registers
-  double phic[T3];
-  if constexpr (TT > 0) {
-#pragma unroll
-    for (int q = 0; q < T3; ++q) phic[q] = (lane < NU) ? Phi[(size_t)q * ldp + lane] : 0.0;
-  }
   for (int q = lane; q < 3 * T; q += QP_THREADS) {
     int t = q / 3, k = q - 3 * t;
     double qk = P.q_s[k], mk = (k == 2) ? m2 : 1.0, c = cv[q];
@@ -368,25 +366,22 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
     double acc = 0;
     if (lane < nu) {
       const int a = lane;
-      for (int t = a >> 1; t < T; ++t) {
-        const double* Pt = Phi + (size_t)t * 3 * ldp;
-        acc += Pt[a] * in3[t * 3] + Pt[ldp + a] * in3[t * 3 + 1] + Pt[2 * ldp + a] * in3[t * 3 + 2];
+      if constexpr (TT > 0) {        // Phi[t][k][a] is stored as 0 for t < a/2: no lane-dependent trip count
+        double a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+          const double* Pt = Phi + (size_t)t * 3 * ldp;
+          a0 = fma(Pt[a], in3[t * 3], a0); a1 = fma(Pt[ldp + a], in3[t * 3 + 1], a1); a2 = fma(Pt[2 * ldp + a], in3[t * 3 + 2], a2);
+        }
+        acc = a0 + a1 + a2;
+      } else {
+        for (int t = a >> 1; t < T; ++t) {
+          const double* Pt = Phi + (size_t)t * 3 * ldp;
+          acc += Pt[a] * in3[t * 3] + Pt[ldp + a] * in3[t * 3 + 1] + Pt[2 * ldp + a] * in3[t * 3 + 2];
+        }
       }
     }
     return acc;
-  };
-  // fast path: the same product with the operand (q0,q1,q2)[t] held by lane t
-  auto phi_tmul_reg = [&](double q0, double q1, double q2, bool use2) -> double {
-    double acc0 = 0, acc1 = 0;
-    if constexpr (TT > 0) {
-#pragma unroll
-      for (int t = 0; t < TT; ++t) {
-        acc0 = fma(phic[3 * t], readlane_f64(q0, t), acc0);
-        acc1 = fma(phic[3 * t + 1], readlane_f64(q1, t), acc1);
-        if (use2) acc0 = fma(phic[3 * t + 2], readlane_f64(q2, t), acc0);
-      }
-    }
-    return acc0 + acc1;
   };
   // C_u' y for variable a (y indexed like the u rows)
   auto ct_mul = [&](const double* y, int a) -> double {
@@ -397,6 +392,41 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
     return acc;
   };
 
+  // ---- warm start from the previous PAN iteration of this forward call ----------------------
+  // (x, multipliers) of the previous solve, pushed back inside the cone by QP_WARM_DELTA; slacks
+  // are recomputed from the new problem data.  oracle/condensed_ipm.py: 12.6 -> 8.8 iterations.
+  const int nwarm = nu + T + mf + mcu + 2 * T;
+  double* wrm = warm ? warm + (size_t)b * nwarm : nullptr;
+  const bool use_warm = wrm && flags && flags[b * 4 + 2];
+  if (use_warm) {
+    const double dl = QP_WARM_DELTA;
+    for (int a = lane; a < nu; a += QP_THREADS) xu[a] = wrm[a];
+    for (int t = lane; t < T; t += QP_THREADS) xd[t] = fmin(fmax(wrm[nu + t], dmin0), dmaxv);
+    LSYNC();
+    phi_mul(xu, s3);
+    LSYNC();
+    for (int i = lane; i < mf; i += QP_THREADS) {
+      int t = i / M;
+      double l = fmax(wrm[nu + T + i], dl);
+      lf[i] = l;
+      wf[i] = fmax(fa0[i] * s3[t * 3] + fa1[i] * s3[t * 3 + 1] - xd[t] - ff[i] + l * iro, dl);
+    }
+    for (int i = lane; i < mcu; i += QP_THREADS) {
+      if (cact[i]) {
+        int v = (i < 4 * T) ? (i >> 1) : ((i - 4 * T) >> 1);
+        double sg = (i & 1) ? -1.0 : 1.0;
+        double cx = (i < 4 * T) ? sg * xu[v] : sg * (xu[v + 2] - xu[v]);
+        lc[i] = fmax(wrm[nu + T + mf + i], dl);
+        wc[i] = fmax(cb[i] - cx, dl);
+      }
+    }
+    for (int i = lane; i < 2 * T && obs; i += QP_THREADS) {
+      int t = i >> 1;
+      ld_[i] = fmax(wrm[nu + T + mf + mcu + i], dl);
+      wd[i] = fmax((i & 1) ? xd[t] - dmin0 : dmaxv - xd[t], dl);
+    }
+    LSYNC();
+  }
   PROF(0);
   for (it = 0; it <= QP_MAX_IT; ++it) {
     // ================= residuals =================
@@ -436,7 +466,7 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
     LSYNC();
     // per-step sums over the M hinge rows (lane = t)
     double r1dmax = 0;
-    double S0r = 0, S1r = 0, S2r = 0, v0r = 0, v1r = 0, ikr = 0, r1dr = 0, q0r = 0, q1r = 0, q2r = 0;
+    double S0r = 0, S1r = 0, S2r = 0, v0r = 0, v1r = 0, ikr = 0, r1dr = 0;
     for (int t = lane; t < T; t += QP_THREADS) {
       double z0 = 0, z1 = 0, zs = 0, s00 = 0, s01 = 0, s11 = 0, v0 = 0, v1 = 0, sg = 0;
 #pragma unroll 5
@@ -462,10 +492,9 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
       q3[t * 3 + 2] = W2 * s3[t * 3 + 2] + lin[t * 3 + 2];
       r1dmax = fmax(r1dmax, fabs(r1d));
       S0r = S[0]; S1r = S[1]; S2r = S[2]; v0r = v0; v1r = v1; ikr = ik; r1dr = r1d;
-      q0r = q3[t * 3 + 0]; q1r = q3[t * 3 + 1]; q2r = q3[t * 3 + 2];
     }
     LSYNC();
-    double r1u = (TT > 0) ? phi_tmul_reg(q0r, q1r, q2r, true) : phi_tmul(q3);   // lane a < nu
+    double r1u = phi_tmul(q3);                     // lane a < nu
     if (lane < nu) {
       const int a = lane;
       if (!(a & 1)) r1u += 2.0 * pu * pu * xu[a] + pub;
@@ -492,13 +521,23 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
     double myinv = 1.0;
     bool chol_ok = true;
     if constexpr (TT > 0) {
-      // Y[tk][c] = S'_t[k][:] Phi_xy[t][:, c]  (lane = column c), staged in LDS for broadcast reads
+      // K' = H + band + sum_t Phi_xy(t)' S'_t Phi_xy(t) without touching all T terms per entry:
+      // with P_t = S'_t + A(t+1)' P_{t+1} A(t+1) (3x3, backward in t; A = I + a e_2') the entries of
+      // block row i are  K'[a][c] += (P_i B_i[:,a&1]) . Phi_i[:,c]  for c <= a   (3 FMAs each).
+      {
+        double p00 = 0, p01 = 0, p02 = 0, p11 = 0, p12 = 0, p22 = 0;
+        double* Pst = Yt;                              // [T][6] staging of P_t (uniform values)
 #pragma unroll
-      for (int t = 0; t < TT; ++t) {
-        double s0 = readlane_f64(S0r, t), s1 = readlane_f64(S1r, t), s2 = readlane_f64(S2r, t);
-        if (lane < NU) {
-          Yt[(size_t)(2 * t) * NU + lane] = s0 * phic[3 * t] + s1 * phic[3 * t + 1];
-          Yt[(size_t)(2 * t + 1) * NU + lane] = s1 * phic[3 * t] + s2 * phic[3 * t + 1];
+        for (int t = TT - 1; t >= 0; --t) {
+          if (t < TT - 1) {
+            const double a0 = Abc[(t + 1) * 12 + 0], a1 = Abc[(t + 1) * 12 + 1];
+            const double pa0 = p00 * a0 + p01 * a1, pa1 = p01 * a0 + p11 * a1, pa2 = p02 * a0 + p12 * a1;
+            p22 += 2.0 * pa2 + (a0 * pa0 + a1 * pa1);
+            p02 += pa0; p12 += pa1;
+          }
+          p00 += readlane_f64(S0r, t); p01 += readlane_f64(S1r, t); p11 += readlane_f64(S2r, t);
+          Pst[t * 6 + 0] = p00; Pst[t * 6 + 1] = p01; Pst[t * 6 + 2] = p02;
+          Pst[t * 6 + 3] = p11; Pst[t * 6 + 4] = p12; Pst[t * 6 + 5] = p22;
         }
       }
       const int ar = lane < NU ? lane : 0;
@@ -513,19 +552,19 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
         if (t >= 1) Hm[a * ldk + a - 2] = hoff - doff;
       }
       LSYNC();
-#pragma unroll
-      for (int c = 0; c < NU; ++c) arow[c] = Hm[ar * ldk + c];
       PROF(2);
-      // K'[a][c] += sum_{t,k} Phi[t][k][a] Y[t][k][c]; Y[tk][c] = 0 for c > 2t+1
+      {
+        const int i = ar >> 1, k2 = ar & 1;
+        const double* Pi = Yt + i * 6;
+        const double* Bi = Abc + i * 12 + 2 + k2;      // B_i[:, k2] = o[2+k2], o[4+k2], o[6+k2]
+        const double b0 = Bi[0], b1 = Bi[2], b2 = Bi[4];
+        const double g0 = Pi[0] * b0 + Pi[1] * b1 + Pi[2] * b2;
+        const double g1 = Pi[1] * b0 + Pi[3] * b1 + Pi[4] * b2;
+        const double g2 = Pi[2] * b0 + Pi[4] * b1 + Pi[5] * b2;
+        const double* Ph = Phi + (size_t)i * 3 * ldp;  // Phi_i rows (zero beyond column 2i+1)
 #pragma unroll
-      for (int t = 0; t < TT; ++t) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const double pv = phic[3 * t + k];
-          const double* Y = Yt + (size_t)(2 * t + k) * NU;
-#pragma unroll
-          for (int c = 0; c < 2 * t + 2; ++c) arow[c] = fma(pv, Y[c], arow[c]);
-        }
+        for (int c = 0; c < NU; ++c)
+          arow[c] = fma(g0, Ph[c], fma(g1, Ph[ldp + c], fma(g2, Ph[2 * ldp + c], Hm[ar * ldk + c])));
       }
       PROF(3);
       // right-looking Cholesky, row i in lane i: after step k, arow[k] = L[i][k] (entries above the
@@ -639,13 +678,14 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
         rdr = rd;
         pq0 = -(z0 - v0r * e);
         pq1 = -(z1 - v1r * e);
-        if constexpr (TT == 0) { q3[t * 3 + 0] = pq0; q3[t * 3 + 1] = pq1; q3[t * 3 + 2] = 0.0; }
+        q3[t * 3 + 0] = pq0; q3[t * 3 + 1] = pq1; q3[t * 3 + 2] = 0.0;
       }
       double rr;
       PROF(5);
+      LSYNC();
+      rr = phi_tmul(q3);
+      if (lane < nu) rr += -r1u - ct_mul(dwc, lane);
       if constexpr (TT > 0) {
-        rr = phi_tmul_reg(pq0, pq1, 0.0, false);
-        if (lane < nu) rr += -r1u - ct_mul(dwc, lane);
         // forward substitution L y = rhs, backward L' dx = y; lane i owns entry i, L in registers
 #pragma unroll
         for (int k = 0; k < NU; ++k) rr = fma(-arow[k], readlane_f64(rr * myinv, k), rr);
@@ -654,9 +694,6 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
         for (int k = NU - 1; k >= 0; --k) rr = fma(-bcol[k], readlane_f64(rr * myinv, k), rr);
         rr *= myinv;                         // dx_u
       } else {
-        LSYNC();
-        rr = phi_tmul(q3);
-        if (lane < nu) rr += -r1u - ct_mul(dwc, lane);
         for (int k = 0; k < nu; ++k) {
           double yk = readlane_f64(rr * myinv, k);
           if (lane == k) rr = yk;
@@ -684,8 +721,8 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
         double Fdx = fa0[i] * s3[t * 3] + fa1[i] * s3[t * 3 + 1] - dxd[t];
         double dl = -(dwf[i] + l * Fdx * iwf[i]);             // -(r4 + l r3 + l Fdx)/(w + l/ro)
         double dw = Fdx + dl * iro + r3[i];
-        if (dl < 0) amax = fmin(amax, -l * fast_rcp(dl));
-        if (dw < 0) amax = fmin(amax, -w * fast_rcp(dw));
+        if (dl < 0) amax = fmin(amax, -l * rough_rcp(dl));
+        if (dw < 0) amax = fmin(amax, -w * rough_rcp(dw));
         dlf[i] = dl; dwf[i] = dw;
       }
       for (int i = lane; i < mcu; i += QP_THREADS) {
@@ -696,8 +733,8 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
           double Cdx = (i < 4 * T) ? sg * dxu[v] : sg * (dxu[v + 2] - dxu[v]);
           dl = dwc[i] + lc[i] * Cdx * iwc[i];                   // (lc r2 - r4 + lc Cdx)/wc
           dw = -r2[i] - Cdx;
-          if (dl < 0) amax = fmin(amax, -lc[i] * fast_rcp(dl));
-          if (dw < 0) amax = fmin(amax, -wc[i] * fast_rcp(dw));
+          if (dl < 0) amax = fmin(amax, -lc[i] * rough_rcp(dl));
+          if (dw < 0) amax = fmin(amax, -wc[i] * rough_rcp(dw));
         }
         dlc[i] = dl; dwc[i] = dw;
       }
@@ -706,8 +743,8 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
         double Cdx = (i & 1) ? -dxd[t] : dxd[t];
         double dl = dwd[i] + ld_[i] * Cdx * iwd[i];
         double dw = -r2d[i] - Cdx;
-        if (dl < 0) amax = fmin(amax, -ld_[i] * fast_rcp(dl));
-        if (dw < 0) amax = fmin(amax, -wd[i] * fast_rcp(dw));
+        if (dl < 0) amax = fmin(amax, -ld_[i] * rough_rcp(dl));
+        if (dw < 0) amax = fmin(amax, -wd[i] * rough_rcp(dw));
         dld[i] = dl; dwd[i] = dw;
       }
       amax = wave_reduce<OpMin>(amax);
@@ -762,6 +799,13 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
       if (cur_d_out) cur_d_out[(size_t)b * T + t] = fv;
       if (out_d) out_d[(size_t)b * T + t] = fv;
     }
+  if (wrm) {
+    for (int a = lane; a < nu + T; a += QP_THREADS) wrm[a] = xbest[a];
+    for (int i = lane; i < mf; i += QP_THREADS) wrm[nu + T + i] = lf[i];
+    for (int i = lane; i < mcu; i += QP_THREADS) wrm[nu + T + mf + i] = lc[i];
+    for (int i = lane; i < 2 * T && obs; i += QP_THREADS) wrm[nu + T + mf + mcu + i] = ld_[i];
+    if (flags && lane == 0) flags[b * 4 + 2] = (status == 0) ? 1 : 0;
+  }
   if (qp_info && lane == 0) {
     double* qi = qp_info + (size_t)b * QP_INFO_STRIDE;
     qi[0] = best_it; qi[1] = best_merit; qi[2] = last_mu; qi[3] = status; qi[4] = it;
@@ -860,7 +904,7 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
                                     const float* dist_sorted, const int* count, float* cur_s_out, float* cur_u_out,
                                     float* cur_d_out, float* out_s, float* out_u, float* out_d,
                                     float* out_min_distance, int* out_iters, float* out_nrmp_points, int* flags,
-                                    float* state, double* qp_info, hipStream_t stream) {
+                                    float* state, double* qp_info, double* warm, hipStream_t stream) {
   const size_t wave_bytes = npa_qp_shmem_bytes(P.T, P.M);
   // as many scenes per workgroup as LDS allows (<= QP_WAVES)
   int wpg = (int)((160 * 1024) / wave_bytes);
@@ -880,7 +924,7 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
   hipLaunchKernelGGL((nrmp_qp_kernel<TTV, MMV>), dim3(nblocks), dim3(QP_THREADS * wpg), shmem, stream, P, cur_s_in, cur_u_in, \
                      ref_s, ref_us, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count, cur_s_out, cur_u_out, \
                      cur_d_out, out_s, out_u, out_d, out_min_distance, out_iters, out_nrmp_points, flags, state, \
-                     qp_info, scene0, batch, wave_doubles, wpg)
+                     qp_info, warm, scene0, batch, wave_doubles, wpg)
   if (P.T == 10 && P.M == 10 && !force_generic) QP_LAUNCH(10, 10);
   else if (P.T == 20 && P.M == 10 && !force_generic) QP_LAUNCH(20, 10);
   else QP_LAUNCH(0, 0);

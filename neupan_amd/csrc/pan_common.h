@@ -45,10 +45,14 @@ __host__ __device__ inline size_t npa_state_floats(int T, int M, int E) {
 
 // ---- scratch: struct-of-arrays over the batch (offsets in 4-byte words) ---------------------
 // cur_s [B][3][T+1]  cur_u [B][2][T]  cur_d [B][T]  mu [B][T+1][M][E]  lam [B][T+1][M][2]
-// pts [B][T+1][M][2]  dist [B][T+1][M]  count [B][T+1] (int)  flags [B][4] (int: done, iters)
+// pts [B][T+1][M][2]  dist [B][T+1][M]  count [B][T+1] (int)
+// flags [B][4] (int: done, iters, warm-start valid)  warm [B][nwarm] (double: x, multipliers)
 struct ScratchLayout {
-  size_t cur_s, cur_u, cur_d, mu, lam, pts, dist, count, flags, total;
+  size_t cur_s, cur_u, cur_d, mu, lam, pts, dist, count, flags, warm, qp_info, total;
 };
+__host__ __device__ inline size_t npa_warm_doubles(int T, int M) {   // per scene
+  return (size_t)2 * T + T + (size_t)T * M + (8 * T - 4) + 2 * T;
+}
 __host__ __device__ inline ScratchLayout npa_scratch_layout(int B, int T, int M, int E) {
   ScratchLayout L;
   size_t o = 0;
@@ -62,6 +66,9 @@ __host__ __device__ inline ScratchLayout npa_scratch_layout(int B, int T, int M,
   L.dist = take((size_t)B * (T + 1) * M);
   L.count = take((size_t)B * (T + 1));
   L.flags = take((size_t)B * 4);
+  o = (o + 3) & ~(size_t)3;                       // 16-byte alignment for the doubles
+  L.warm = take((size_t)B * npa_warm_doubles(T, M) * 2);
+  L.qp_info = take((size_t)B * 16 * 2);          // per-scene solver diagnostics of the last QP (16 doubles)
   L.total = o;
   return L;
 }

@@ -242,10 +242,12 @@ class PAN(torch.nn.Module):
         return t
 
     # ------------------------------------------------------------------ batched entry
-    def forward_batch(self, nom_s, nom_u, ref_s, ref_us, points=None, velocities=None, n_points=None):
-        """Plan B independent scenes.  Shapes: nom_s (B,3,T+1) nom_u (B,2,T) ref_s (B,3,T+1)
-        ref_us (B,T) points (B,2,N)|None velocities (B,2,N)|None n_points (B,) int32|None.
-        Returns dict(opt_s, opt_u, opt_d|None, min_distance (B,), iters (B,), nrmp_points (B,2,M)|None)."""
+    def forward_begin(self, nom_s, nom_u, ref_s, ref_us, points=None, velocities=None, n_points=None,
+                      qp_on_helper_stream=False):
+        """Stage one batch (see forward_batch for shapes) and start a forward: follow with
+        forward_iter(k) for k in range(iter_num) and forward_end().  With qp_on_helper_stream the QP
+        chain of this batch runs on the handle's helper stream so that another planner's DUNE
+        launches, enqueued on the same (current) stream, overlap it -- see forward_interleaved."""
         T, M = self.T, self.nrmp_max_num
         nom_s = self._dev(nom_s)
         B = nom_s.shape[0]
@@ -280,15 +282,34 @@ class PAN(torch.nn.Module):
         out_np = torch.zeros((B, 2, M), dtype=torch.float32, device=dev) if not self.no_obs else None
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            check(self._lib.npa_forward_batch(
+            check(self._lib.npa_forward_begin(
                 self._h, B, max(n_stride, 1), _ptr(nom_s), _ptr(nom_u), _ptr(ref_s), _ptr(ref_us), _ptr(points),
                 _ptr(velocities), _ptr(n_points), _ptr(out_s), _ptr(out_u), _ptr(out_d), _ptr(out_md), _ptr(out_it),
-                _ptr(out_np), _ptr(ws), ws.numel(), _ptr(state), state.numel(), C.c_void_p(stream)),
-                "npa_forward_batch")
+                _ptr(out_np), _ptr(ws), ws.numel(), _ptr(state), state.numel(), C.c_void_p(stream),
+                1 if qp_on_helper_stream else 0), "npa_forward_begin")
         # keep inputs alive until the stream has consumed them
         self._last = dict(points=points, velocities=velocities, n_points=n_points, min_distance=out_md,
                           nrmp_points=out_np, used_points=use_pts, hold=(nom_s, nom_u, ref_s, ref_us))
-        return dict(opt_s=out_s, opt_u=out_u, opt_d=out_d, min_distance=out_md, iters=out_it, nrmp_points=out_np)
+        self._pending = dict(opt_s=out_s, opt_u=out_u, opt_d=out_d, min_distance=out_md, iters=out_it, nrmp_points=out_np)
+
+    def forward_iter(self, k):
+        """Enqueue PAN iteration k (DUNE launch + QP launch) of the forward started by forward_begin."""
+        check(self._lib.npa_forward_iter(self._h, int(k)), "npa_forward_iter")
+
+    def forward_end(self):
+        """Join the helper streams; returns the output dict (device tensors, valid in stream order)."""
+        check(self._lib.npa_forward_end(self._h), "npa_forward_end")
+        out, self._pending = self._pending, None
+        return out
+
+    def forward_batch(self, nom_s, nom_u, ref_s, ref_us, points=None, velocities=None, n_points=None):
+        """Plan B independent scenes.  Shapes: nom_s (B,3,T+1) nom_u (B,2,T) ref_s (B,3,T+1)
+        ref_us (B,T) points (B,2,N)|None velocities (B,2,N)|None n_points (B,) int32|None.
+        Returns dict(opt_s, opt_u, opt_d|None, min_distance (B,), iters (B,), nrmp_points (B,2,M)|None)."""
+        self.forward_begin(nom_s, nom_u, ref_s, ref_us, points, velocities, n_points)
+        for k in range(self.iter_num):
+            self.forward_iter(k)
+        return self.forward_end()
 
     # ------------------------------------------------------------------ reference signature
     def forward(self, nom_s, nom_u, ref_s, ref_us, obs_points=None, point_velocities=None):
@@ -370,6 +391,13 @@ class PAN(torch.nn.Module):
         torch.cuda.synchronize(dev)
         return dict(opt_s=out_s, opt_u=out_u, opt_d=out_d, info=info)
 
+    def last_qp_info(self):
+        """(B,16) float64: per-scene diagnostics of the last QP solved by forward_batch
+        (best iteration, merit, mu, status, iterations run)."""
+        off = self._lib.npa_workspace_qp_info_offset(self._h, self._B)
+        torch.cuda.synchronize(self.device)
+        return self._ws[off:off + self._B * 16 * 8].view(torch.float64).reshape(self._B, 16).cpu().numpy()
+
     def profile(self, enable=True):
         check(self._lib.npa_profile_enable(self._h, 1 if enable else 0), "npa_profile_enable")
 
@@ -377,3 +405,20 @@ class PAN(torch.nn.Module):
         a, b, n = C.c_double(), C.c_double(), C.c_int64()
         check(self._lib.npa_profile_read(self._h, C.byref(a), C.byref(b), C.byref(n)), "npa_profile_read")
         return dict(dune_ms=a.value, nrmp_ms=b.value, launches=n.value)
+
+
+def forward_interleaved(planners, inputs):
+    """Plan several independent batches concurrently: `planners[i]` (one PAN per batch in flight,
+    same configuration) plans `inputs[i]` (the positional arguments of forward_batch).  The PAN
+    iterations are enqueued round-robin on the current stream, so the DUNE launches of all batches
+    stay ordered there while each batch's latency-bound QP runs on its planner's helper stream
+    underneath the other batches' DUNE launches.  Returns the list of output dicts."""
+    assert len(planners) == len(inputs) and len(planners) >= 1
+    K = planners[0].iter_num
+    for p, a in zip(planners, inputs):
+        assert p.iter_num == K
+        p.forward_begin(*a, qp_on_helper_stream=len(planners) > 1)
+    for k in range(K):
+        for p in planners:
+            p.forward_iter(k)
+    return [p.forward_end() for p in planners]

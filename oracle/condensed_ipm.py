@@ -74,7 +74,12 @@ def condense(pb: NrmpProblem):
     return H, g, F, f, C, c, Phi, cv
 
 
-def solve_condensed(pb: NrmpProblem, tol=1e-12, max_iter=40, trace=None):
+WARM_DELTA = 0.1        # QP_WARM_DELTA in nrmp_qp.hip
+
+
+def solve_condensed(pb: NrmpProblem, tol=1e-12, max_iter=40, trace=None, warm=None):
+    """warm = (x, lc, lf) of a previous, similar solve: the kernel's warm start across the PAN
+    iterations of one forward call (multipliers and slacks floored at WARM_DELTA)."""
     H, g, F, f, C, c, Phi, cv = condense(pb)
     n = H.shape[0]; T = pb.T; nu = 2 * T
     ro = pb.ro_obs
@@ -86,10 +91,17 @@ def solve_condensed(pb: NrmpProblem, tol=1e-12, max_iter=40, trace=None):
         x[nu:] = 0.5 * (max(pb.d_min, 0.0) + pb.d_max)
     lc = np.ones(mc); wc = np.maximum(c - C @ x, 1.0)
     lf = np.ones(mf); wf = np.maximum(F @ x - f + lf / ro, 1.0)
+    if warm is not None:
+        x = np.array(warm[0], dtype=float)
+        if not pb.no_obs:
+            x[nu:] = np.clip(x[nu:], max(pb.d_min, 0.0), pb.d_max)
+        lc = np.maximum(warm[1], WARM_DELTA); lf = np.maximum(warm[2], WARM_DELTA)
+        wc = np.maximum(c - C @ x, WARM_DELTA); wf = np.maximum(F @ x - f + lf / ro, WARM_DELTA)
     scale_d = 1.0 + np.abs(g).max()
     scale_p = 1.0 + (np.abs(c).max() if mc else 0.0)
     best = (np.inf, x.copy(), 0)
     stall = 0
+    lam_out = (lc, lf)
     for it in range(max_iter + 1):
         r1 = H @ x + g + C.T @ lc - F.T @ lf
         r2 = C @ x + wc - c
@@ -135,8 +147,9 @@ def solve_condensed(pb: NrmpProblem, tol=1e-12, max_iter=40, trace=None):
         dx, dwc, dlc, dwf, dlf = solve(lc * wc + dwc * dlc - sigma * mu, lf * wf + dwf * dlf - sigma * mu)
         a = min(1.0, 0.995 * min(max_step(wc, dwc), max_step(lc, dlc), max_step(wf, dwf), max_step(lf, dlf)))
         x = x + a * dx; wc = wc + a * dwc; lc = lc + a * dlc; wf = wf + a * dwf; lf = lf + a * dlf
+        lam_out = (lc, lf)
     merit, x, it_used = best
     u = x[:nu].reshape(T, 2).T.copy()
     s = np.stack([Phi[t] @ x[:nu] + cv[t] for t in range(T + 1)], axis=1)
     d = None if pb.no_obs else x[nu:].reshape(1, T).copy()
-    return s, u, d, {"iters": it_used, "merit": merit}
+    return s, u, d, {"iters": it_used, "merit": merit, "warm": (x, lam_out[0], lam_out[1])}

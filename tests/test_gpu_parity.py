@@ -196,3 +196,25 @@ def test_full_size_batch_properties():
     assert (d >= 0.1 - 1e-6).all() and (d <= 1.0 + 1e-6).all()
     assert np.array_equal(s[:, :, 0], batch["nom_s"][:, :, 0])
     assert (out["min_distance"].cpu().numpy() > 0).all()
+
+
+def test_interleaved_batches_equal_sequential():
+    """forward_interleaved (several batches in flight, QP on helper streams) must give bitwise the
+    results of planning each batch on its own."""
+    from gpu_helpers import make_gpu_pan
+    from neupan_amd.pan import forward_interleaved
+    cfg = CONFIGS["diff_1k_T10_K10"]
+    B = 48
+    inputs = []
+    for j in range(3):
+        b = make_batch(cfg, 500 + j * B, B, 400)
+        inputs.append([b[k] for k in ("nom_s", "nom_u", "ref_s", "ref_us", "points")])
+    pans = [make_gpu_pan(cfg, dune_max_num=400, iter_num=4) for _ in range(3)]
+    outs = forward_interleaved(pans, inputs)
+    ref = make_gpu_pan(cfg, dune_max_num=400, iter_num=4)
+    for j in range(3):
+        ref.reset_stop_state()
+        o = ref.forward_batch(*inputs[j])
+        assert np.array_equal(o["opt_u"].cpu().numpy(), outs[j]["opt_u"].cpu().numpy())
+        assert np.array_equal(o["opt_s"].cpu().numpy(), outs[j]["opt_s"].cpu().numpy())
+        assert (outs[j]["iters"].cpu().numpy() == 4).all()

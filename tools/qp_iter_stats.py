@@ -1,0 +1,16 @@
+"""Iteration statistics of the QP solves along the PAN iterations of one forward call."""
+import sys, os, numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from gpu_helpers import make_gpu_pan
+from helpers import CONFIGS
+from neupan_amd.scenes import make_batch
+cfg = CONFIGS["diff_1k_T10_K10"]; B = 256
+batch = make_batch(cfg, 0, B)
+args = [batch[k] for k in ("nom_s", "nom_u", "ref_s", "ref_us", "points")]
+for K in (1, 2, 3, 5, 10):
+    pan = make_gpu_pan(cfg, iter_num=K)
+    pan.forward_batch(*args)
+    info = pan.last_qp_info()
+    print("K=%2d last-QP iterations: mean %.2f max %d  status!=0: %d  merit max %.1e" %
+          (K, info[:, 4].mean(), info[:, 4].max(), (info[:, 3] != 0).sum(), info[:, 1].max()))
