@@ -11,10 +11,15 @@
 #include <string>
 #include <vector>
 
-extern "C" hipError_t npa_launch_dune(const DevParams& P, const float* wpack, int batch, int scene0, int t0, int n_stride,
-                                      const float* cur_s, const float* points, const float* vel,
-                                      const int* n_points, const int* flags, float* mu_sorted, float* lam_sorted,
-                                      float* pts_sorted, float* dist_sorted, int* count, hipStream_t stream);
+extern "C" hipError_t npa_launch_encode(const DevParams& P, const float* wpack, int batch, int scene0, int t0,
+                                        int n_stride, const float* cur_s, const float* points, const float* vel,
+                                        const int* n_points, const int* flags, unsigned* gkeys, int n_cu,
+                                        int blocks_per_cu, hipStream_t stream);
+extern "C" hipError_t npa_launch_select(const DevParams& P, const float* wpack, int batch, int scene0, int t0,
+                                        int n_stride, const float* cur_s, const float* points, const float* vel,
+                                        const int* n_points, const int* flags, const unsigned* gkeys,
+                                        float* mu_sorted, float* lam_sorted, float* pts_sorted, float* dist_sorted,
+                                        int* count, hipStream_t stream);
 extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, const float* cur_s_in,
                                     const float* cur_u_in, const float* ref_s, const float* ref_us, const float* mu_sorted,
                                     const float* lam_sorted, const float* pts_sorted, const float* dist_sorted,
@@ -38,10 +43,14 @@ struct npa_handle {
   DevParams P;
   float* wpack = nullptr;     // device
   int device = 0;
+  int n_cu = 256;
+  float* stage_cand = nullptr;   // candidate scratch of npa_dune_stage (grown on demand)
+  size_t stage_cand_bytes = 0;
   // sub-batch pipelining: DUNE launches stay in order on the caller's stream, each
   // sub-batch's QP chain runs on its own helper stream so it overlaps the other
   // sub-batches' DUNE launches (the QP is latency bound and occupies one wave per scene)
   int n_sub = 2;
+  int enc_blocks_shared = 4;  // encode workgroups per CU while QP kernels run underneath
   bool warm_start = true;     // IPM warm start across the PAN iterations of one forward call
   hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> sync_ev;
@@ -72,6 +81,11 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
   memset(&P, 0, sizeof(P));
   P.T = cfg->receding; P.M = (cfg->dune_max_num > 0) ? cfg->nrmp_max_num : 0; P.E = cfg->edge_num;
   P.kin = cfg->kinematics; P.K = cfg->iter_num; P.dune_max_num = cfg->dune_max_num;
+  {
+    long long n = cfg->dune_max_num > 0 ? cfg->dune_max_num : 1;
+    if (n > NPA_MAX_POINTS) n = NPA_MAX_POINTS;
+    P.key_stride = (int)((n + 31) / 32 * 32);
+  }
   P.iter_threshold = cfg->iter_threshold;
   P.dt = cfg->step_time; P.dt32 = (float)cfg->step_time; P.L = cfg->wheelbase;
   for (int k = 0; k < 2; ++k) { P.speed_bound[k] = cfg->speed_bound[k]; P.acce_bound[k] = cfg->acce_bound[k]; }
@@ -109,7 +123,13 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
     if (v >= 1 && v <= 4) h->n_sub = v;
   }
   if (const char* env = getenv("NPA_QP_WARM")) h->warm_start = atoi(env) != 0;
+  if (const char* env = getenv("NPA_ENC_BLOCKS")) { int v = atoi(env); if (v >= 1 && v <= 4) h->enc_blocks_shared = v; }
   hipError_t e = hipGetDevice(&h->device);
+  if (e == hipSuccess) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0)
+      h->n_cu = prop.multiProcessorCount;
+  }
   for (int i = 0; i < (h->n_sub > 1 ? h->n_sub : 1) && e == hipSuccess; ++i)
     e = hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc(&h->wpack, WP_TOTAL * sizeof(float));
@@ -131,6 +151,7 @@ extern "C" int npa_destroy(npa_handle* h) {
   for (auto& ev : h->sync_ev) hipEventDestroy(ev);
   for (int i = 0; i < 4; ++i) if (h->aux[i]) hipStreamDestroy(h->aux[i]);
   if (h->wpack) hipFree(h->wpack);
+  if (h->stage_cand) hipFree(h->stage_cand);
   delete h;
   return NPA_OK;
 }
@@ -144,11 +165,11 @@ extern "C" int npa_set_adjust(npa_handle* h, const float q_s[3], float p_u, floa
 
 extern "C" size_t npa_workspace_bytes(const npa_handle* h, int batch) {
   if (!h || batch < 1) return 0;
-  return npa_scratch_layout(batch, h->P.T, mdim(h->P), h->P.E).total * sizeof(float);
+  return npa_scratch_layout(batch, h->P.T, mdim(h->P), h->P.E, h->P.key_stride).total * sizeof(float);
 }
 extern "C" size_t npa_workspace_qp_info_offset(const npa_handle* h, int batch) {
   if (!h || batch < 1) return 0;
-  return npa_scratch_layout(batch, h->P.T, mdim(h->P), h->P.E).qp_info * sizeof(float);
+  return npa_scratch_layout(batch, h->P.T, mdim(h->P), h->P.E, h->P.key_stride).qp_info * sizeof(float);
 }
 extern "C" size_t npa_state_bytes(const npa_handle* h, int batch) {
   if (!h || batch < 1) return 0;
@@ -202,8 +223,26 @@ extern "C" int npa_dune_stage(npa_handle* h, int batch, int n_stride, const floa
       !dist_sorted || !count)
     return fail(NPA_E_ARG, "npa_dune_stage: bad argument");
   if (h->P.M <= 0) return fail(NPA_E_ARG, "npa_dune_stage: planner has no obstacle stage (nrmp_max_num or dune_max_num is 0)");
-  HIP_TRY(npa_launch_dune(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr, mu_sorted,
-                          lam_sorted, pts_sorted, dist_sorted, count, (hipStream_t)stream));
+  {
+    int nmax = n_stride < h->P.dune_max_num ? n_stride : h->P.dune_max_num;
+    if (nmax > h->P.key_stride) return fail(NPA_E_UNSUPPORTED, "more than 32768 points per scene after decimation");
+  }
+  // key scratch (+ one work counter) owned by the handle (the stage entry point is a
+  // test/profiling hook, the production path carves both from the caller's workspace)
+  const size_t key_bytes = (size_t)batch * (h->P.T + 1) * h->P.key_stride * sizeof(unsigned);
+  const size_t need = key_bytes + 64;
+  if (need > h->stage_cand_bytes) {
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (h->stage_cand) HIP_TRY(hipFree(h->stage_cand));
+    h->stage_cand = nullptr; h->stage_cand_bytes = 0;
+    HIP_TRY(hipMalloc(&h->stage_cand, need));
+    h->stage_cand_bytes = need;
+  }
+  HIP_TRY(npa_launch_encode(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr,
+                            (unsigned*)h->stage_cand, h->n_cu, 4, (hipStream_t)stream));
+  HIP_TRY(npa_launch_select(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr,
+                            (const unsigned*)h->stage_cand, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count,
+                            (hipStream_t)stream));
   return NPA_OK;
 }
 
@@ -260,12 +299,14 @@ extern "C" int npa_forward_begin(npa_handle* h, int batch, int n_stride, const f
   if (workspace_bytes < npa_workspace_bytes(h, batch)) return fail(NPA_E_ARG, "workspace too small");
   if (state_bytes < npa_state_bytes(h, batch)) return fail(NPA_E_ARG, "state buffer too small");
   if (points && n_stride < 1) return fail(NPA_E_ARG, "n_stride < 1");
+  if (points && (n_stride < P.dune_max_num ? n_stride : P.dune_max_num) > P.key_stride)
+    return fail(NPA_E_UNSUPPORTED, "more than 32768 points per scene after decimation");
   std::lock_guard<std::mutex> lock(g_pending_mu);
   PendingCall* pc = pending_of(h, true);
   if (pc->active) return fail(NPA_E_ARG, "npa_forward_begin: previous forward on this handle not ended");
   hipStream_t stream = (hipStream_t)stream_;
   const int T = P.T;
-  const ScratchLayout L = npa_scratch_layout(batch, T, mdim(P), P.E);
+  const ScratchLayout L = npa_scratch_layout(batch, T, mdim(P), P.E, P.key_stride);
   float* ws = (float*)workspace;
   HIP_TRY(hipMemcpyAsync(ws + L.cur_s, nom_s, (size_t)batch * 3 * (T + 1) * sizeof(float), hipMemcpyDeviceToDevice, stream));
   HIP_TRY(hipMemcpyAsync(ws + L.cur_u, nom_u, (size_t)batch * 2 * T * sizeof(float), hipMemcpyDeviceToDevice, stream));
@@ -277,7 +318,8 @@ extern "C" int npa_forward_begin(npa_handle* h, int batch, int n_stride, const f
   pc->state = (float*)state; pc->stream = stream;
   pc->dune = P.M > 0 && points != nullptr;
   // sub-batches [lo_i, hi_i): DUNE(i,k) on `stream` in (k, i) order, QP(i,k) on aux[i]
-  pc->nsub = (h->n_sub > 1 && pc->dune && batch >= 16 * h->n_sub) ? h->n_sub : 1;
+  // (when the caller interleaves several batches the batches themselves are the pipeline stages)
+  pc->nsub = (h->n_sub > 1 && pc->dune && batch >= 16 * h->n_sub && !qp_on_helper_stream) ? h->n_sub : 1;
   pc->qp_aux = pc->dune && (pc->nsub > 1 || (qp_on_helper_stream && h->aux[0]));
   const size_t need_ev = (size_t)2 * pc->nsub * P.K + 1;
   while (h->sync_ev.size() < need_ev) {
@@ -301,7 +343,7 @@ extern "C" int npa_forward_iter(npa_handle* h, int k) {
   const DevParams& P = h->P;
   if (k < 0 || k >= P.K) return fail(NPA_E_ARG, "npa_forward_iter: iteration index out of range");
   const int T = P.T, batch = pc->batch, nsub = pc->nsub;
-  const ScratchLayout L = npa_scratch_layout(batch, T, mdim(P), P.E);
+  const ScratchLayout L = npa_scratch_layout(batch, T, mdim(P), P.E, P.key_stride);
   float* ws = pc->ws;
   float *cur_s = ws + L.cur_s, *cur_u = ws + L.cur_u, *cur_d = ws + L.cur_d;
   float *mu = ws + L.mu, *lam = ws + L.lam, *pts = ws + L.pts, *dist = ws + L.dist;
@@ -309,6 +351,7 @@ extern "C" int npa_forward_iter(npa_handle* h, int k) {
   int* flags = (int*)(ws + L.flags);
   double* warm = (double*)(ws + L.warm);
   double* qp_info = (double*)(ws + L.qp_info);
+  unsigned* gkeys = (unsigned*)(ws + L.keys);
   hipStream_t stream = pc->stream;
   auto lo = [&](int i) { return (int)((long long)batch * i / nsub); };
   auto ev_d = [&](int i, int kk) { return h->sync_ev[1 + (size_t)2 * (kk * nsub + i)]; };
@@ -320,13 +363,18 @@ extern "C" int npa_forward_iter(npa_handle* h, int k) {
       if (pc->qp_aux && k > 0) HIP_TRY(hipStreamWaitEvent(stream, ev_q(i, k - 1), 0));
       EventPair* ev = next_event(h, h->ev_dune, h->n_dune);
       if (ev) HIP_TRY(hipEventRecord(ev->a, stream));
-      HIP_TRY(npa_launch_dune(P, h->wpack, nb, s0, k == 0 ? 0 : 1, pc->n_stride, cur_s, pc->points, pc->velocities,
-                              pc->n_points, flags, mu, lam, pts, dist, count, stream));
+      const int t0 = k == 0 ? 0 : 1;
+      HIP_TRY(npa_launch_encode(P, h->wpack, nb, s0, t0, pc->n_stride, cur_s, pc->points, pc->velocities,
+                                pc->n_points, flags, gkeys, h->n_cu, pc->qp_aux ? h->enc_blocks_shared : 4, stream));
       if (ev) HIP_TRY(hipEventRecord(ev->b, stream));
       if (pc->qp_aux) {
         HIP_TRY(hipEventRecord(ev_d(i, k), stream));
         HIP_TRY(hipStreamWaitEvent(qs, ev_d(i, k), 0));
       }
+      // selection + QP follow the encode on the helper stream (when there is one): the next
+      // encode launch on `stream` -- another sub-batch or another batch in flight -- overlaps them
+      HIP_TRY(npa_launch_select(P, h->wpack, nb, s0, t0, pc->n_stride, cur_s, pc->points, pc->velocities,
+                                pc->n_points, flags, gkeys, mu, lam, pts, dist, count, qs));
     }
     EventPair* ev = next_event(h, h->ev_qp, h->n_qp);
     if (ev) HIP_TRY(hipEventRecord(ev->a, qs));

@@ -1,36 +1,48 @@
-// dune.hip -- point flow + DUNE encoder + nearest-M gather, one workgroup per
-// (scene, horizon step) slice.  gfx950 (MI355X) only.
+// dune.hip -- point flow + DUNE encoder + nearest-M, gfx950 (MI355X) only.
 //
-// Replaces, for every slice t of every scene (reference file:line):
+// Replaces, for every horizon slice t of every scene (reference file:line):
 //   PAN.generate_point_flow / point_state_transform   neupan/blocks/pan.py:150-212
 //   util.downsample_decimation                        neupan/util/__init__.py:285-305
 //   ObsPointNet forward                               neupan/blocks/obs_point_net.py:31-49
 //   DUNE.forward (lam, distance, sort, gathers)       neupan/blocks/dune.py:58-127
 // Only the first M sorted columns are ever consumed downstream (nrmp.py:254-255,
-// pan.py:234-237), so instead of a full argsort the kernel keeps the slice's distances in
-// LDS, extracts the M smallest (distance, index) keys in ascending order, and re-evaluates
-// the encoder for just those M points to emit mu / lam / point / distance rows -- nothing
-// per-point ever goes to HBM.
+// pan.py:234-237), so no full argsort is done and nothing per-point goes to HBM.
+//
+// Work decomposition (two launches per PAN iteration)
+//   dune_kernel    a flat stream of 32-point tiles over all (scene, slice) pairs of the launch, cut
+//                  into equal contiguous chunks, one chunk per resident wave: every wave does the
+//                  same number of tiles (+-1), never synchronises with another wave and writes one
+//                  order-preserving 32-bit distance key per point (4 B/point, L2/MALL resident).
+//   select_kernel  one wave per slice: reads the slice's keys, extracts the M smallest
+//                  (distance, index) pairs in ascending order (stable ties), re-encodes just those
+//                  M points (one tile) and writes the sorted mu / lam / point / distance rows the
+//                  QP consumes.  Rows >= min(N,M) replicate row 0 (padding rule of nrmp.py:258-259).
 //
 // Mapping to the hardware
-//   * 4 waves per workgroup; a wave pushes tiles of 32 points through the MLP.  The four
-//     32x32 layers run on v_mfma_f32_32x32x2_f32 (exact fp32, 16 K-steps per layer) with the
-//     points on the N axis: lane (j = lane&31, hf = lane>>5) ends a layer holding features
-//     feat(r,hf) of point j in accumulator register r, which is precisely the B operand
-//     layout of the next layer's K-step r -- activations never leave their registers.
-//     Weight A-fragments (65 VGPRs) are loaded once per wave and reused for every tile.
-//   * bias / LayerNorm affine vectors and the 32xE output layer sit in LDS; a lane fetches
-//     its 16 features with four broadcast ds_read_b128.
-//   * LayerNorm reductions: 16 in-lane adds + one v_permlane32_swap (features of a point
-//     live in lanes j and j+32).
-//   * the 2->32 input layer is one MFMA (K=2); the 32->E output layer is VALU work
-//     (an MFMA would waste 28 of 32 rows).
+//   * the four 32x32 layers run on v_mfma_f32_32x32x2_f32 (exact fp32, 16 K-steps per layer) with
+//     the points on the N axis: lane (j = lane&31, hf = lane>>5) ends a layer holding features
+//     feat(r,hf) of point j in accumulator register r, which is precisely the B operand layout
+//     of the next layer's K-step r -- activations never leave their registers.  Weight
+//     A-fragments (65 VGPRs) are loaded once per wave; 128 VGPRs total -> 4 waves per SIMD.
+//   * bias / LayerNorm affine vectors and the 32xE output layer sit in LDS (broadcast
+//     ds_read_b128); the tanh scale 2*log2(e) is folded into gamma/beta on the host.
+//   * LayerNorm reductions: 16 in-lane adds + one v_permlane32_swap (features of a point live in
+//     lanes j and j+32).  The 2->32 input layer is one MFMA (K=2); the 32->E output layer is VALU.
+//   * on gfx950 the fp32-input MFMA and fp32 VALU work serialise on the SIMD (PMC:
+//     SQ_VALU_MFMA_COEXEC_CYCLES = 0), so the VALU instruction count per tile matters as much as
+//     the 65 MFMAs.
 #include "pan_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define DUNE_THREADS 256
 #define DUNE_WAVES 4
+
+#define WSYNC()                                              \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   \
+    __builtin_amdgcn_wave_barrier();                         \
+  } while (0)
 
 __device__ __forceinline__ float pair_sum(float x) {
   // value + value of lane^32 (bitwise identical in both lanes: fp add commutes)
@@ -145,13 +157,24 @@ __device__ __forceinline__ unsigned ordered_key(float d) {
   return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
+  unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xF, 0xF, false);
+  unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xF, 0xF, false);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long umin64(unsigned long long a, unsigned long long b) { return a < b ? a : b; }
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l) {
+  unsigned lo = __builtin_amdgcn_readlane((unsigned)v, l), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), l);
+  return ((unsigned long long)hi << 32) | lo;
+}
+// full-wave min of a 64-bit key (DPP inside each 16-lane row, then 4 readlanes); uniform result
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    unsigned long long o = __shfl_xor(v, off, 64);
-    v = o < v ? o : v;
-  }
-  return v;
+  v = umin64(v, dpp_u64<0xB1>(v));
+  v = umin64(v, dpp_u64<0x4E>(v));
+  v = umin64(v, dpp_u64<0x141>(v));
+  v = umin64(v, dpp_u64<0x140>(v));
+  return umin64(umin64(readlane_u64(v, 0), readlane_u64(v, 16)), umin64(readlane_u64(v, 32), readlane_u64(v, 48)));
 }
 
 struct SliceFrame {
@@ -168,6 +191,31 @@ __device__ __forceinline__ int src_index(int n, int n_raw, int n_use) {
   return (int)((double)n * step);
 }
 
+// frame of a slice: robot pose at horizon step t, (-R)G^T
+template <int E>
+__device__ __forceinline__ void load_frame(const DevParams& P, const float* __restrict__ cur_s, int b, int t,
+                                           SliceFrame& F) {
+  const int T = P.T;
+  const float* s = cur_s + (size_t)b * 3 * (T + 1);
+  float th = s[2 * (T + 1) + t];
+  F.tx = s[t];
+  F.ty = s[(T + 1) + t];
+  F.c = (float)cos((double)th);
+  F.s = (float)sin((double)th);
+  F.tstep = (float)t;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {     // (-R) @ G^T, R = [[c,-s],[s,c]]
+    F.rg[0][e] = fmaf(-F.c, P.G[e][0], __fmul_rn(F.s, P.G[e][1]));
+    F.rg[1][e] = fmaf(-F.s, P.G[e][0], -__fmul_rn(F.c, P.G[e][1]));
+  }
+  // the frame is wave-uniform: park it in SGPRs, the VGPR budget (128) is tight
+  auto uni = [](float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); };
+  F.c = uni(F.c); F.s = uni(F.s); F.tx = uni(F.tx); F.ty = uni(F.ty); F.tstep = uni(F.tstep);
+#pragma unroll
+  for (int e = 0; e < E; ++e) { F.rg[0][e] = uni(F.rg[0][e]); F.rg[1][e] = uni(F.rg[1][e]); }
+}
+
+// one point (two lanes) through point flow + encoder + lam/distance
 template <int E>
 __device__ __forceinline__ void point_features(const DevParams& P, const SliceFrame& F, const WaveWeights& W,
                                                const float* vec, const float* w6, const float* b6,
@@ -196,122 +244,191 @@ __device__ __forceinline__ void point_features(const DevParams& P, const SliceFr
   }
 }
 
+__device__ __forceinline__ void load_weights(const float* __restrict__ wpack, int lane, WaveWeights& W) {
+  W.w1 = wpack[WP_W1 + lane];
+#pragma unroll
+  for (int l = 0; l < 4; ++l)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) W.wl[l][r] = wpack[WP_WL + (l * 16 + r) * 64 + lane];
+}
+
+// ---- launch 1: distance key of every point of every slice -----------------------------------------
+// tile id -> (scene, slice, tile in slice); tiles_per_slice = key_stride/32
 template <int E>
 __global__ __launch_bounds__(DUNE_THREADS, 4) void dune_kernel(
     DevParams P, const float* __restrict__ wpack, int n_stride, const float* __restrict__ cur_s,
     const float* __restrict__ points, const float* __restrict__ vel, const int* __restrict__ n_points,
-    const int* __restrict__ flags, float* __restrict__ mu_sorted, float* __restrict__ lam_sorted,
-    float* __restrict__ pts_sorted, float* __restrict__ dist_sorted, int* __restrict__ count, int scene0,
-    int t0) {
+    const int* __restrict__ flags, unsigned* __restrict__ gkeys, int key_stride, int scene0, int nscene, int t0) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* vec = smem;                       // [11][32]
+  float* w6 = vec + 11 * 32;               // [8][32]
+  float* b6 = w6 + 8 * 32;                 // [8]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, hf = lane >> 5;
+  const int T = P.T;
+
+  for (int i = tid; i < 11 * 32 + 8 * 32 + 8; i += DUNE_THREADS) smem[i] = wpack[WP_VEC + i];
+  WaveWeights W;
+  load_weights(wpack, lane, W);
+  __syncthreads();                          // the only workgroup barrier: vectors staged
+
+  const int nsl = T + 1 - t0;
+  const int tps = key_stride >> 5;                          // tiles per slice
+  const long long total = (long long)nscene * nsl * tps;
+  // Work distribution: the tile stream is cut into equal contiguous chunks, one per resident wave
+  // (a dynamic hand-out through atomic tickets was measured slower: per-chunk frame set-up and the
+  // ticket round trip cost more than the imbalance they remove).
+  const long long nwaves = (long long)gridDim.x * DUNE_WAVES, wid = (long long)blockIdx.x * DUNE_WAVES + wave;
+  const long long lo = total * wid / nwaves, hi = total * (wid + 1) / nwaves;
+  int cur_b = -1, cur_t = -1, n_raw = 0, n_use = 0;
+  bool skip = false;
+  SliceFrame F;
+  const float *px_row = nullptr, *py_row = nullptr, *vx_row = nullptr, *vy_row = nullptr;
+#pragma unroll 1
+  for (long long g = lo; g < hi; ++g) {
+    const int sl = (int)(g / tps), tile = (int)(g - (long long)sl * tps);
+    const int bl = sl / nsl, t = sl - bl * nsl + t0, b = bl + scene0;
+    if (b != cur_b || t != cur_t) {                          // wave-uniform: at most a few times per chunk
+      cur_b = b; cur_t = t;
+      n_raw = n_points ? n_points[b] : n_stride;
+      n_use = n_raw < P.dune_max_num ? n_raw : P.dune_max_num;
+      skip = (flags && flags[b * 4 + 0]) || n_use <= 0;     // converged scene (pan.py:144-145) / no points
+      if (!skip) {
+        load_frame<E>(P, cur_s, b, t, F);
+        px_row = points + (size_t)b * 2 * n_stride;
+        py_row = px_row + n_stride;
+        vx_row = vel ? vel + (size_t)b * 2 * n_stride : nullptr;
+        vy_row = vel ? vx_row + n_stride : nullptr;
+      }
+    }
+    if (skip || tile * 32 >= n_use) continue;
+    const int n = tile * 32 + j;
+    const int nc = n < n_use ? n : n_use - 1;
+    float mu[E], gx, gy, lx, ly, dist;
+    point_features<E>(P, F, W, vec, w6, b6, px_row, py_row, vx_row, vy_row, src_index(nc, n_raw, n_use), hf, mu, gx,
+                      gy, lx, ly, dist);
+    if (hf == 0 && n < n_use) gkeys[((size_t)b * (T + 1) + t) * key_stride + n] = ordered_key(dist);
+  }
+}
+
+// ---- launch 2: the M nearest of a slice, one wave per slice -----------------------------------------
+template <int E>
+__global__ __launch_bounds__(64, 4) void select_kernel(
+    DevParams P, const float* __restrict__ wpack, int n_stride, const float* __restrict__ cur_s,
+    const float* __restrict__ points, const float* __restrict__ vel, const int* __restrict__ n_points,
+    const int* __restrict__ flags, const unsigned* __restrict__ gkeys, int key_stride,
+    float* __restrict__ mu_sorted, float* __restrict__ lam_sorted, float* __restrict__ pts_sorted,
+    float* __restrict__ dist_sorted, int* __restrict__ count, int scene0, int t0) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* vec = smem;                       // [11][32]
   float* w6 = vec + 11 * 32;               // [8][32]
   float* b6 = w6 + 8 * 32;                 // [8]
   int* sel = reinterpret_cast<int*>(b6 + 8);            // [NPA_MAX_M]
   unsigned* dkey = reinterpret_cast<unsigned*>(sel + NPA_MAX_M);   // [n_use]
-
-  const int t = blockIdx.x + t0, b = blockIdx.y + scene0;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = blockIdx.x + t0, b = blockIdx.y + scene0, lane = threadIdx.x;
   const int j = lane & 31, hf = lane >> 5;
   const int T = P.T, M = P.M;
-  if (flags && flags[b * 4 + 0]) return;   // scene already converged (pan.py:144-145)
-
+  if (flags && flags[b * 4 + 0]) return;
   const int n_raw = n_points ? n_points[b] : n_stride;
   const int n_use = n_raw < P.dune_max_num ? n_raw : P.dune_max_num;
   const size_t orow = (size_t)b * (T + 1) + t;
   if (n_use <= 0) {
-    if (tid == 0) count[orow] = 0;
+    if (lane == 0) count[orow] = 0;
     return;
   }
-
-  for (int i = tid; i < 11 * 32 + 8 * 32 + 8; i += DUNE_THREADS) smem[i] = wpack[WP_VEC + i];
+  for (int i = lane; i < 11 * 32 + 8 * 32 + 8; i += 64) smem[i] = wpack[WP_VEC + i];
+  const unsigned* gk = gkeys + orow * key_stride;
+  for (int n = lane; n < n_use; n += 64) dkey[n] = gk[n];
   WaveWeights W;
-  W.w1 = wpack[WP_W1 + lane];
-#pragma unroll
-  for (int l = 0; l < 4; ++l)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) W.wl[l][r] = wpack[WP_WL + (l * 16 + r) * 64 + lane];
-
+  load_weights(wpack, lane, W);
   SliceFrame F;
-  {
-    const float* s = cur_s + (size_t)b * 3 * (T + 1);
-    float th = s[2 * (T + 1) + t];
-    F.tx = s[t];
-    F.ty = s[(T + 1) + t];
-    F.c = (float)cos((double)th);
-    F.s = (float)sin((double)th);
-    F.tstep = (float)t;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {     // (-R) @ G^T, R = [[c,-s],[s,c]]
-      F.rg[0][e] = fmaf(-F.c, P.G[e][0], __fmul_rn(F.s, P.G[e][1]));
-      F.rg[1][e] = fmaf(-F.s, P.G[e][0], -__fmul_rn(F.c, P.G[e][1]));
-    }
-  }
+  load_frame<E>(P, cur_s, b, t, F);
   const float* px_row = points + (size_t)b * 2 * n_stride;
   const float* py_row = px_row + n_stride;
   const float* vx_row = vel ? vel + (size_t)b * 2 * n_stride : nullptr;
   const float* vy_row = vel ? vx_row + n_stride : nullptr;
-  __syncthreads();
+  WSYNC();
 
-  // ---- phase 1: distance of every point of the slice --------------------------------
-  const int ntiles = (n_use + 31) >> 5;
-  for (int tile = wave; tile < ntiles; tile += DUNE_WAVES) {
-    int n = tile * 32 + j;
-    int nc = n < n_use ? n : n_use - 1;
-    float mu[E], gx, gy, lx, ly, dist;
-    point_features<E>(P, F, W, vec, w6, b6, px_row, py_row, vx_row, vy_row, src_index(nc, n_raw, n_use), hf, mu,
-                      gx, gy, lx, ly, dist);
-    if (hf == 0 && n < n_use) dkey[n] = ordered_key(dist);
-  }
-  __syncthreads();
-
-  // ---- phase 2: the M smallest (distance, index) keys, ascending (stable ties) --------
   const int msel = n_use < M ? n_use : M;
-  if (wave == 0) {
-    for (int m = 0; m < msel; ++m) {
-      unsigned long long best = ~0ull;
-      for (int n = lane; n < n_use; n += 64) {
-        unsigned long long k = ((unsigned long long)dkey[n] << 32) | (unsigned)n;
-        best = k < best ? k : best;
-      }
-      best = wave_min_u64(best);
-      int idx = (int)(best & 0xFFFFFFFFu);
-      if (lane == 0) { sel[m] = idx; dkey[idx] = 0xFFFFFFFFu; }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // LDS store -> later loads, same wave
-      __builtin_amdgcn_wave_barrier();
-    }
-    // ---- phase 3: re-encode the selected points and emit the sorted rows -------------
-    // rows >= msel replicate row 0, the padding rule of nrmp.py:258-259
-    int m = j < msel ? j : 0;
-    float mu[E], gx, gy, lx, ly, dist;
-    point_features<E>(P, F, W, vec, w6, b6, px_row, py_row, vx_row, vy_row, src_index(sel[m], n_raw, n_use), hf, mu,
-                      gx, gy, lx, ly, dist);
-    if (hf == 0 && j < M) {
-      size_t o = orow * M + j;
-#pragma unroll
-      for (int e = 0; e < E; ++e) mu_sorted[o * E + e] = mu[e];
-      lam_sorted[o * 2 + 0] = lx; lam_sorted[o * 2 + 1] = ly;
-      pts_sorted[o * 2 + 0] = gx; pts_sorted[o * 2 + 1] = gy;
-      dist_sorted[o] = dist;
-    }
-    if (lane == 0) count[orow] = msel;
+  for (int m = 0; m < msel; ++m) {
+    unsigned long long best = ~0ull;
+    for (int n = lane; n < n_use; n += 64) best = umin64(best, ((unsigned long long)dkey[n] << 32) | (unsigned)n);
+    best = wave_min_u64(best);
+    const int idx = (int)(best & 0xFFFFFFFFu);
+    if (lane == 0) { sel[m] = idx; dkey[idx] = 0xFFFFFFFFu; }
+    WSYNC();
   }
+  // re-encode the selected points and emit the sorted rows; rows >= msel replicate row 0
+  const int m = j < msel ? j : 0;
+  float mu[E], gx, gy, lx, ly, dist;
+  point_features<E>(P, F, W, vec, w6, b6, px_row, py_row, vx_row, vy_row, src_index(sel[m], n_raw, n_use), hf, mu, gx,
+                    gy, lx, ly, dist);
+  if (hf == 0 && j < M) {
+    size_t o = orow * M + j;
+#pragma unroll
+    for (int e = 0; e < E; ++e) mu_sorted[o * E + e] = mu[e];
+    lam_sorted[o * 2 + 0] = lx; lam_sorted[o * 2 + 1] = ly;
+    pts_sorted[o * 2 + 0] = gx; pts_sorted[o * 2 + 1] = gy;
+    dist_sorted[o] = dist;
+  }
+  if (lane == 0) count[orow] = msel;
 }
 
-// host-side launcher (called from c_api.hip)
+// ---- host-side launchers (called from c_api.hip) --------------------------------------------------
 // t0 = first horizon slice to evaluate: slice 0 does not depend on the iterate (s(0) is pinned,
-// robot.py:234), so after the first PAN iteration of a forward call only slices 1..T are redone
-extern "C" hipError_t npa_launch_dune(const DevParams& P, const float* wpack, int batch, int scene0, int t0, int n_stride,
-                                      const float* cur_s, const float* points, const float* vel,
-                                      const int* n_points, const int* flags, float* mu_sorted, float* lam_sorted,
-                                      float* pts_sorted, float* dist_sorted, int* count, hipStream_t stream) {
-  dim3 grid(P.T + 1 - t0, batch), block(DUNE_THREADS);
+// robot.py:234), so after the first PAN iteration of a forward call only slices 1..T are redone.
+// The two launches may go to different streams (select only needs the keys of its own scenes).
+static int tiles_per_slice(const DevParams& P, int n_stride) {
   int n_use_max = n_stride < P.dune_max_num ? n_stride : P.dune_max_num;
-  size_t shmem = (11 * 32 + 8 * 32 + 8) * sizeof(float) + NPA_MAX_M * sizeof(int) +
-                 ((size_t)(n_use_max > 0 ? n_use_max : 1) * sizeof(unsigned) + 15) / 16 * 16;
-#define LAUNCH(EE)                                                                                         \
-  hipLaunchKernelGGL(dune_kernel<EE>, grid, block, shmem, stream, P, wpack, n_stride, cur_s, points, vel,  \
-                     n_points, flags, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count, scene0, t0)
+  if (n_use_max < 1) n_use_max = 1;
+  return (n_use_max + 31) / 32;
+}
+
+extern "C" hipError_t npa_launch_encode(const DevParams& P, const float* wpack, int batch, int scene0, int t0,
+                                        int n_stride, const float* cur_s, const float* points, const float* vel,
+                                        const int* n_points, const int* flags, unsigned* gkeys, int n_cu,
+                                        int blocks_per_cu, hipStream_t stream) {
+  const int nsl = P.T + 1 - t0;
+  const int tps = tiles_per_slice(P, n_stride);
+  if (tps * 32 > P.key_stride) return hipErrorInvalidValue;
+  const long long tiles = (long long)batch * nsl * tps;
+  // resident workgroups: 4 per CU fill the register file (4 waves/SIMD x 120 VGPRs); 3 per CU
+  // leave 152 VGPRs per SIMD for a QP wave of another batch/sub-batch to run underneath
+  const int slots = n_cu * blocks_per_cu;
+  int blocks = (int)((tiles + DUNE_WAVES - 1) / DUNE_WAVES);
+  if (blocks > slots) blocks = slots;
+  if (blocks < 1) blocks = 1;
+  const size_t shmem = (11 * 32 + 8 * 32 + 8) * sizeof(float);
+#define LAUNCH(EE)                                                                                                  \
+  hipLaunchKernelGGL(dune_kernel<EE>, dim3(blocks), dim3(DUNE_THREADS), shmem, stream, P, wpack, n_stride, cur_s,   \
+                     points, vel, n_points, flags, gkeys, tps * 32, scene0, batch, t0)
+  switch (P.E) {
+    case 3: LAUNCH(3); break;
+    case 4: LAUNCH(4); break;
+    case 5: LAUNCH(5); break;
+    case 6: LAUNCH(6); break;
+    case 7: LAUNCH(7); break;
+    case 8: LAUNCH(8); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef LAUNCH
+  return hipGetLastError();
+}
+
+extern "C" hipError_t npa_launch_select(const DevParams& P, const float* wpack, int batch, int scene0, int t0,
+                                        int n_stride, const float* cur_s, const float* points, const float* vel,
+                                        const int* n_points, const int* flags, const unsigned* gkeys,
+                                        float* mu_sorted, float* lam_sorted, float* pts_sorted, float* dist_sorted,
+                                        int* count, hipStream_t stream) {
+  const int nsl = P.T + 1 - t0;
+  const int tps = tiles_per_slice(P, n_stride);
+  const size_t shmem = (11 * 32 + 8 * 32 + 8) * sizeof(float) + NPA_MAX_M * sizeof(int) +
+                       ((size_t)tps * 32 * sizeof(unsigned) + 15) / 16 * 16;
+#define LAUNCH(EE)                                                                                                  \
+  hipLaunchKernelGGL(select_kernel<EE>, dim3(nsl, batch), dim3(64), shmem, stream, P, wpack, n_stride, cur_s, points, \
+                     vel, n_points, flags, gkeys, tps * 32, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count,  \
+                     scene0, t0)
   switch (P.E) {
     case 3: LAUNCH(3); break;
     case 4: LAUNCH(4); break;

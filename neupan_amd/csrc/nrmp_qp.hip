@@ -563,8 +563,9 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
         const double g2 = Pi[2] * b0 + Pi[4] * b1 + Pi[5] * b2;
         const double* Ph = Phi + (size_t)i * 3 * ldp;  // Phi_i rows (zero beyond column 2i+1)
 #pragma unroll
-        for (int c = 0; c < NU; ++c)
+        for (int c = 0; c < NU; ++c) {
           arow[c] = fma(g0, Ph[c], fma(g1, Ph[ldp + c], fma(g2, Ph[2 * ldp + c], Hm[ar * ldk + c])));
+        }
       }
       PROF(3);
       // right-looking Cholesky, row i in lane i: after step k, arow[k] = L[i][k] (entries above the

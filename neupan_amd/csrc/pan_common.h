@@ -6,10 +6,12 @@
 #define NPA_MAX_T 21
 #define NPA_MAX_M 32
 #define NPA_MAX_E 8
+#define NPA_MAX_POINTS 32768       // points per scene after decimation (select_kernel keeps a slice's keys in LDS)
 
 // Kernel-argument copy of npa_config (include/neupan_amd.h), passed by value.
 struct DevParams {
   int T, M, E, kin, K, dune_max_num;
+  int key_stride;             // per-slice stride of the distance-key buffer: min(dune_max_num, NPA_MAX_POINTS) up to 32
   float iter_threshold;
   float dt32;                 // (float)dt, the value fp32 tensor*python-float products see
   double dt, L;
@@ -47,13 +49,14 @@ __host__ __device__ inline size_t npa_state_floats(int T, int M, int E) {
 // cur_s [B][3][T+1]  cur_u [B][2][T]  cur_d [B][T]  mu [B][T+1][M][E]  lam [B][T+1][M][2]
 // pts [B][T+1][M][2]  dist [B][T+1][M]  count [B][T+1] (int)
 // flags [B][4] (int: done, iters, warm-start valid)  warm [B][nwarm] (double: x, multipliers)
+// keys [B][T+1][key_stride] (uint: order-preserving distance key of every point of every slice)
 struct ScratchLayout {
-  size_t cur_s, cur_u, cur_d, mu, lam, pts, dist, count, flags, warm, qp_info, total;
+  size_t cur_s, cur_u, cur_d, mu, lam, pts, dist, count, flags, warm, qp_info, keys, total;
 };
 __host__ __device__ inline size_t npa_warm_doubles(int T, int M) {   // per scene
   return (size_t)2 * T + T + (size_t)T * M + (8 * T - 4) + 2 * T;
 }
-__host__ __device__ inline ScratchLayout npa_scratch_layout(int B, int T, int M, int E) {
+__host__ __device__ inline ScratchLayout npa_scratch_layout(int B, int T, int M, int E, int key_stride) {
   ScratchLayout L;
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o += (n + 3) & ~(size_t)3; return r; };
@@ -69,6 +72,7 @@ __host__ __device__ inline ScratchLayout npa_scratch_layout(int B, int T, int M,
   o = (o + 3) & ~(size_t)3;                       // 16-byte alignment for the doubles
   L.warm = take((size_t)B * npa_warm_doubles(T, M) * 2);
   L.qp_info = take((size_t)B * 16 * 2);          // per-scene solver diagnostics of the last QP (16 doubles)
+  L.keys = take((size_t)B * (T + 1) * key_stride);
   L.total = o;
   return L;
 }
