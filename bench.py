@@ -46,17 +46,20 @@ def cpu_baseline(cfg, n_scenes, u_gpu):
     except Exception:  # pragma: no cover
         limiter = None
     torch.set_num_threads(1)
-    errs = []
+    errs, moving = [], []
     t0 = time.perf_counter()
     for b in range(n_scenes):
         sc = make_scene(cfg, b)
         orc = make_oracle(cfg)
         s, u, d = orc.forward(sc["nom_s"], sc["nom_u"], sc["ref_s"], sc["ref_us"], sc["points"], sc["velocities"])
         errs.append(float(np.linalg.norm(u_gpu[b].astype(np.float64) - u)))
+        # does the oracle's own PAN iteration still move at the last step?  (a non-contracting
+        # fixed-point iteration amplifies 1e-7 differences by a constant factor per iteration)
+        moving.append(float(np.linalg.norm(orc.trace[-1][1] - orc.trace[-2][1])) if len(orc.trace) > 1 else 0.0)
     dt = time.perf_counter() - t0
     if limiter is not None:
         limiter.restore_original_limits() if hasattr(limiter, "restore_original_limits") else None
-    return n_scenes / dt, errs
+    return n_scenes / dt, errs, moving
 
 
 def main():
@@ -155,6 +158,18 @@ def main():
     dune_s = prof["dune_ms"] * 1e-3
     achieved = flops_per_launch / dune_s / 1e12 if dune_s > 0 else 0.0
 
+    # HBM bytes per dune_kernel launch from the PMC passes of tools/hbm_traffic.py (separate rocprofv3
+    # runs: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), committed under profiles/
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            per_launch_256 = tj["dune_kernel<4>"]["hbm_bytes_per_launch"]     # measured at 256 scenes / launch
+            traffic = int(per_launch_256 * (args.steps * K * BATCH / max(prof["launches"], 1)) / BATCH)
+        except Exception:
+            traffic = None
+
     line = {
         "metric": "MPC plans/sec (node), diff robot, 1k pts, T=10, K=10; ctrl L2 vs ref",
         "value": round(value, 1), "unit": "plans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -167,19 +182,22 @@ def main():
                    "parallelism": f"scene-shard x{world}, RCCL all-gather of controls"},
         "roofline": {"bound": "mfma", "kernel": "dune_kernel<4>", "achieved": round(achieved, 3),
                      "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                     "traffic": None, "flops_per_launch": int(flops_per_launch),
+                     "traffic": traffic, "flops_per_launch": int(flops_per_launch),
                      "launch_ms": round(prof["dune_ms"], 4), "launches_timed": prof["launches"],
                      "nrmp_qp_launch_ms": round(prof["nrmp_ms"], 4)},
     }
     if rank == 0 and world == 1 and not args.no_cpu:
         u_gpu = out["opt_u"].cpu().numpy()
-        cpu_rate, errs = cpu_baseline(cfg, args.cpu_scenes, u_gpu)
-        errs = np.array(errs)
+        cpu_rate, errs, moving = cpu_baseline(cfg, args.cpu_scenes, u_gpu)
+        errs, moving = np.array(errs), np.array(moving)
+        conv = moving <= 1.0
         line["cpu_baseline"] = {"value": round(cpu_rate, 3), "unit": "plans/s", "cores": 1, "kind": "port",
                                 "sample": f"first {args.cpu_scenes} scenes of the same workload, K=10 each, "
                                           "oracle/pan_oracle.py (numpy fp32 + fp64 IPM), 1 thread"}
         line["parity"] = {"ctrl_l2_vs_oracle_median": float(np.median(errs)), "max": float(errs.max()),
                           "frac_le_1e-4": float((errs <= 1e-4).mean()), "scenes": int(len(errs)),
+                          "scenes_with_contracting_pan_iteration": int(conv.sum()),
+                          "max_over_contracting": float(errs[conv].max()) if conv.any() else None,
                           "note": "oracle = reference code restated + substituted fp64 QP solver (ECOS unavailable)"}
     if rank == 0:
         print(json.dumps(line), flush=True)

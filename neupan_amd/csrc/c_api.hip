@@ -49,9 +49,12 @@ struct npa_handle {
   // sub-batch pipelining: DUNE launches stay in order on the caller's stream, each
   // sub-batch's QP chain runs on its own helper stream so it overlaps the other
   // sub-batches' DUNE launches (the QP is latency bound and occupies one wave per scene)
-  int n_sub = 2;
+  int n_sub = 1;              // sub-batches of one forward (NPA_PIPELINE); >1 rarely pays, see DESIGN.md
   int enc_blocks_shared = 4;  // encode workgroups per CU while QP kernels run underneath
-  bool warm_start = true;     // IPM warm start across the PAN iterations of one forward call
+  // IPM warm start across the PAN iterations of one forward call (NPA_QP_WARM=1): fewer iterations
+  // on average (12.6 -> 8.5) but a longer tail, and the iterates land at slightly different points of
+  // the QP's flat directions (control L2 vs oracle up to 1e-3 on some scenes) -> off by default
+  bool warm_start = false;
   hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> sync_ev;
   // profiling (bench.py): HIP events on the launch stream around every stage launch
