@@ -63,6 +63,7 @@ def cpu_baseline(cfg, n_scenes, u_gpu):
 
 
 def main():
+    global BATCH
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -70,6 +71,9 @@ def main():
     ap.add_argument("--cpu-scenes", type=int, default=24, help="scenes timed through the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--inflight", type=int, default=3, help="independent batches (steps) kept in flight")
+    ap.add_argument("--workload", default=WORKLOAD, choices=sorted(k for k in __import__("neupan_amd.scenes", fromlist=["CONFIGS"]).CONFIGS),
+                    help="scene configuration (default: the one BASELINE.json's metric is quoted on)")
+    ap.add_argument("--batch", type=int, default=BATCH, help="scenes per step and GPU")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -92,7 +96,8 @@ def main():
     from neupan_amd.pan import forward_interleaved
     from neupan_amd.scenes import make_batch
 
-    cfg = CONFIGS[WORKLOAD]
+    cfg = CONFIGS[args.workload]
+    BATCH = args.batch
     T, K, N, E = cfg.T, cfg.iter_num, cfg.n_points, 4
     nfl = max(1, args.inflight)
     pans = [make_gpu_pan(cfg, device=dev) for _ in range(nfl)]
@@ -112,7 +117,7 @@ def main():
                 p.reset_stop_state()
             outs = forward_interleaved(pans[:g], args_dev[:g])
             for o in outs:
-                gathered = gather_controls(o["opt_u"], dist, world)     # RCCL all-gather when world > 1
+                gathered = gather_controls(o["opt_u"], dist, world, equal_shards=True)   # RCCL all-gather when world > 1
             out0 = outs[0]
             done += g
         return out0, gathered
@@ -171,12 +176,15 @@ def main():
             traffic = None
 
     line = {
-        "metric": "MPC plans/sec (node), diff robot, 1k pts, T=10, K=10; ctrl L2 vs ref",
+        "metric": "MPC plans/sec (node), diff robot, 1k pts, T=10, K=10; ctrl L2 vs ref" if args.workload == WORKLOAD
+                  else f"MPC plans/sec (node), workload {args.workload}; ctrl L2 vs ref",
         "value": round(value, 1), "unit": "plans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE.json configs[1]: batch=256 synthetic scenes/GPU, diff robot, 1000 pts, "
-                               "T=10, K=10 (iter_threshold=0), M=10, fp32 DUNE (MFMA) + fp64 QP",
+        "config": {"workload": ("BASELINE.json configs[1]: batch=256 synthetic scenes/GPU, diff robot, 1000 pts, "
+                                "T=10, K=10 (iter_threshold=0), M=10, fp32 DUNE (MFMA) + fp64 QP") if args.workload == WORKLOAD
+                               else f"{args.workload}: batch={BATCH} synthetic scenes/GPU, {cfg.kinematics} robot, {N} pts, "
+                                    f"T={T}, K={K} (iter_threshold=0), M={cfg.nrmp_max_num}, fp32 DUNE (MFMA) + fp64 QP",
                    "scenes_per_gpu": BATCH, "points": N, "T": T, "K": K, "M": cfg.nrmp_max_num,
                    "batches_in_flight": nfl,
                    "parallelism": f"scene-shard x{world}, RCCL all-gather of controls"},

@@ -21,12 +21,18 @@ def shard_range(total: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_controls(opt_u: torch.Tensor, dist=None, world: int = 1):
+def gather_controls(opt_u: torch.Tensor, dist=None, world: int = 1, equal_shards: bool = False):
     """All-gather per-scene controls (B_local, 2, T) -> (sum B_local, 2, T) in rank order.
-    Equal shard sizes use one all_gather_into_tensor; ragged shards are padded to the
-    largest shard and trimmed."""
+    Equal shard sizes use one all_gather_into_tensor (pass equal_shards=True when the caller knows
+    that every rank holds the same number of scenes: it saves the size exchange); ragged shards
+    are padded to the largest shard and trimmed."""
     if dist is None or world == 1:
         return opt_u
+    if equal_shards and dist.get_backend() != "gloo":
+        send = opt_u.contiguous()
+        out = torch.empty((world * send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        dist.all_gather_into_tensor(out, send)
+        return out
     b_local = torch.tensor([opt_u.shape[0]], device=opt_u.device, dtype=torch.int64)
     sizes = [torch.zeros_like(b_local) for _ in range(world)]
     dist.all_gather(sizes, b_local)

@@ -63,7 +63,9 @@ CONFIGS = {
         robot=dict(kinematics="acker", length=4.6, width=1.6, wheelbase=3, max_speed=[8, 1],
                    max_acce=[8, 0.5]),
         adjust=dict(q_s=1.0, p_u=1.0, eta=15.0, d_max=1.0, d_min=0.1, bk=0.1, ro_obs=400),
-        x_range=(-6.0, 20.0), obs_x=(6.0, 17.0), obs_gap=(1.1, 2.4),
+        # a 4.6 m car with a 3 m wheelbase needs a wider lane than the 1.6 m diff robot
+        x_range=(-6.0, 24.0), wall_half_width=(4.5, 6.0), obs_x=(7.0, 20.0), obs_gap=(1.4, 2.8),
+        obs_count=(2, 5),
     ),
     # configs[3]: moving points (dyna_non_obs), 4000 pts/scene
     "dyna_4k_T10_K10": SceneConfig(

@@ -7,18 +7,24 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from gpu_helpers import make_gpu_pan
 from helpers import CONFIGS, make_oracle
 from neupan_amd.scenes import make_batch
-cfg = CONFIGS["diff_1k_T10_K10"]; B = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+cfg = CONFIGS[sys.argv[2] if len(sys.argv) > 2 else "diff_1k_T10_K10"]; B = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+if len(sys.argv) > 3:
+    import dataclasses
+    cfg = dataclasses.replace(cfg, n_points=int(sys.argv[3]))
 batch = make_batch(cfg, 0, B)
 args = [batch[k] for k in ("nom_s", "nom_u", "ref_s", "ref_us", "points")]
 orc_u = []
 for b in range(B):
     o = make_oracle(cfg)
-    o.forward(*[a[b] for a in args])
+    o.forward(*[a[b] for a in args], None if batch['velocities'] is None else batch['velocities'][b])
     orc_u.append([t[1] for t in o.trace])
 errs = np.zeros((B, cfg.iter_num))
 for K in range(1, cfg.iter_num + 1):
     pan = make_gpu_pan(cfg, iter_num=K)
-    u = pan.forward_batch(*args)["opt_u"].cpu().numpy()
+    u = pan.forward_batch(*args, batch["velocities"])["opt_u"].cpu().numpy()
+    info = pan.last_qp_info()
+    if (info[:, 3] != 0).any() or info[:, 1].max() > 1e-8:
+        print("K", K, "QP status", info[:, 3], "merit", info[:, 1])
     for b in range(B):
         errs[b, K - 1] = np.linalg.norm(u[b].astype(np.float64) - orc_u[b][K - 1])
 np.set_printoptions(linewidth=200, formatter={"float": lambda v: "%.1e" % v})
