@@ -224,7 +224,7 @@ def test_interleaved_batches_equal_sequential():
 def test_other_baseline_configs_full_size(cfgname, scenes):
     """BASELINE.json configs[2] (acker, 2000 pts, T=20, K=15) and configs[3] (moving points,
     4000 pts/scene) at full size on a few scenes: wherever the oracle's own PAN iteration has
-    settled (last step |du| < 1e-3) the HIP path must agree to control L2 <= 1e-4."""
+    nearly settled (last step |du| < 0.1) the HIP path must agree to control L2 <= 1e-4."""
     from gpu_helpers import l2, make_gpu_pan
     cfg = CONFIGS[cfgname]
     pan = make_gpu_pan(cfg)
@@ -233,7 +233,7 @@ def test_other_baseline_configs_full_size(cfgname, scenes):
         sc = make_scene(cfg, b)
         orc = make_oracle(cfg)
         s, u, d = orc.forward(sc["nom_s"], sc["nom_u"], sc["ref_s"], sc["ref_us"], sc["points"], sc["velocities"])
-        settled = np.linalg.norm(orc.trace[-1][1] - orc.trace[-2][1]) < 1e-3
+        settled = np.linalg.norm(orc.trace[-1][1] - orc.trace[-2][1]) < 0.1
         pan.reset_stop_state()
         sg, ug, dg = pan(sc["nom_s"], sc["nom_u"], sc["ref_s"], sc["ref_us"], sc["points"], sc["velocities"])
         if settled:
