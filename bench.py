@@ -170,7 +170,8 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            per_launch_256 = tj["dune_kernel<4>"]["hbm_bytes_per_launch"]     # measured at 256 scenes / launch
+            key = [k for k in tj if k.startswith("dune_kernel")][0]
+            per_launch_256 = tj[key]["hbm_bytes_per_launch"]                 # measured at 256 scenes / launch
             traffic = int(per_launch_256 * (args.steps * K * BATCH / max(prof["launches"], 1)) / BATCH)
         except Exception:
             traffic = None
@@ -188,7 +189,12 @@ def main():
                    "scenes_per_gpu": BATCH, "points": N, "T": T, "K": K, "M": cfg.nrmp_max_num,
                    "batches_in_flight": nfl,
                    "parallelism": f"scene-shard x{world}, RCCL all-gather of controls"},
-        "roofline": {"bound": "mfma", "kernel": "dune_kernel<4>", "achieved": round(achieved, 3),
+        "roofline": {"bound": "mfma", "kernel": "dune_kernel<4,true>" if os.environ.get("NPA_DUNE_FP32KEYS") is None else "dune_kernel<4,false>",
+                     "note": ("algorithmic fp32 flops / launch time against the fp32-input MFMA peak; the kernel evaluates "
+                              "the four 32x32 layers as bf16x3 split products (6 bf16 MFMAs per fp32 one, fp32-accurate) "
+                              "on v_mfma_f32_32x32x16_bf16, the emitted rows are re-encoded with the exact fp32 MFMA")
+                             if os.environ.get("NPA_DUNE_FP32KEYS") is None else "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+                     "achieved": round(achieved, 3),
                      "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                      "traffic": traffic, "flops_per_launch": int(flops_per_launch),
                      "launch_ms": round(prof["dune_ms"], 4), "launches_timed": prof["launches"],

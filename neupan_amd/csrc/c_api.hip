@@ -50,7 +50,8 @@ struct npa_handle {
   // sub-batch's QP chain runs on its own helper stream so it overlaps the other
   // sub-batches' DUNE launches (the QP is latency bound and occupies one wave per scene)
   int n_sub = 1;              // sub-batches of one forward (NPA_PIPELINE); >1 rarely pays, see DESIGN.md
-  int enc_blocks_shared = 4;  // encode workgroups per CU while QP kernels run underneath
+  int enc_blocks = 5;         // encode workgroups per CU (persistent grid = n_cu * enc_blocks; the
+                              // launcher caps it at 4 for the fp32-key variant, 115 VGPRs)
   // IPM warm start across the PAN iterations of one forward call (NPA_QP_WARM=1): fewer iterations
   // on average (12.6 -> 8.5) but a longer tail, and the iterates land at slightly different points of
   // the QP's flat directions (control L2 vs oracle up to 1e-3 on some scenes) -> off by default
@@ -120,13 +121,34 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
       memcpy(&pack[WP_W6 + e * 32], w->lin_w[5] + e * 32, 32 * sizeof(float));
       pack[WP_B6 + e] = w->lin_b[5][e];
     }
+    // bf16x3 split fragments (see pan_common.h)
+    auto bf16_rne = [](float x) -> uint16_t {
+      uint32_t u; memcpy(&u, &x, 4);
+      if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
+      u += 0x7fffu + ((u >> 16) & 1u);
+      return (uint16_t)(u >> 16);
+    };
+    auto bf16_to_f = [](uint16_t b) -> float { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
+    uint16_t* bf = reinterpret_cast<uint16_t*>(&pack[WP_BF]);
+    for (int L = 0; L < 4; ++L)
+      for (int s2 = 0; s2 < 2; ++s2)
+        for (int l = 0; l < 64; ++l)
+          for (int q = 0; q < 8; ++q) {
+            float wv = w->lin_w[1 + L][(l & 31) * 32 + npa_feat(8 * s2 + q, l >> 5)];
+            float r = wv;
+            for (int t = 0; t < 3; ++t) {
+              uint16_t b = bf16_rne(r);
+              bf[((((size_t)L * 3 + t) * 2 + s2) * 64 + l) * 8 + q] = b;
+              r -= bf16_to_f(b);
+            }
+          }
   }
   if (const char* env = getenv("NPA_PIPELINE")) {
     int v = atoi(env);
     if (v >= 1 && v <= 4) h->n_sub = v;
   }
   if (const char* env = getenv("NPA_QP_WARM")) h->warm_start = atoi(env) != 0;
-  if (const char* env = getenv("NPA_ENC_BLOCKS")) { int v = atoi(env); if (v >= 1 && v <= 4) h->enc_blocks_shared = v; }
+  if (const char* env = getenv("NPA_ENC_BLOCKS")) { int v = atoi(env); if (v >= 1 && v <= 8) h->enc_blocks = v; }
   hipError_t e = hipGetDevice(&h->device);
   if (e == hipSuccess) {
     hipDeviceProp_t prop;
@@ -242,7 +264,7 @@ extern "C" int npa_dune_stage(npa_handle* h, int batch, int n_stride, const floa
     h->stage_cand_bytes = need;
   }
   HIP_TRY(npa_launch_encode(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr,
-                            (unsigned*)h->stage_cand, h->n_cu, 4, (hipStream_t)stream));
+                            (unsigned*)h->stage_cand, h->n_cu, h->enc_blocks, (hipStream_t)stream));
   HIP_TRY(npa_launch_select(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr,
                             (const unsigned*)h->stage_cand, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count,
                             (hipStream_t)stream));
@@ -368,7 +390,7 @@ extern "C" int npa_forward_iter(npa_handle* h, int k) {
       if (ev) HIP_TRY(hipEventRecord(ev->a, stream));
       const int t0 = k == 0 ? 0 : 1;
       HIP_TRY(npa_launch_encode(P, h->wpack, nb, s0, t0, pc->n_stride, cur_s, pc->points, pc->velocities,
-                                pc->n_points, flags, gkeys, h->n_cu, pc->qp_aux ? h->enc_blocks_shared : 4, stream));
+                                pc->n_points, flags, gkeys, h->n_cu, h->enc_blocks, stream));
       if (ev) HIP_TRY(hipEventRecord(ev->b, stream));
       if (pc->qp_aux) {
         HIP_TRY(hipEventRecord(ev_d(i, k), stream));

@@ -32,6 +32,7 @@
 //     SQ_VALU_MFMA_COEXEC_CYCLES = 0), so the VALU instruction count per tile matters as much as
 //     the 65 MFMAs.
 #include "pan_common.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -105,6 +106,43 @@ __device__ __forceinline__ f32x16 layer32(const float (&w)[16], const float (&a)
   return acc;
 }
 
+// ---- bf16x3 split-precision layer (dune_kernel only: distance keys) ------------------------------
+// x = x1 + x2 + x3 with bf16 terms (RNE of the running residual: |x - x1 - x2 - x3| <= 2^-24 |x|),
+// product terms (1,1) (1,2) (2,1) (1,3) (3,1) (2,2) kept: the dropped ones are <= 2^-25 relative,
+// below fp32 rounding.  Each bf16 x bf16 product is exact in the fp32 accumulator, so the layer is
+// fp32-accurate (not bit-identical to the fmaf chain of the fp32 MFMA) at 12 x 32-cycle MFMAs
+// instead of 16 x 64-cycle ones -- and, unlike the fp32-input MFMA, the bf16 MFMA runs on the
+// matrix pipe concurrently with the VALU work of the other waves of the SIMD.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3(const float (&a)[16], bf16x8 (&x1)[2], bf16x8 (&x2)[2], bf16x8 (&x3)[2]) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const __bf16 b1 = (__bf16)a[r];
+    const float r1 = a[r] - (float)b1;
+    const __bf16 b2 = (__bf16)r1;
+    const __bf16 b3 = (__bf16)(r1 - (float)b2);
+    x1[r >> 3][r & 7] = b1; x2[r >> 3][r & 7] = b2; x3[r >> 3][r & 7] = b3;
+  }
+}
+
+// wl: LDS image of one layer's split A-fragments [term 3][step 2][lane 64] x 16 B
+__device__ __forceinline__ f32x16 layer32_bf16x3(const bf16x8* wl, int lane, const float (&a)[16], f32x16 acc) {
+  bf16x8 x1[2], x2[2], x3[2];
+  split3(a, x1, x2, x3);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const bf16x8 w1 = wl[(0 * 2 + s) * 64 + lane], w2 = wl[(1 * 2 + s) * 64 + lane], w3 = wl[(2 * 2 + s) * 64 + lane];
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, x1[s], acc, 0, 0, 0);     // small terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x3[s], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x2[s], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x1[s], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x2[s], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x1[s], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
 struct WaveWeights {
   float w1;
   float wl[4][16];
@@ -112,9 +150,16 @@ struct WaveWeights {
 
 // Encoder for the 32 points of a tile.  p0x/p0y: the point in the robot frame (both lanes of
 // a pair hold both).  Returns mu[e] (e<E) in BOTH lanes of the pair.
-template <int E>
-__device__ __forceinline__ void encode_tile(const WaveWeights& W, const float* vec, const float* w6,
-                                            const float* b6, float p0x, float p0y, int hf, float mu[E]) {
+// SPLIT = false: exact fp32 MFMA (v_mfma_f32_32x32x2_f32), weights in W.wl.
+// SPLIT = true : bf16x3 split MFMA, split weight fragments in LDS (wbf), W.wl unused.
+template <int E, bool SPLIT>
+__device__ __forceinline__ void encode_tile(const WaveWeights& W, const bf16x8* wbf, const float* vec, const float* w6,
+                                            const float* b6, float p0x, float p0y, int lane, float mu[E]) {
+  const int hf = lane >> 5;
+  auto layer = [&](int L, const float (&a_)[16], f32x16 acc) -> f32x16 {
+    if constexpr (SPLIT) return layer32_bf16x3(wbf + (size_t)L * 3 * 2 * 64, lane, a_, acc);
+    else return layer32(W.wl[L], a_, acc);
+  };
   float a[16];
   {
     f32x16 acc = bias_init(vec + V_B1 * 32, hf);
@@ -122,21 +167,21 @@ __device__ __forceinline__ void encode_tile(const WaveWeights& W, const float* v
     ln_tanh(acc, vec + V_G1 * 32, vec + V_BE1 * 32, hf, a);
   }
   {
-    f32x16 acc = layer32(W.wl[0], a, bias_init(vec + V_B2 * 32, hf));
+    f32x16 acc = layer(0, a, bias_init(vec + V_B2 * 32, hf));
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r], 0.f);
   }
   {
-    f32x16 acc = layer32(W.wl[1], a, bias_init(vec + V_B3 * 32, hf));
+    f32x16 acc = layer(1, a, bias_init(vec + V_B3 * 32, hf));
     ln_tanh(acc, vec + V_G2 * 32, vec + V_BE2 * 32, hf, a);
   }
   {
-    f32x16 acc = layer32(W.wl[2], a, bias_init(vec + V_B4 * 32, hf));
+    f32x16 acc = layer(2, a, bias_init(vec + V_B4 * 32, hf));
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r], 0.f);
   }
   {
-    f32x16 acc = layer32(W.wl[3], a, bias_init(vec + V_B5 * 32, hf));
+    f32x16 acc = layer(3, a, bias_init(vec + V_B5 * 32, hf));
     ln_tanh(acc, vec + V_G3 * 32, vec + V_BE3 * 32, hf, a);
   }
 #pragma unroll
@@ -216,11 +261,11 @@ __device__ __forceinline__ void load_frame(const DevParams& P, const float* __re
 }
 
 // one point (two lanes) through point flow + encoder + lam/distance
-template <int E>
+template <int E, bool SPLIT>
 __device__ __forceinline__ void point_features(const DevParams& P, const SliceFrame& F, const WaveWeights& W,
-                                               const float* vec, const float* w6, const float* b6,
+                                               const bf16x8* wbf, const float* vec, const float* w6, const float* b6,
                                                const float* px_row, const float* py_row, const float* vx_row,
-                                               const float* vy_row, int src, int hf, float mu[E], float& gx,
+                                               const float* vy_row, int src, int lane, float mu[E], float& gx,
                                                float& gy, float& lx, float& ly, float& dist) {
   // pan.py:182  receding_obs_points = obs_points + i * (point_velocities * dt)
   gx = px_row[src];
@@ -233,7 +278,7 @@ __device__ __forceinline__ void point_features(const DevParams& P, const SliceFr
   float dx = __fsub_rn(gx, F.tx), dy = __fsub_rn(gy, F.ty);
   float p0x = fmaf(F.c, dx, __fmul_rn(F.s, dy));
   float p0y = fmaf(F.c, dy, -__fmul_rn(F.s, dx));
-  encode_tile<E>(W, vec, w6, b6, p0x, p0y, hf, mu);
+  encode_tile<E, SPLIT>(W, wbf, vec, w6, b6, p0x, p0y, lane, mu);
   lx = 0.f; ly = 0.f; dist = 0.f;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
@@ -254,7 +299,7 @@ __device__ __forceinline__ void load_weights(const float* __restrict__ wpack, in
 
 // ---- launch 1: distance key of every point of every slice -----------------------------------------
 // tile id -> (scene, slice, tile in slice); tiles_per_slice = key_stride/32
-template <int E>
+template <int E, bool SPLIT>
 __global__ __launch_bounds__(DUNE_THREADS, 4) void dune_kernel(
     DevParams P, const float* __restrict__ wpack, int n_stride, const float* __restrict__ cur_s,
     const float* __restrict__ points, const float* __restrict__ vel, const int* __restrict__ n_points,
@@ -270,8 +315,16 @@ __global__ __launch_bounds__(DUNE_THREADS, 4) void dune_kernel(
 
   for (int i = tid; i < 11 * 32 + 8 * 32 + 8; i += DUNE_THREADS) smem[i] = wpack[WP_VEC + i];
   WaveWeights W;
-  load_weights(wpack, lane, W);
-  __syncthreads();                          // the only workgroup barrier: vectors staged
+  const bf16x8* wbf = nullptr;
+  if constexpr (SPLIT) {
+    float* wb = b6 + 8;                     // 16-byte aligned: (11*32 + 8*32 + 8) floats precede it
+    for (int i = tid; i < WP_BF_FLOATS; i += DUNE_THREADS) wb[i] = wpack[WP_BF + i];
+    wbf = reinterpret_cast<const bf16x8*>(wb);
+    W.w1 = wpack[WP_W1 + lane];
+  } else {
+    load_weights(wpack, lane, W);
+  }
+  __syncthreads();                          // the only workgroup barrier: vectors / fragments staged
 
   const int nsl = T + 1 - t0;
   const int tps = key_stride >> 5;                          // tiles per slice
@@ -306,8 +359,8 @@ __global__ __launch_bounds__(DUNE_THREADS, 4) void dune_kernel(
     const int n = tile * 32 + j;
     const int nc = n < n_use ? n : n_use - 1;
     float mu[E], gx, gy, lx, ly, dist;
-    point_features<E>(P, F, W, vec, w6, b6, px_row, py_row, vx_row, vy_row, src_index(nc, n_raw, n_use), hf, mu, gx,
-                      gy, lx, ly, dist);
+    point_features<E, SPLIT>(P, F, W, wbf, vec, w6, b6, px_row, py_row, vx_row, vy_row, src_index(nc, n_raw, n_use),
+                             lane, mu, gx, gy, lx, ly, dist);
     if (hf == 0 && n < n_use) gkeys[((size_t)b * (T + 1) + t) * key_stride + n] = ordered_key(dist);
   }
 }
@@ -362,8 +415,8 @@ __global__ __launch_bounds__(64, 4) void select_kernel(
   // re-encode the selected points and emit the sorted rows; rows >= msel replicate row 0
   const int m = j < msel ? j : 0;
   float mu[E], gx, gy, lx, ly, dist;
-  point_features<E>(P, F, W, vec, w6, b6, px_row, py_row, vx_row, vy_row, src_index(sel[m], n_raw, n_use), hf, mu, gx,
-                    gy, lx, ly, dist);
+  point_features<E, false>(P, F, W, nullptr, vec, w6, b6, px_row, py_row, vx_row, vy_row,
+                           src_index(sel[m], n_raw, n_use), lane, mu, gx, gy, lx, ly, dist);
   if (hf == 0 && j < M) {
     size_t o = orow * M + j;
 #pragma unroll
@@ -395,14 +448,22 @@ extern "C" hipError_t npa_launch_encode(const DevParams& P, const float* wpack, 
   const long long tiles = (long long)batch * nsl * tps;
   // resident workgroups: 4 per CU fill the register file (4 waves/SIMD x 120 VGPRs); 3 per CU
   // leave 152 VGPRs per SIMD for a QP wave of another batch/sub-batch to run underneath
+  static const bool split = getenv("NPA_DUNE_FP32KEYS") == nullptr;   // default: bf16x3 split keys
+  if (!split && blocks_per_cu > 4) blocks_per_cu = 4;
   const int slots = n_cu * blocks_per_cu;
   int blocks = (int)((tiles + DUNE_WAVES - 1) / DUNE_WAVES);
   if (blocks > slots) blocks = slots;
   if (blocks < 1) blocks = 1;
-  const size_t shmem = (11 * 32 + 8 * 32 + 8) * sizeof(float);
+  const size_t shmem = (11 * 32 + 8 * 32 + 8) * sizeof(float) + (split ? WP_BF_FLOATS * sizeof(float) : 0);
 #define LAUNCH(EE)                                                                                                  \
-  hipLaunchKernelGGL(dune_kernel<EE>, dim3(blocks), dim3(DUNE_THREADS), shmem, stream, P, wpack, n_stride, cur_s,   \
-                     points, vel, n_points, flags, gkeys, tps * 32, scene0, batch, t0)
+  do {                                                                                                              \
+    if (split)                                                                                                      \
+      hipLaunchKernelGGL((dune_kernel<EE, true>), dim3(blocks), dim3(DUNE_THREADS), shmem, stream, P, wpack, n_stride, \
+                         cur_s, points, vel, n_points, flags, gkeys, tps * 32, scene0, batch, t0);                  \
+    else                                                                                                            \
+      hipLaunchKernelGGL((dune_kernel<EE, false>), dim3(blocks), dim3(DUNE_THREADS), shmem, stream, P, wpack, n_stride, \
+                         cur_s, points, vel, n_points, flags, gkeys, tps * 32, scene0, batch, t0);                  \
+  } while (0)
   switch (P.E) {
     case 3: LAUNCH(3); break;
     case 4: LAUNCH(4); break;

@@ -33,7 +33,13 @@ struct DevParams {
 #define WP_VEC (WP_WL + 4 * 16 * 64)              // [11][32]        per-feature vectors
 #define WP_W6 (WP_VEC + 11 * 32)                  // [8][32]         Linear(32,E) rows (zero padded)
 #define WP_B6 (WP_W6 + 8 * 32)                    // [8]
-#define WP_TOTAL (WP_B6 + 8)
+// bf16x3 split of the four 32x32 layers for v_mfma_f32_32x32x16_bf16 (dune_kernel's distance
+// keys): w = w1 + w2 + w3, each term bf16 (RNE of the running residual).  A-operand layout of
+// that MFMA: lane l holds A[i = l&31][k = 8*(l>>5) + q], q = 0..7; K-step s (0,1) of a layer
+// contracts over the features feat(8s+q, hf).  [layer 4][term 3][step 2][lane 64][8 bf16]
+#define WP_BF (WP_B6 + 8)
+#define WP_BF_FLOATS (4 * 3 * 2 * 64 * 4)
+#define WP_TOTAL (WP_BF + WP_BF_FLOATS)
 // order of the per-feature vectors
 enum { V_B1 = 0, V_G1, V_BE1, V_B2, V_B3, V_G2, V_BE2, V_B4, V_B5, V_G3, V_BE3 };
 
