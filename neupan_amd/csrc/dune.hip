@@ -417,13 +417,30 @@ __global__ __launch_bounds__(64, 4) void select_kernel(
   float mu[E], gx, gy, lx, ly, dist;
   point_features<E, false>(P, F, W, nullptr, vec, w6, b6, px_row, py_row, vx_row, vy_row,
                            src_index(sel[m], n_raw, n_use), lane, mu, gx, gy, lx, ly, dist);
-  if (hf == 0 && j < M) {
-    size_t o = orow * M + j;
+  // The winners were ranked on the split-precision keys; order the (at most 32) exact rows by
+  // their exact (distance, index) key so that the emitted rows are ascending in the fp32 result.
+  const unsigned long long kx = (j < msel) ? (((unsigned long long)ordered_key(dist) << 32) | (unsigned)sel[m]) : ~0ull;
+  int rank = 0;
+  for (int i = 0; i < msel; ++i) rank += readlane_u64(kx, i) < kx ? 1 : 0;
+  if (hf == 0 && j < msel) {
+    size_t o = orow * M + rank;
 #pragma unroll
     for (int e = 0; e < E; ++e) mu_sorted[o * E + e] = mu[e];
     lam_sorted[o * 2 + 0] = lx; lam_sorted[o * 2 + 1] = ly;
     pts_sorted[o * 2 + 0] = gx; pts_sorted[o * 2 + 1] = gy;
     dist_sorted[o] = dist;
+  }
+  // rows >= msel replicate the nearest row (padding rule of nrmp.py:258-259): the lane holding it
+  // (rank 0) writes the copies
+  if (hf == 0 && j < msel && rank == 0) {
+    for (int q = msel; q < M; ++q) {
+      size_t o = orow * M + q;
+#pragma unroll
+      for (int e = 0; e < E; ++e) mu_sorted[o * E + e] = mu[e];
+      lam_sorted[o * 2 + 0] = lx; lam_sorted[o * 2 + 1] = ly;
+      pts_sorted[o * 2 + 0] = gx; pts_sorted[o * 2 + 1] = gy;
+      dist_sorted[o] = dist;
+    }
   }
   if (lane == 0) count[orow] = msel;
 }
