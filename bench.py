@@ -10,7 +10,7 @@ K = 10 PAN iterations (iter_threshold = 0 so that exactly K run), fp32 DUNE + fp
 A step = one pass of the hot path (npa_forward_batch) over one batch of 256 scenes per
 rank, inputs already resident in HBM; with N > 1 ranks every rank plans its own 256 scenes
 (weak scaling, no data-path collective) and the control outputs are all-gathered over
-RCCL inside the timed region.  Like any serving loop the bench keeps `--inflight` (default 3)
+RCCL inside the timed region.  Like any serving loop the bench keeps `--inflight` (default 4)
 independent batches in flight: consecutive steps are different batches of 256 scenes whose PAN
 iterations are interleaved on one stream (the latency-bound QP of one batch runs underneath the
 DUNE launches of the other).  Every step still executes its full K iterations inside the timed
@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-scenes", type=int, default=24, help="scenes timed through the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--inflight", type=int, default=3, help="independent batches (steps) kept in flight")
+    ap.add_argument("--inflight", type=int, default=4, help="independent batches (steps) kept in flight")
     ap.add_argument("--workload", default=WORKLOAD, choices=sorted(k for k in __import__("neupan_amd.scenes", fromlist=["CONFIGS"]).CONFIGS),
                     help="scene configuration (default: the one BASELINE.json's metric is quoted on)")
     ap.add_argument("--batch", type=int, default=BATCH, help="scenes per step and GPU")
@@ -167,7 +167,7 @@ def main():
     # runs: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), committed under profiles/
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and args.workload == WORKLOAD:      # measured for this workload only
         try:
             tj = json.load(open(tpath))
             key = [k for k in tj if k.startswith("dune_kernel")][0]

@@ -299,12 +299,20 @@ __device__ __forceinline__ void load_weights(const float* __restrict__ wpack, in
 
 // ---- launch 1: distance key of every point of every slice -----------------------------------------
 // tile id -> (scene, slice, tile in slice); tiles_per_slice = key_stride/32
-template <int E, bool SPLIT>
-__global__ __launch_bounds__(DUNE_THREADS, 4) void dune_kernel(
+// WAVES = waves per workgroup.  4: five workgroups per CU (<= 96 VGPRs).  16: ONE workgroup per CU,
+// 4 waves per SIMD at <= 72 VGPRs and a single LDS copy of the weight fragments, which leaves room
+// (216 VGPRs per SIMD, 130 KB LDS) for a QP workgroup of another batch to be co-resident.
+template <int E, bool SPLIT, int WAVES>
+__global__ __attribute__((amdgpu_flat_work_group_size(64 * WAVES, 64 * WAVES), amdgpu_waves_per_eu(WAVES == 16 ? 7 : 4)))
+void dune_kernel(
     DevParams P, const float* __restrict__ wpack, int n_stride, const float* __restrict__ cur_s,
     const float* __restrict__ points, const float* __restrict__ vel, const int* __restrict__ n_points,
-    const int* __restrict__ flags, unsigned* __restrict__ gkeys, int key_stride, int scene0, int nscene, int t0) {
+    const int* __restrict__ flags, unsigned* __restrict__ gkeys, int key_stride, int scene0, int nscene, int t0,
+    int chunk) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ int wg_ticket_s;
+  int* wg_ticket = &wg_ticket_s;
+  if (threadIdx.x == 0) wg_ticket_s = 0;
   float* vec = smem;                       // [11][32]
   float* w6 = vec + 11 * 32;               // [8][32]
   float* b6 = w6 + 8 * 32;                 // [8]
@@ -313,12 +321,12 @@ __global__ __launch_bounds__(DUNE_THREADS, 4) void dune_kernel(
   const int j = lane & 31, hf = lane >> 5;
   const int T = P.T;
 
-  for (int i = tid; i < 11 * 32 + 8 * 32 + 8; i += DUNE_THREADS) smem[i] = wpack[WP_VEC + i];
+  for (int i = tid; i < 11 * 32 + 8 * 32 + 8; i += 64 * WAVES) smem[i] = wpack[WP_VEC + i];
   WaveWeights W;
   const bf16x8* wbf = nullptr;
   if constexpr (SPLIT) {
     float* wb = b6 + 8;                     // 16-byte aligned: (11*32 + 8*32 + 8) floats precede it
-    for (int i = tid; i < WP_BF_FLOATS; i += DUNE_THREADS) wb[i] = wpack[WP_BF + i];
+    for (int i = tid; i < WP_BF_FLOATS; i += 64 * WAVES) wb[i] = wpack[WP_BF + i];
     wbf = reinterpret_cast<const bf16x8*>(wb);
     W.w1 = wpack[WP_W1 + lane];
   } else {
@@ -329,17 +337,27 @@ __global__ __launch_bounds__(DUNE_THREADS, 4) void dune_kernel(
   const int nsl = T + 1 - t0;
   const int tps = key_stride >> 5;                          // tiles per slice
   const long long total = (long long)nscene * nsl * tps;
-  // Work distribution: the tile stream is cut into equal contiguous chunks, one per resident wave
-  // (a dynamic hand-out through atomic tickets was measured slower: per-chunk frame set-up and the
-  // ticket round trip cost more than the imbalance they remove).
-  const long long nwaves = (long long)gridDim.x * DUNE_WAVES, wid = (long long)blockIdx.x * DUNE_WAVES + wave;
-  const long long lo = total * wid / nwaves, hi = total * (wid + 1) / nwaves;
+  // Work distribution: the tile stream is cut into equal contiguous ranges, one per workgroup; inside
+  // a workgroup the waves (one per SIMD) draw `chunk`-tile tickets from an LDS counter.  A purely
+  // static split per wave is balanced only while the kernel has the chip to itself: a QP wave of
+  // another batch in flight slows the DUNE waves on its SIMD by ~1.3x, and every launch would wait
+  // for those.  (Tickets from a global counter were measured: same-address device-scope atomics
+  // serialise at ~20 ns each, far too slow for 10^4 tickets per launch.)
+  const long long wg_lo = total * blockIdx.x / gridDim.x, wg_hi = total * (blockIdx.x + 1) / gridDim.x;
+  long long g = 0, hi = 0;
   int cur_b = -1, cur_t = -1, n_raw = 0, n_use = 0;
   bool skip = false;
   SliceFrame F;
   const float *px_row = nullptr, *py_row = nullptr, *vx_row = nullptr, *vy_row = nullptr;
 #pragma unroll 1
-  for (long long g = lo; g < hi; ++g) {
+  for (;; ++g) {
+    if (g >= hi) {
+      int c = 0;
+      if (lane == 0) c = atomicAdd(wg_ticket, chunk);
+      g = wg_lo + __builtin_amdgcn_readfirstlane(c);
+      if (g >= wg_hi) break;
+      hi = g + chunk < wg_hi ? g + chunk : wg_hi;
+    }
     const int sl = (int)(g / tps), tile = (int)(g - (long long)sl * tps);
     const int bl = sl / nsl, t = sl - bl * nsl + t0, b = bl + scene0;
     if (b != cur_b || t != cur_t) {                          // wave-uniform: at most a few times per chunk
@@ -463,23 +481,28 @@ extern "C" hipError_t npa_launch_encode(const DevParams& P, const float* wpack, 
   const int tps = tiles_per_slice(P, n_stride);
   if (tps * 32 > P.key_stride) return hipErrorInvalidValue;
   const long long tiles = (long long)batch * nsl * tps;
-  // resident workgroups: 4 per CU fill the register file (4 waves/SIMD x 120 VGPRs); 3 per CU
-  // leave 152 VGPRs per SIMD for a QP wave of another batch/sub-batch to run underneath
+  // resident workgroups (4-wave form): blocks_per_cu per CU; the exact-fp32 variant needs 117 VGPRs
   static const bool split = getenv("NPA_DUNE_FP32KEYS") == nullptr;   // default: bf16x3 split keys
   if (!split && blocks_per_cu > 4) blocks_per_cu = 4;
-  const int slots = n_cu * blocks_per_cu;
-  int blocks = (int)((tiles + DUNE_WAVES - 1) / DUNE_WAVES);
+  // one 16-wave workgroup per CU once every wave has a few tiles to stream; small launches keep
+  // 4-wave workgroups (more CUs busy).  NPA_ENC_WAVES=4 forces the small form.
+  static const bool small_only = getenv("NPA_ENC_WAVES") && atoi(getenv("NPA_ENC_WAVES")) == 4;
+  const int waves = (split && !small_only && tiles >= (long long)n_cu * 16 * 4) ? 16 : DUNE_WAVES;
+  const int slots = waves == 16 ? n_cu : n_cu * blocks_per_cu;
+  int blocks = (int)((tiles + waves - 1) / waves);
   if (blocks > slots) blocks = slots;
   if (blocks < 1) blocks = 1;
   const size_t shmem = (11 * 32 + 8 * 32 + 8) * sizeof(float) + (split ? WP_BF_FLOATS * sizeof(float) : 0);
+  static const int chunk_env = getenv("NPA_ENC_CHUNK") ? atoi(getenv("NPA_ENC_CHUNK")) : 2;
+  const int chunk = chunk_env < 1 ? 1 : chunk_env;
+#define LAUNCH1(EE, SP, WV)                                                                                         \
+  hipLaunchKernelGGL((dune_kernel<EE, SP, WV>), dim3(blocks), dim3(64 * WV), shmem, stream, P, wpack, n_stride,     \
+                     cur_s, points, vel, n_points, flags, gkeys, tps * 32, scene0, batch, t0, chunk)
 #define LAUNCH(EE)                                                                                                  \
   do {                                                                                                              \
-    if (split)                                                                                                      \
-      hipLaunchKernelGGL((dune_kernel<EE, true>), dim3(blocks), dim3(DUNE_THREADS), shmem, stream, P, wpack, n_stride, \
-                         cur_s, points, vel, n_points, flags, gkeys, tps * 32, scene0, batch, t0);                  \
-    else                                                                                                            \
-      hipLaunchKernelGGL((dune_kernel<EE, false>), dim3(blocks), dim3(DUNE_THREADS), shmem, stream, P, wpack, n_stride, \
-                         cur_s, points, vel, n_points, flags, gkeys, tps * 32, scene0, batch, t0);                  \
+    if (split && waves == 16) LAUNCH1(EE, true, 16);                                                                \
+    else if (split) LAUNCH1(EE, true, DUNE_WAVES);                                                                  \
+    else LAUNCH1(EE, false, DUNE_WAVES);                                                                            \
   } while (0)
   switch (P.E) {
     case 3: LAUNCH(3); break;
@@ -491,6 +514,7 @@ extern "C" hipError_t npa_launch_encode(const DevParams& P, const float* wpack, 
     default: return hipErrorInvalidValue;
   }
 #undef LAUNCH
+#undef LAUNCH1
   return hipGetLastError();
 }
 

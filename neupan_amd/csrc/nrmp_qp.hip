@@ -907,9 +907,14 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
                                     float* out_min_distance, int* out_iters, float* out_nrmp_points, int* flags,
                                     float* state, double* qp_info, double* warm, hipStream_t stream) {
   const size_t wave_bytes = npa_qp_shmem_bytes(P.T, P.M);
-  // as many scenes per workgroup as LDS allows (<= QP_WAVES)
+  // One scene (wave) per workgroup by default: the dispatcher then spreads the QP waves of a launch
+  // evenly over the CUs, so that DUNE workgroups of other batches in flight are slowed uniformly
+  // (they balance inside a CU through their LDS ticket, not across CUs).  NPA_QP_WPG=2..4 packs
+  // scenes per workgroup (as many as LDS allows).
+  static const int wpg_env = getenv("NPA_QP_WPG") ? atoi(getenv("NPA_QP_WPG")) : 1;
   int wpg = (int)((160 * 1024) / wave_bytes);
   wpg = wpg < 1 ? 1 : (wpg > QP_WAVES ? QP_WAVES : wpg);
+  if (wpg_env >= 1 && wpg_env < wpg) wpg = wpg_env;
   const size_t shmem = wave_bytes * wpg;
   const int wave_doubles = (int)(wave_bytes / sizeof(double));
   const int nblocks = (batch + wpg - 1) / wpg;
