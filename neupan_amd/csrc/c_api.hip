@@ -129,12 +129,32 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
       return (uint16_t)(u >> 16);
     };
     auto bf16_to_f = [](uint16_t b) -> float { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
+    // key path (dune_kernel): LayerNorm centring folded into Linear 1, 3, 5 (fp64, rounded once)
+    std::vector<float> wkey[4];                       // the four 32x32 layers as the key path sees them
+    for (int L = 0; L < 4; ++L) wkey[L].assign(w->lin_w[1 + L], w->lin_w[1 + L] + 32 * 32);
+    auto centre_cols = [](const float* W, int ncol, float* out) {   // out = (I - 11'/32) W, W is [32][ncol]
+      for (int c = 0; c < ncol; ++c) {
+        double m = 0;
+        for (int i = 0; i < 32; ++i) m += (double)W[i * ncol + c];
+        m /= 32.0;
+        for (int i = 0; i < 32; ++i) out[i * ncol + c] = (float)((double)W[i * ncol + c] - m);
+      }
+    };
+    centre_cols(w->lin_w[2], 32, wkey[1].data());     // Linear 3
+    centre_cols(w->lin_w[4], 32, wkey[3].data());     // Linear 5
+    {
+      float w1c[32 * 2];
+      centre_cols(w->lin_w[0], 2, w1c);
+      for (int l = 0; l < 64; ++l) pack[WP_KW1 + l] = w1c[(l & 31) * 2 + (l >> 5)];
+      const int lin_of[3] = {0, 2, 4};
+      for (int k = 0; k < 3; ++k) centre_cols(w->lin_b[lin_of[k]], 1, &pack[WP_KVEC + k * 32]);
+    }
     uint16_t* bf = reinterpret_cast<uint16_t*>(&pack[WP_BF]);
     for (int L = 0; L < 4; ++L)
       for (int s2 = 0; s2 < 2; ++s2)
         for (int l = 0; l < 64; ++l)
           for (int q = 0; q < 8; ++q) {
-            float wv = w->lin_w[1 + L][(l & 31) * 32 + npa_feat(8 * s2 + q, l >> 5)];
+            float wv = wkey[L][(l & 31) * 32 + npa_feat(8 * s2 + q, l >> 5)];
             float r = wv;
             for (int t = 0; t < 3; ++t) {
               uint16_t b = bf16_rne(r);

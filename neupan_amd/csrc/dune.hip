@@ -115,21 +115,43 @@ __device__ __forceinline__ f32x16 layer32(const float (&w)[16], const float (&a)
 // matrix pipe concurrently with the VALU work of the other waves of the SIMD.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// RELU = true: the split is taken of max(a, 0) (the activation of the Linear->ReLU layers)
+template <bool RELU>
 __device__ __forceinline__ void split3(const float (&a)[16], bf16x8 (&x1)[2], bf16x8 (&x2)[2], bf16x8 (&x3)[2]) {
+  // two features at a time: v_cvt_pk_bf16_f32 rounds a pair, the residual is one packed subtract
+  auto widen = [](bf16x2 b) -> f32x2_t {
+    const unsigned u = __builtin_bit_cast(unsigned, b);
+    return f32x2_t{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+  };
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const __bf16 b1 = (__bf16)a[r];
-    const float r1 = a[r] - (float)b1;
-    const __bf16 b2 = (__bf16)r1;
-    const __bf16 b3 = (__bf16)(r1 - (float)b2);
-    x1[r >> 3][r & 7] = b1; x2[r >> 3][r & 7] = b2; x3[r >> 3][r & 7] = b3;
+  for (int p = 0; p < 8; ++p) {
+    f32x2_t v = {a[2 * p], a[2 * p + 1]};
+    if constexpr (RELU) {
+      // integer max on the bit pattern = ReLU in ONE instruction (fmaxf would first canonicalise the
+      // MFMA result with a second v_max; negative floats are negative ints, -0 -> +0)
+      v.x = __int_as_float(max(__float_as_int(v.x), 0));
+      v.y = __int_as_float(max(__float_as_int(v.y), 0));
+    }
+    const bf16x2 b1 = __builtin_convertvector(v, bf16x2);
+    const f32x2_t r1 = v - widen(b1);
+    const bf16x2 b2 = __builtin_convertvector(r1, bf16x2);
+    const f32x2_t r2 = r1 - widen(b2);
+    const bf16x2 b3 = __builtin_convertvector(r2, bf16x2);
+    const int s = p >> 2, q = (2 * p) & 7;
+    x1[s][q] = b1.x; x1[s][q + 1] = b1.y;
+    x2[s][q] = b2.x; x2[s][q + 1] = b2.y;
+    x3[s][q] = b3.x; x3[s][q + 1] = b3.y;
   }
 }
 
 // wl: LDS image of one layer's split A-fragments [term 3][step 2][lane 64] x 16 B
+template <bool RELU>
 __device__ __forceinline__ f32x16 layer32_bf16x3(const bf16x8* wl, int lane, const float (&a)[16], f32x16 acc) {
   bf16x8 x1[2], x2[2], x3[2];
-  split3(a, x1, x2, x3);
+  split3<RELU>(a, x1, x2, x3);
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const bf16x8 w1 = wl[(0 * 2 + s) * 64 + lane], w2 = wl[(1 * 2 + s) * 64 + lane], w3 = wl[(2 * 2 + s) * 64 + lane];
@@ -141,6 +163,84 @@ __device__ __forceinline__ f32x16 layer32_bf16x3(const bf16x8* wl, int lane, con
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x1[s], acc, 0, 0, 0);
   }
   return acc;
+}
+
+// ---- key path: reassociated encoder (packed fp32 VALU, LayerNorm centring folded into the weights) --
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// acc holds CENTRED pre-activations (mean removed through W_c, b_c): var = sum(acc^2)/32
+__device__ __forceinline__ void ln_tanh_centred(f32x16 acc, const float* g, const float* be, int hf, float a[16]) {
+  f32x2 q2 = {0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const f32x2 v = {acc[2 * p], acc[2 * p + 1]};
+    q2 = __builtin_elementwise_fma(v, v, q2);
+  }
+  const float ve = fmaf(pair_sum(q2.x + q2.y), 1.0f / 32.0f, 1e-5f);
+  float rstd = __builtin_amdgcn_rsqf(ve);
+  rstd = rstd * fmaf(-0.5f * ve * rstd, rstd, 1.5f);
+  const f32x2 rs = {rstd, rstd}, one = {1.f, 1.f}, mtwo = {-2.f, -2.f};
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    const float4 gv = *reinterpret_cast<const float4*>(g + 8 * qd + 4 * hf);
+    const float4 bv = *reinterpret_cast<const float4*>(be + 8 * qd + 4 * hf);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const f32x2 x = {acc[4 * qd + 2 * hh], acc[4 * qd + 2 * hh + 1]};
+      const f32x2 gg = hh ? f32x2{gv.z, gv.w} : f32x2{gv.x, gv.y};
+      const f32x2 bb = hh ? f32x2{bv.z, bv.w} : f32x2{bv.x, bv.y};
+      const f32x2 y = __builtin_elementwise_fma(x * rs, gg, bb);
+      f32x2 e = {__builtin_amdgcn_exp2f(y.x), __builtin_amdgcn_exp2f(y.y)};
+      e = e + one;
+      const f32x2 r = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+      const f32x2 th = __builtin_elementwise_fma(r, mtwo, one);
+      a[4 * qd + 2 * hh] = th.x; a[4 * qd + 2 * hh + 1] = th.y;
+    }
+  }
+}
+
+// LDS image of the key path: split fragments, then kvec [3][32]
+template <int E>
+__device__ __forceinline__ void encode_tile_keys(float kw1, const bf16x8* wbf, const float* vec, const float* w6,
+                                                 const float* b6, float p0x, float p0y, int lane, float mu[E]) {
+  const int hf = lane >> 5;
+  const float* kvec = reinterpret_cast<const float*>(wbf) + WP_BF_FLOATS;
+  float a[16];
+  {
+    f32x16 acc = bias_init(kvec + 0 * 32, hf);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kw1, hf ? p0y : p0x, acc, 0, 0, 0);
+    ln_tanh_centred(acc, vec + V_G1 * 32, vec + V_BE1 * 32, hf, a);
+  }
+  // the ReLU of Linear 2 / Linear 4 is applied inside the split of the following layer
+  {
+    f32x16 acc = layer32_bf16x3<false>(wbf + (size_t)0 * 3 * 2 * 64, lane, a, bias_init(vec + V_B2 * 32, hf));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = acc[r];
+  }
+  {
+    f32x16 acc = layer32_bf16x3<true>(wbf + (size_t)1 * 3 * 2 * 64, lane, a, bias_init(kvec + 1 * 32, hf));
+    ln_tanh_centred(acc, vec + V_G2 * 32, vec + V_BE2 * 32, hf, a);
+  }
+  {
+    f32x16 acc = layer32_bf16x3<false>(wbf + (size_t)2 * 3 * 2 * 64, lane, a, bias_init(vec + V_B4 * 32, hf));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = acc[r];
+  }
+  {
+    f32x16 acc = layer32_bf16x3<true>(wbf + (size_t)3 * 3 * 2 * 64, lane, a, bias_init(kvec + 2 * 32, hf));
+    ln_tanh_centred(acc, vec + V_G3 * 32, vec + V_BE3 * 32, hf, a);
+  }
+  // output layer: two features per packed FMA (rows of Linear 6 as stored for the exact path)
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    float wv[16];
+    load_vec16(w6 + e * 32, hf, wv);
+    f32x2 s2 = {0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+      s2 = __builtin_elementwise_fma(f32x2{wv[2 * p], wv[2 * p + 1]}, f32x2{a[2 * p], a[2 * p + 1]}, s2);
+    mu[e] = fmaxf(pair_sum(s2.x + s2.y) + b6[e], 0.f);
+  }
 }
 
 struct WaveWeights {
@@ -157,7 +257,7 @@ __device__ __forceinline__ void encode_tile(const WaveWeights& W, const bf16x8* 
                                             const float* b6, float p0x, float p0y, int lane, float mu[E]) {
   const int hf = lane >> 5;
   auto layer = [&](int L, const float (&a_)[16], f32x16 acc) -> f32x16 {
-    if constexpr (SPLIT) return layer32_bf16x3(wbf + (size_t)L * 3 * 2 * 64, lane, a_, acc);
+    if constexpr (SPLIT) return layer32_bf16x3<false>(wbf + (size_t)L * 3 * 2 * 64, lane, a_, acc);
     else return layer32(W.wl[L], a_, acc);
   };
   float a[16];
@@ -278,7 +378,8 @@ __device__ __forceinline__ void point_features(const DevParams& P, const SliceFr
   float dx = __fsub_rn(gx, F.tx), dy = __fsub_rn(gy, F.ty);
   float p0x = fmaf(F.c, dx, __fmul_rn(F.s, dy));
   float p0y = fmaf(F.c, dy, -__fmul_rn(F.s, dx));
-  encode_tile<E, SPLIT>(W, wbf, vec, w6, b6, p0x, p0y, lane, mu);
+  if constexpr (SPLIT) encode_tile_keys<E>(W.w1, wbf, vec, w6, b6, p0x, p0y, lane, mu);   // W.w1 = centred fragment
+  else encode_tile<E, false>(W, wbf, vec, w6, b6, p0x, p0y, lane, mu);
   lx = 0.f; ly = 0.f; dist = 0.f;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
@@ -326,9 +427,9 @@ void dune_kernel(
   const bf16x8* wbf = nullptr;
   if constexpr (SPLIT) {
     float* wb = b6 + 8;                     // 16-byte aligned: (11*32 + 8*32 + 8) floats precede it
-    for (int i = tid; i < WP_BF_FLOATS; i += 64 * WAVES) wb[i] = wpack[WP_BF + i];
+    for (int i = tid; i < WP_KEY_LDS_FLOATS; i += 64 * WAVES) wb[i] = wpack[WP_BF + i];
     wbf = reinterpret_cast<const bf16x8*>(wb);
-    W.w1 = wpack[WP_W1 + lane];
+    W.w1 = wpack[WP_KW1 + lane];
   } else {
     load_weights(wpack, lane, W);
   }
@@ -492,7 +593,7 @@ extern "C" hipError_t npa_launch_encode(const DevParams& P, const float* wpack, 
   int blocks = (int)((tiles + waves - 1) / waves);
   if (blocks > slots) blocks = slots;
   if (blocks < 1) blocks = 1;
-  const size_t shmem = (11 * 32 + 8 * 32 + 8) * sizeof(float) + (split ? WP_BF_FLOATS * sizeof(float) : 0);
+  const size_t shmem = (11 * 32 + 8 * 32 + 8) * sizeof(float) + (split ? WP_KEY_LDS_FLOATS * sizeof(float) : 0);
   static const int chunk_env = getenv("NPA_ENC_CHUNK") ? atoi(getenv("NPA_ENC_CHUNK")) : 2;
   const int chunk = chunk_env < 1 ? 1 : chunk_env;
 #define LAUNCH1(EE, SP, WV)                                                                                         \

@@ -39,7 +39,15 @@ struct DevParams {
 // contracts over the features feat(8s+q, hf).  [layer 4][term 3][step 2][lane 64][8 bf16]
 #define WP_BF (WP_B6 + 8)
 #define WP_BF_FLOATS (4 * 3 * 2 * 64 * 4)
-#define WP_TOTAL (WP_BF + WP_BF_FLOATS)
+// key-path extras, contiguous behind the split fragments (staged into LDS together with them).
+// The distance keys only decide WHICH points are kept (the kept rows are re-encoded exactly), so the
+// key path may reassociate: the LayerNorm mean is removed through the weights,
+//   W_c = (I - 11'/32) W,  b_c = b - mean(b)     (Linear 1, 3, 5: the layers followed by LayerNorm)
+// -- the split fragments of layers 3 and 5 in WP_BF are those of W_c.
+#define WP_KVEC (WP_BF + WP_BF_FLOATS)            // [3][32]  centred biases of Linear 1, 3, 5
+#define WP_KW1 (WP_KVEC + 3 * 32)                 // [64]     centred Linear(2,32) A-fragment (read per lane)
+#define WP_KEY_LDS_FLOATS (WP_BF_FLOATS + 3 * 32)
+#define WP_TOTAL (WP_KW1 + 64)
 // order of the per-feature vectors
 enum { V_B1 = 0, V_G1, V_BE1, V_B2, V_B3, V_G2, V_BE2, V_B4, V_B5, V_G3, V_BE3 };
 

@@ -1,0 +1,34 @@
+"""GPU diagnostic: determinism of the DUNE stage and agreement of the split-key selection with the
+exact-fp32-key selection.   python tools/key_check.py out.npz [B]      (run once per key mode)"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from helpers import CONFIGS
+from gpu_helpers import make_gpu_pan
+from neupan_amd.scenes import make_batch
+
+out = sys.argv[1]
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+cfg = CONFIGS["diff_1k_T10_K10"]
+pan = make_gpu_pan(cfg)
+batch = make_batch(cfg, 1000, B)
+ref = None
+nd = 0
+for rep in range(8):
+    r = pan.dune_stage(batch["nom_s"], batch["points"])
+    cur = {k: v.cpu().numpy() for k, v in r.items()}
+    if ref is None:
+        ref = cur
+    else:
+        bad = int((cur["pts"] != ref["pts"]).any(axis=(2, 3)).sum())
+        nd += bad
+        print("rep", rep, "slices differing from rep 0:", bad)
+print("nondeterministic slices total", nd)
+np.savez(out, **ref)
+if len(sys.argv) > 3:
+    other = np.load(sys.argv[3])
+    diff = (other["pts"] != ref["pts"]).any(axis=(2, 3))
+    print("slices whose selection differs from", sys.argv[3], ":", int(diff.sum()), "of", diff.size)
+    dd = np.abs(other["dist"] - ref["dist"])
+    print("max |dist difference|", float(dd.max()))
