@@ -151,6 +151,47 @@ int npa_nrmp_stage(npa_handle *h, int batch, const float *nom_s, const float *no
 int npa_profile_enable(npa_handle *h, int enable);
 int npa_profile_read(npa_handle *h, double *dune_ms_avg, double *nrmp_ms_avg, int64_t *launches);
 
+/* ---- the two steps in front of PAN.forward (handle-free, stream-ordered) --------------------------
+ *
+ * npa_nominal_ref_states replaces InitialPath.generate_nom_ref_state (+ motion_predict_model)
+ *   neupan/blocks/initial_path.py:68-126, :388-444, called at neupan/neupan.py:117-119:
+ *   for each scene the T-step rollout of the previous control (nom_s, nom_u) and the reference
+ *   states / gears sampled along its current path curve (ref_s, ref_us).  float64 arithmetic in
+ *   the reference's order, float32 outputs in the layout npa_forward_batch consumes
+ *   (the reference casts at neupan.py:121).
+ *   state [B][3] f64; cur_vel [B][2][T] f32 (PAN's previous opt_u; NULL = zeros, the reference's
+ *   first call, neupan.py:73); ref_speed [B] f64; path [rows][4] f64 rows (x, y, theta, gear) of
+ *   every scene's CURRENT curve (initial_path.py:446-448), scene b owns rows
+ *   curve_off[b] .. curve_off[b]+curve_len[b]-1; point_index [B] (closest_point's result,
+ *   :160-181); interval [B] f64 (:56, :139).  The path is not modified (the reference writes
+ *   2*pi-equivalent headings back into it, :111-112, :190-192).
+ *
+ * npa_scan_to_points replaces neupan.scan_to_point (mode 0, neupan/neupan.py:173-222) and
+ *   neupan.scan_to_point_velocity (mode 1, :224-281): range/angle filter, polar -> sensor frame ->
+ *   robot frame -> world frame, ordered compaction, down-sampling of the kept list.
+ *   ranges [B][beam_stride] f64, beam_vel [B][2][beam_stride] f64 or NULL, n_beams [B] or NULL
+ *   (= beam_stride); points / velocities [B][2][out_stride] f32 (velocities may be NULL), count [B]
+ *   (0 where the reference returns None).  Beams beyond out_stride kept points are dropped. */
+typedef struct npa_scan_params {
+  double angle_min, angle_max;   /* scan["angle_min"], scan["angle_max"]                         */
+  double range_min, range_max;   /* scan["range_min"], scan["range_max"]                         */
+  double state[3];               /* robot pose x, y, theta                                        */
+  double offset[3];              /* scan_offset: sensor pose in the robot frame                   */
+  double angle_range[2];         /* beams outside (lo, hi) are dropped                            */
+  int32_t down_sample;           /* keep every down_sample-th of the surviving points             */
+  int32_t reserved;
+} npa_scan_params;
+
+int npa_nominal_ref_states(int batch, int receding, int kinematics, double step_time, double wheelbase,
+                           const double *state, const float *cur_vel, const double *ref_speed,
+                           const double *path, const int32_t *curve_off, const int32_t *curve_len,
+                           const int32_t *point_index, const double *interval, float *nom_s,
+                           float *nom_u, float *ref_s, float *ref_us, void *stream);
+int npa_scan_to_points(int batch, int beam_stride, const double *ranges, const double *beam_vel,
+                       const int32_t *n_beams, const npa_scan_params *params, int mode,
+                       int out_stride, float *points, float *velocities, int32_t *count,
+                       void *stream);
+
 const char *npa_last_error(void);
 const char *npa_version(void);
 

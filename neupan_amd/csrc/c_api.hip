@@ -28,6 +28,14 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
                                     int* out_iters, float* out_nrmp_points, int* flags, float* state,
                                     double* qp_info, double* warm, hipStream_t stream);
 extern "C" size_t npa_qp_shmem_bytes(int T, int M);
+extern "C" hipError_t npa_launch_nominal(int batch, int T, int kin, double dt, double L, const double* state,
+                                         const float* vel, const double* ref_speed, const double* path,
+                                         const int* curve_off, const int* curve_len, const int* point_index,
+                                         const double* interval, float* nom_s, float* nom_u, float* ref_s,
+                                         float* ref_us, hipStream_t stream);
+extern "C" hipError_t npa_launch_scan(int batch, int beam_stride, const double* ranges, const double* beam_vel,
+                                      const int* n_beams, const npa_scan_params* params, int mode, int out_stride,
+                                      float* points, float* velocities, int* count, hipStream_t stream);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -460,6 +468,35 @@ extern "C" int npa_forward_batch(npa_handle* h, int batch, int n_stride, const f
     if (rc != NPA_OK) { npa_forward_end(h); return rc; }
   }
   return npa_forward_end(h);
+}
+
+// ---- front end (frontend.hip) ----------------------------------------------------------------------
+extern "C" int npa_nominal_ref_states(int batch, int receding, int kinematics, double step_time, double wheelbase,
+                                      const double* state, const float* cur_vel, const double* ref_speed,
+                                      const double* path, const int32_t* curve_off, const int32_t* curve_len,
+                                      const int32_t* point_index, const double* interval, float* nom_s, float* nom_u,
+                                      float* ref_s, float* ref_us, void* stream) {
+  if (batch < 1 || !state || !ref_speed || !path || !curve_off || !curve_len || !point_index || !interval || !nom_s ||
+      !nom_u || !ref_s || !ref_us)
+    return fail(NPA_E_ARG, "npa_nominal_ref_states: bad argument");
+  if (receding < 1 || receding > NPA_MAX_T) return fail(NPA_E_UNSUPPORTED, "receding outside [1,NPA_MAX_T]");
+  if (kinematics < 0 || kinematics > 2) return fail(NPA_E_ARG, "unknown kinematics");
+  if (kinematics == NPA_KIN_ACKER && !(wheelbase > 0)) return fail(NPA_E_ARG, "acker needs wheelbase > 0");
+  HIP_TRY(npa_launch_nominal(batch, receding, kinematics, step_time, wheelbase, state, cur_vel, ref_speed, path,
+                             curve_off, curve_len, point_index, interval, nom_s, nom_u, ref_s, ref_us,
+                             (hipStream_t)stream));
+  return NPA_OK;
+}
+
+extern "C" int npa_scan_to_points(int batch, int beam_stride, const double* ranges, const double* beam_vel,
+                                  const int32_t* n_beams, const npa_scan_params* params, int mode, int out_stride,
+                                  float* points, float* velocities, int32_t* count, void* stream) {
+  if (batch < 1 || beam_stride < 1 || out_stride < 1 || !ranges || !params || !points || !count)
+    return fail(NPA_E_ARG, "npa_scan_to_points: bad argument");
+  if (mode != 0 && mode != 1) return fail(NPA_E_ARG, "npa_scan_to_points: mode must be 0 or 1");
+  HIP_TRY(npa_launch_scan(batch, beam_stride, ranges, beam_vel, n_beams, params, mode, out_stride, points, velocities,
+                          count, (hipStream_t)stream));
+  return NPA_OK;
 }
 
 static void drop_pending(npa_handle* h) {
