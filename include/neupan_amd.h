@@ -192,6 +192,18 @@ int npa_scan_to_points(int batch, int beam_stride, const double *ranges, const d
                        int out_stride, float *points, float *velocities, int32_t *count,
                        void *stream);
 
+/* ---- DUNE training labels (offline) ---------------------------------------------------------------
+ * npa_dune_labels replaces DUNETrain.prob_solve / generate_data_set
+ *   (neupan/blocks/dune_train.py:82-99, :109-140): for every point p the maximiser mu of
+ *   mu^T (G p - h) s.t. ||G^T mu|| <= 1, mu >= 0 and the optimal value (the distance of p to the
+ *   robot polygon), by closed form instead of one ECOS call per point.
+ *   G [E][2], h [E]: HOST arrays (float64), consecutive counter-clockwise edges as
+ *   gen_inequal_from_vertex produces them (util/__init__.py:161-206);
+ *   points [n][2] f64 (device); mu [n][E] f32, dist [n] f32 (device; the reference stores float32
+ *   tensors, dune_train.py:101-107). */
+int npa_dune_labels(int edge_num, const double *G, const double *h, int64_t n, const double *points,
+                    float *mu, float *dist, void *stream);
+
 const char *npa_last_error(void);
 const char *npa_version(void);
 

@@ -50,6 +50,7 @@ SYMBOLS = {
     "npa_nrmp_stage": (_I, [_P, _I] + [_P] * 12 + [_P]),
     "npa_nominal_ref_states": (_I, [_I, _I, _I, C.c_double, C.c_double] + [_P] * 12 + [_P]),
     "npa_scan_to_points": (_I, [_I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "npa_dune_labels": (_I, [_I, _P, _P, C.c_int64, _P, _P, _P, _P]),
     "npa_profile_enable": (_I, [_P, _I]),
     "npa_profile_read": (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "npa_last_error": (C.c_char_p, []),

@@ -499,6 +499,16 @@ extern "C" int npa_scan_to_points(int batch, int beam_stride, const double* rang
   return NPA_OK;
 }
 
+extern "C" hipError_t npa_launch_labels(int E, const double* G, const double* h, long long n, const double* points,
+                                        float* mu, float* dist, hipStream_t stream);
+extern "C" int npa_dune_labels(int edge_num, const double* G, const double* h, int64_t n, const double* points,
+                               float* mu, float* dist, void* stream) {
+  if (!G || !h || n < 0 || (n > 0 && (!points || !mu || !dist))) return fail(NPA_E_ARG, "npa_dune_labels: bad argument");
+  if (edge_num < 3 || edge_num > NPA_MAX_E) return fail(NPA_E_UNSUPPORTED, "edge_num outside [3,NPA_MAX_E]");
+  HIP_TRY(npa_launch_labels(edge_num, G, h, (long long)n, points, mu, dist, (hipStream_t)stream));
+  return NPA_OK;
+}
+
 static void drop_pending(npa_handle* h) {
   std::lock_guard<std::mutex> lock(g_pending_mu);
   for (size_t i = 0; i < g_pending.size(); ++i)
