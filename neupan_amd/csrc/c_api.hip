@@ -129,15 +129,8 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
       memcpy(&pack[WP_W6 + e * 32], w->lin_w[5] + e * 32, 32 * sizeof(float));
       pack[WP_B6 + e] = w->lin_b[5][e];
     }
-    // bf16x3 split fragments (see pan_common.h)
-    auto bf16_rne = [](float x) -> uint16_t {
-      uint32_t u; memcpy(&u, &x, 4);
-      if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
-      u += 0x7fffu + ((u >> 16) & 1u);
-      return (uint16_t)(u >> 16);
-    };
-    auto bf16_to_f = [](uint16_t b) -> float { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; };
-    // key path (dune_kernel): LayerNorm centring folded into Linear 1, 3, 5 (fp64, rounded once)
+    // ---- key path (dune_kernel): see pan_common.h --------------------------------------------------
+    // LayerNorm centring folded into Linear 1, 3, 5 (fp64, rounded once)
     std::vector<float> wkey[4];                       // the four 32x32 layers as the key path sees them
     for (int L = 0; L < 4; ++L) wkey[L].assign(w->lin_w[1 + L], w->lin_w[1 + L] + 32 * 32);
     auto centre_cols = [](const float* W, int ncol, float* out) {   // out = (I - 11'/32) W, W is [32][ncol]
@@ -150,25 +143,70 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
     };
     centre_cols(w->lin_w[2], 32, wkey[1].data());     // Linear 3
     centre_cols(w->lin_w[4], 32, wkey[3].data());     // Linear 5
+    float bkey[5][32];                                // biases of Linear 1..5 as the key path sees them
     {
       float w1c[32 * 2];
       centre_cols(w->lin_w[0], 2, w1c);
       for (int l = 0; l < 64; ++l) pack[WP_KW1 + l] = w1c[(l & 31) * 2 + (l >> 5)];
-      const int lin_of[3] = {0, 2, 4};
-      for (int k = 0; k < 3; ++k) centre_cols(w->lin_b[lin_of[k]], 1, &pack[WP_KVEC + k * 32]);
+      centre_cols(w->lin_b[0], 1, bkey[0]);
+      memcpy(bkey[1], w->lin_b[1], sizeof(bkey[1]));
+      centre_cols(w->lin_b[2], 1, bkey[2]);
+      memcpy(bkey[3], w->lin_b[3], sizeof(bkey[3]));
+      centre_cols(w->lin_b[4], 1, bkey[4]);
     }
-    uint16_t* bf = reinterpret_cast<uint16_t*>(&pack[WP_BF]);
+    // exact power-of-two scales.  tanh outputs are produced as 2^10 * tanh; a Linear->ReLU layer
+    // (key layers 0, 2) gets the largest weight scale for which its output provably fits fp16
+    // (|z_i| <= sum_j |W_ij| + |b_i| because |tanh| <= 1); a Linear->LayerNorm layer (1, 3) is
+    // scale-free downstream, its weights are scaled into [512, 1024).
+    const double TANH_SCALE = 1024.0;
+    double sig_out[4];                                 // scale of each key layer's accumulator
+    double wscale[4];
+    for (int L = 0; L < 4; ++L) {
+      double wmax = 0, bound = 0;
+      for (int i = 0; i < 32; ++i) {
+        double r = std::fabs((double)bkey[1 + L][i]);
+        for (int jx = 0; jx < 32; ++jx) {
+          r += std::fabs((double)wkey[L][i * 32 + jx]);
+          wmax = std::max(wmax, std::fabs((double)wkey[L][i * 32 + jx]));
+        }
+        bound = std::max(bound, r);
+      }
+      if (!(wmax > 0)) wmax = 1;
+      if (L == 0 || L == 2) {
+        const double sig_in = TANH_SCALE;
+        int e = (int)std::floor(std::log2(30000.0 / (sig_in * std::max(bound, 1e-30))));
+        e = std::max(-14, std::min(14, e));
+        while (e > -14 && std::ldexp(wmax, e) > 30000.0) --e;
+        wscale[L] = std::ldexp(1.0, e);
+        sig_out[L] = sig_in * wscale[L];
+      } else {
+        const double sig_in = sig_out[L - 1];
+        int e = (int)std::floor(std::log2(1023.0 / wmax));
+        e = std::max(-14, std::min(24, e));
+        wscale[L] = std::ldexp(1.0, e);
+        sig_out[L] = sig_in * wscale[L];
+      }
+    }
+    for (int i = 0; i < 32; ++i) {
+      pack[WP_KVEC + 0 * 32 + i] = bkey[0][i];
+      for (int L = 0; L < 4; ++L) pack[WP_KVEC + (1 + L) * 32 + i] = (float)((double)bkey[1 + L][i] * sig_out[L]);
+    }
+    pack[WP_KSC + 0] = 1e-5f;
+    pack[WP_KSC + 1] = (float)(1e-5 * sig_out[1] * sig_out[1]);
+    pack[WP_KSC + 2] = (float)(1e-5 * sig_out[3] * sig_out[3]);
+    pack[WP_KSC + 3] = (float)TANH_SCALE;              // after LayerNorm 1, 2: feeds a split layer
+    pack[WP_KSC + 4] = (float)TANH_SCALE;
+    pack[WP_KSC + 5] = 1.0f;                           // after LayerNorm 3: feeds the output layer
+    _Float16* kh = reinterpret_cast<_Float16*>(&pack[WP_BF]);
     for (int L = 0; L < 4; ++L)
       for (int s2 = 0; s2 < 2; ++s2)
         for (int l = 0; l < 64; ++l)
           for (int q = 0; q < 8; ++q) {
-            float wv = wkey[L][(l & 31) * 32 + npa_feat(8 * s2 + q, l >> 5)];
-            float r = wv;
-            for (int t = 0; t < 3; ++t) {
-              uint16_t b = bf16_rne(r);
-              bf[((((size_t)L * 3 + t) * 2 + s2) * 64 + l) * 8 + q] = b;
-              r -= bf16_to_f(b);
-            }
+            const float wv = (float)((double)wkey[L][(l & 31) * 32 + npa_feat(8 * s2 + q, l >> 5)] * wscale[L]);
+            const _Float16 h1 = (_Float16)wv;                       // RNE
+            const _Float16 h2 = (_Float16)(wv - (float)h1);
+            kh[((((size_t)L * 2 + 0) * 2 + s2) * 64 + l) * 8 + q] = h1;
+            kh[((((size_t)L * 2 + 1) * 2 + s2) * 64 + l) * 8 + q] = h2;
           }
   }
   if (const char* env = getenv("NPA_PIPELINE")) {

@@ -106,26 +106,20 @@ __device__ __forceinline__ f32x16 layer32(const float (&w)[16], const float (&a)
   return acc;
 }
 
-// ---- bf16x3 split-precision layer (dune_kernel only: distance keys) ------------------------------
-// x = x1 + x2 + x3 with bf16 terms (RNE of the running residual: |x - x1 - x2 - x3| <= 2^-24 |x|),
-// product terms (1,1) (1,2) (2,1) (1,3) (3,1) (2,2) kept: the dropped ones are <= 2^-25 relative,
-// below fp32 rounding.  Each bf16 x bf16 product is exact in the fp32 accumulator, so the layer is
-// fp32-accurate (not bit-identical to the fmaf chain of the fp32 MFMA) at 12 x 32-cycle MFMAs
-// instead of 16 x 64-cycle ones -- and, unlike the fp32-input MFMA, the bf16 MFMA runs on the
-// matrix pipe concurrently with the VALU work of the other waves of the SIMD.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// ---- fp16x2 split-precision layer (dune_kernel only: distance keys) ------------------------------
+// x = x1 + x2, w = w1 + w2 with fp16 terms (RNE of the running residual: |x - x1 - x2| <= 2^-22 |x|
+// while the terms are normal numbers, which the host-chosen power-of-two scales guarantee for
+// every value that matters), product terms (2,1) (1,2) (1,1); the dropped (2,2) term is <= 2^-22
+// relative.  Each fp16 x fp16 product is exact in the fp32 accumulator.  6 x 32-cycle MFMAs per
+// layer instead of 16 x 64-cycle fp32-input ones.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef f16x8 bf16x8;      // (name kept by the staging code: a 16-byte fragment per lane)
 
 // RELU = true: the split is taken of max(a, 0) (the activation of the Linear->ReLU layers)
 template <bool RELU>
-__device__ __forceinline__ void split3(const float (&a)[16], bf16x8 (&x1)[2], bf16x8 (&x2)[2], bf16x8 (&x3)[2]) {
-  // two features at a time: v_cvt_pk_bf16_f32 rounds a pair, the residual is one packed subtract
-  auto widen = [](bf16x2 b) -> f32x2_t {
-    const unsigned u = __builtin_bit_cast(unsigned, b);
-    return f32x2_t{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
-  };
+__device__ __forceinline__ void split2(const float (&a)[16], f16x8 (&x1)[2], f16x8 (&x2)[2]) {
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
     f32x2_t v = {a[2 * p], a[2 * p + 1]};
@@ -135,32 +129,26 @@ __device__ __forceinline__ void split3(const float (&a)[16], bf16x8 (&x1)[2], bf
       v.x = __int_as_float(max(__float_as_int(v.x), 0));
       v.y = __int_as_float(max(__float_as_int(v.y), 0));
     }
-    const bf16x2 b1 = __builtin_convertvector(v, bf16x2);
-    const f32x2_t r1 = v - widen(b1);
-    const bf16x2 b2 = __builtin_convertvector(r1, bf16x2);
-    const f32x2_t r2 = r1 - widen(b2);
-    const bf16x2 b3 = __builtin_convertvector(r2, bf16x2);
+    const f16x2 b1 = __builtin_convertvector(v, f16x2);                 // v_cvt_pk_f16_f32 (RNE)
+    const f32x2_t r1 = v - __builtin_convertvector(b1, f32x2_t);
+    const f16x2 b2 = __builtin_convertvector(r1, f16x2);
     const int s = p >> 2, q = (2 * p) & 7;
     x1[s][q] = b1.x; x1[s][q + 1] = b1.y;
     x2[s][q] = b2.x; x2[s][q + 1] = b2.y;
-    x3[s][q] = b3.x; x3[s][q + 1] = b3.y;
   }
 }
 
-// wl: LDS image of one layer's split A-fragments [term 3][step 2][lane 64] x 16 B
+// wl: LDS image of one layer's split A-fragments [term 2][step 2][lane 64] x 16 B
 template <bool RELU>
-__device__ __forceinline__ f32x16 layer32_bf16x3(const bf16x8* wl, int lane, const float (&a)[16], f32x16 acc) {
-  bf16x8 x1[2], x2[2], x3[2];
-  split3<RELU>(a, x1, x2, x3);
+__device__ __forceinline__ f32x16 layer32_f16x2(const f16x8* wl, int lane, const float (&a)[16], f32x16 acc) {
+  f16x8 x1[2], x2[2];
+  split2<RELU>(a, x1, x2);
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const bf16x8 w1 = wl[(0 * 2 + s) * 64 + lane], w2 = wl[(1 * 2 + s) * 64 + lane], w3 = wl[(2 * 2 + s) * 64 + lane];
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, x1[s], acc, 0, 0, 0);     // small terms first
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x3[s], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x2[s], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x1[s], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x2[s], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x1[s], acc, 0, 0, 0);
+    const f16x8 w1 = wl[(0 * 2 + s) * 64 + lane], w2 = wl[(1 * 2 + s) * 64 + lane];
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, x1[s], acc, 0, 0, 0);      // small terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, x2[s], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, x1[s], acc, 0, 0, 0);
   }
   return acc;
 }
@@ -169,17 +157,19 @@ __device__ __forceinline__ f32x16 layer32_bf16x3(const bf16x8* wl, int lane, con
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // acc holds CENTRED pre-activations (mean removed through W_c, b_c): var = sum(acc^2)/32
-__device__ __forceinline__ void ln_tanh_centred(f32x16 acc, const float* g, const float* be, int hf, float a[16]) {
+__device__ __forceinline__ void ln_tanh_centred(f32x16 acc, const float* g, const float* be, int hf, float eps,
+                                                float out_scale, float a[16]) {
   f32x2 q2 = {0.f, 0.f};
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
     const f32x2 v = {acc[2 * p], acc[2 * p + 1]};
     q2 = __builtin_elementwise_fma(v, v, q2);
   }
-  const float ve = fmaf(pair_sum(q2.x + q2.y), 1.0f / 32.0f, 1e-5f);
+  const float ve = fmaf(pair_sum(q2.x + q2.y), 1.0f / 32.0f, eps);
   float rstd = __builtin_amdgcn_rsqf(ve);
   rstd = rstd * fmaf(-0.5f * ve * rstd, rstd, 1.5f);
-  const f32x2 rs = {rstd, rstd}, one = {1.f, 1.f}, mtwo = {-2.f, -2.f};
+  // out_scale * tanh: out_scale - 2 out_scale / (e + 1)
+  const f32x2 rs = {rstd, rstd}, one = {1.f, 1.f}, osc = {out_scale, out_scale}, mtwo = {-2.f * out_scale, -2.f * out_scale};
 #pragma unroll
   for (int qd = 0; qd < 4; ++qd) {
     const float4 gv = *reinterpret_cast<const float4*>(g + 8 * qd + 4 * hf);
@@ -193,42 +183,44 @@ __device__ __forceinline__ void ln_tanh_centred(f32x16 acc, const float* g, cons
       f32x2 e = {__builtin_amdgcn_exp2f(y.x), __builtin_amdgcn_exp2f(y.y)};
       e = e + one;
       const f32x2 r = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
-      const f32x2 th = __builtin_elementwise_fma(r, mtwo, one);
+      const f32x2 th = __builtin_elementwise_fma(r, mtwo, osc);
       a[4 * qd + 2 * hh] = th.x; a[4 * qd + 2 * hh + 1] = th.y;
     }
   }
 }
 
-// LDS image of the key path: split fragments, then kvec [3][32]
+// LDS image of the key path: split fragments, then kvec [5][32], then ksc [8] (pan_common.h)
 template <int E>
-__device__ __forceinline__ void encode_tile_keys(float kw1, const bf16x8* wbf, const float* vec, const float* w6,
+__device__ __forceinline__ void encode_tile_keys(float kw1, const f16x8* wbf, const float* vec, const float* w6,
                                                  const float* b6, float p0x, float p0y, int lane, float mu[E]) {
   const int hf = lane >> 5;
   const float* kvec = reinterpret_cast<const float*>(wbf) + WP_BF_FLOATS;
+  const float* ksc = kvec + 5 * 32;
+  constexpr int LSTR = 2 * 2 * 64;          // fragments per layer
   float a[16];
   {
     f32x16 acc = bias_init(kvec + 0 * 32, hf);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kw1, hf ? p0y : p0x, acc, 0, 0, 0);
-    ln_tanh_centred(acc, vec + V_G1 * 32, vec + V_BE1 * 32, hf, a);
+    ln_tanh_centred(acc, vec + V_G1 * 32, vec + V_BE1 * 32, hf, ksc[0], ksc[3], a);
   }
   // the ReLU of Linear 2 / Linear 4 is applied inside the split of the following layer
   {
-    f32x16 acc = layer32_bf16x3<false>(wbf + (size_t)0 * 3 * 2 * 64, lane, a, bias_init(vec + V_B2 * 32, hf));
+    f32x16 acc = layer32_f16x2<false>(wbf + 0 * LSTR, lane, a, bias_init(kvec + 1 * 32, hf));
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = acc[r];
   }
   {
-    f32x16 acc = layer32_bf16x3<true>(wbf + (size_t)1 * 3 * 2 * 64, lane, a, bias_init(kvec + 1 * 32, hf));
-    ln_tanh_centred(acc, vec + V_G2 * 32, vec + V_BE2 * 32, hf, a);
+    f32x16 acc = layer32_f16x2<true>(wbf + 1 * LSTR, lane, a, bias_init(kvec + 2 * 32, hf));
+    ln_tanh_centred(acc, vec + V_G2 * 32, vec + V_BE2 * 32, hf, ksc[1], ksc[4], a);
   }
   {
-    f32x16 acc = layer32_bf16x3<false>(wbf + (size_t)2 * 3 * 2 * 64, lane, a, bias_init(vec + V_B4 * 32, hf));
+    f32x16 acc = layer32_f16x2<false>(wbf + 2 * LSTR, lane, a, bias_init(kvec + 3 * 32, hf));
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = acc[r];
   }
   {
-    f32x16 acc = layer32_bf16x3<true>(wbf + (size_t)3 * 3 * 2 * 64, lane, a, bias_init(kvec + 2 * 32, hf));
-    ln_tanh_centred(acc, vec + V_G3 * 32, vec + V_BE3 * 32, hf, a);
+    f32x16 acc = layer32_f16x2<true>(wbf + 3 * LSTR, lane, a, bias_init(kvec + 4 * 32, hf));
+    ln_tanh_centred(acc, vec + V_G3 * 32, vec + V_BE3 * 32, hf, ksc[2], ksc[5], a);
   }
   // output layer: two features per packed FMA (rows of Linear 6 as stored for the exact path)
 #pragma unroll
@@ -250,16 +242,12 @@ struct WaveWeights {
 
 // Encoder for the 32 points of a tile.  p0x/p0y: the point in the robot frame (both lanes of
 // a pair hold both).  Returns mu[e] (e<E) in BOTH lanes of the pair.
-// SPLIT = false: exact fp32 MFMA (v_mfma_f32_32x32x2_f32), weights in W.wl.
-// SPLIT = true : bf16x3 split MFMA, split weight fragments in LDS (wbf), W.wl unused.
-template <int E, bool SPLIT>
-__device__ __forceinline__ void encode_tile(const WaveWeights& W, const bf16x8* wbf, const float* vec, const float* w6,
-                                            const float* b6, float p0x, float p0y, int lane, float mu[E]) {
+// Exact fp32 MFMA (v_mfma_f32_32x32x2_f32), weights in W.wl; the reference's operation order.
+template <int E>
+__device__ __forceinline__ void encode_tile(const WaveWeights& W, const float* vec, const float* w6, const float* b6,
+                                            float p0x, float p0y, int lane, float mu[E]) {
   const int hf = lane >> 5;
-  auto layer = [&](int L, const float (&a_)[16], f32x16 acc) -> f32x16 {
-    if constexpr (SPLIT) return layer32_bf16x3<false>(wbf + (size_t)L * 3 * 2 * 64, lane, a_, acc);
-    else return layer32(W.wl[L], a_, acc);
-  };
+  auto layer = [&](int L, const float (&a_)[16], f32x16 acc) -> f32x16 { return layer32(W.wl[L], a_, acc); };
   float a[16];
   {
     f32x16 acc = bias_init(vec + V_B1 * 32, hf);
@@ -379,7 +367,7 @@ __device__ __forceinline__ void point_features(const DevParams& P, const SliceFr
   float p0x = fmaf(F.c, dx, __fmul_rn(F.s, dy));
   float p0y = fmaf(F.c, dy, -__fmul_rn(F.s, dx));
   if constexpr (SPLIT) encode_tile_keys<E>(W.w1, wbf, vec, w6, b6, p0x, p0y, lane, mu);   // W.w1 = centred fragment
-  else encode_tile<E, false>(W, wbf, vec, w6, b6, p0x, p0y, lane, mu);
+  else encode_tile<E>(W, vec, w6, b6, p0x, p0y, lane, mu);
   lx = 0.f; ly = 0.f; dist = 0.f;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
@@ -404,7 +392,7 @@ __device__ __forceinline__ void load_weights(const float* __restrict__ wpack, in
 // 4 waves per SIMD at <= 72 VGPRs and a single LDS copy of the weight fragments, which leaves room
 // (216 VGPRs per SIMD, 130 KB LDS) for a QP workgroup of another batch to be co-resident.
 template <int E, bool SPLIT, int WAVES>
-__global__ __attribute__((amdgpu_flat_work_group_size(64 * WAVES, 64 * WAVES), amdgpu_waves_per_eu(WAVES == 16 ? 7 : 4)))
+__global__ __attribute__((amdgpu_flat_work_group_size(64 * WAVES, 64 * WAVES), amdgpu_waves_per_eu(WAVES >= 8 ? 7 : 4)))
 void dune_kernel(
     DevParams P, const float* __restrict__ wpack, int n_stride, const float* __restrict__ cur_s,
     const float* __restrict__ points, const float* __restrict__ vel, const int* __restrict__ n_points,
@@ -437,32 +425,39 @@ void dune_kernel(
 
   const int nsl = T + 1 - t0;
   const int tps = key_stride >> 5;                          // tiles per slice
-  const long long total = (long long)nscene * nsl * tps;
+  const int total = nscene * nsl * tps;                     // < 2^31: checked by the launcher
   // Work distribution: the tile stream is cut into equal contiguous ranges, one per workgroup; inside
   // a workgroup the waves (one per SIMD) draw `chunk`-tile tickets from an LDS counter.  A purely
   // static split per wave is balanced only while the kernel has the chip to itself: a QP wave of
   // another batch in flight slows the DUNE waves on its SIMD by ~1.3x, and every launch would wait
   // for those.  (Tickets from a global counter were measured: same-address device-scope atomics
   // serialise at ~20 ns each, far too slow for 10^4 tickets per launch.)
-  const long long wg_lo = total * blockIdx.x / gridDim.x, wg_hi = total * (blockIdx.x + 1) / gridDim.x;
-  long long g = 0, hi = 0;
-  int cur_b = -1, cur_t = -1, n_raw = 0, n_use = 0;
+  const int wg_lo = (int)((long long)total * blockIdx.x / gridDim.x);
+  const int wg_hi = (int)((long long)total * (blockIdx.x + 1) / gridDim.x);
+  int g = 0, hi = 0, sl = 0, tile = 0;
+  int cur_sl = -1, n_raw = 0, n_use = 0, t = 0;
   bool skip = false;
   SliceFrame F;
   const float *px_row = nullptr, *py_row = nullptr, *vx_row = nullptr, *vy_row = nullptr;
+  unsigned* key_row = nullptr;
 #pragma unroll 1
-  for (;; ++g) {
-    if (g >= hi) {
+  for (;; ++g, ++tile) {
+    if (g >= hi) {                                          // next ticket: locate it in the stream
       int c = 0;
       if (lane == 0) c = atomicAdd(wg_ticket, chunk);
       g = wg_lo + __builtin_amdgcn_readfirstlane(c);
       if (g >= wg_hi) break;
       hi = g + chunk < wg_hi ? g + chunk : wg_hi;
+      sl = (int)((unsigned)g / (unsigned)tps);
+      tile = g - sl * tps;
+    } else if (tile == tps) {                               // ran into the next slice
+      tile = 0;
+      ++sl;
     }
-    const int sl = (int)(g / tps), tile = (int)(g - (long long)sl * tps);
-    const int bl = sl / nsl, t = sl - bl * nsl + t0, b = bl + scene0;
-    if (b != cur_b || t != cur_t) {                          // wave-uniform: at most a few times per chunk
-      cur_b = b; cur_t = t;
+    if (sl != cur_sl) {                                     // wave-uniform: a few times per workgroup range
+      cur_sl = sl;
+      const int bl = (int)((unsigned)sl / (unsigned)nsl), b = bl + scene0;
+      t = sl - bl * nsl + t0;
       n_raw = n_points ? n_points[b] : n_stride;
       n_use = n_raw < P.dune_max_num ? n_raw : P.dune_max_num;
       skip = (flags && flags[b * 4 + 0]) || n_use <= 0;     // converged scene (pan.py:144-145) / no points
@@ -472,6 +467,7 @@ void dune_kernel(
         py_row = px_row + n_stride;
         vx_row = vel ? vel + (size_t)b * 2 * n_stride : nullptr;
         vy_row = vel ? vx_row + n_stride : nullptr;
+        key_row = gkeys + ((size_t)b * (T + 1) + t) * key_stride;
       }
     }
     if (skip || tile * 32 >= n_use) continue;
@@ -480,7 +476,7 @@ void dune_kernel(
     float mu[E], gx, gy, lx, ly, dist;
     point_features<E, SPLIT>(P, F, W, wbf, vec, w6, b6, px_row, py_row, vx_row, vy_row, src_index(nc, n_raw, n_use),
                              lane, mu, gx, gy, lx, ly, dist);
-    if (hf == 0 && n < n_use) gkeys[((size_t)b * (T + 1) + t) * key_stride + n] = ordered_key(dist);
+    if (hf == 0 && n < n_use) key_row[n] = ordered_key(dist);
   }
 }
 
@@ -582,26 +578,37 @@ extern "C" hipError_t npa_launch_encode(const DevParams& P, const float* wpack, 
   const int tps = tiles_per_slice(P, n_stride);
   if (tps * 32 > P.key_stride) return hipErrorInvalidValue;
   const long long tiles = (long long)batch * nsl * tps;
+  if (tiles >= (1ll << 31)) return hipErrorInvalidValue;
   // resident workgroups (4-wave form): blocks_per_cu per CU; the exact-fp32 variant needs 117 VGPRs
-  static const bool split = getenv("NPA_DUNE_FP32KEYS") == nullptr;   // default: bf16x3 split keys
+  static const bool split = getenv("NPA_DUNE_FP32KEYS") == nullptr;   // default: fp16x2 split keys
   if (!split && blocks_per_cu > 4) blocks_per_cu = 4;
   // one 16-wave workgroup per CU once every wave has a few tiles to stream; small launches keep
   // 4-wave workgroups (more CUs busy).  NPA_ENC_WAVES=4 forces the small form.
   static const bool small_only = getenv("NPA_ENC_WAVES") && atoi(getenv("NPA_ENC_WAVES")) == 4;
-  const int waves = (split && !small_only && tiles >= (long long)n_cu * 16 * 4) ? 16 : DUNE_WAVES;
-  const int slots = waves == 16 ? n_cu : n_cu * blocks_per_cu;
+  int waves = (split && !small_only && tiles >= (long long)n_cu * 16 * 4) ? 16 : DUNE_WAVES;
+#ifdef NPA_OCC_EXPERIMENT
+  static const int wexp = getenv("NPA_ENC_WAVES") ? atoi(getenv("NPA_ENC_WAVES")) : 0;
+  if (split && (wexp == 8 || wexp == 12)) waves = wexp;
+#endif
+  const int slots = waves >= 8 ? n_cu : n_cu * blocks_per_cu;
   int blocks = (int)((tiles + waves - 1) / waves);
   if (blocks > slots) blocks = slots;
   if (blocks < 1) blocks = 1;
   const size_t shmem = (11 * 32 + 8 * 32 + 8) * sizeof(float) + (split ? WP_KEY_LDS_FLOATS * sizeof(float) : 0);
   static const int chunk_env = getenv("NPA_ENC_CHUNK") ? atoi(getenv("NPA_ENC_CHUNK")) : 2;
   const int chunk = chunk_env < 1 ? 1 : chunk_env;
+#ifdef NPA_OCC_EXPERIMENT
+#define OCC_CASES(EE) else if (split && waves == 8) LAUNCH1(EE, true, 8); else if (split && waves == 12) LAUNCH1(EE, true, 12);
+#else
+#define OCC_CASES(EE)
+#endif
 #define LAUNCH1(EE, SP, WV)                                                                                         \
   hipLaunchKernelGGL((dune_kernel<EE, SP, WV>), dim3(blocks), dim3(64 * WV), shmem, stream, P, wpack, n_stride,     \
                      cur_s, points, vel, n_points, flags, gkeys, tps * 32, scene0, batch, t0, chunk)
 #define LAUNCH(EE)                                                                                                  \
   do {                                                                                                              \
     if (split && waves == 16) LAUNCH1(EE, true, 16);                                                                \
+    OCC_CASES(EE)                                                                                                   \
     else if (split) LAUNCH1(EE, true, DUNE_WAVES);                                                                  \
     else LAUNCH1(EE, false, DUNE_WAVES);                                                                            \
   } while (0)

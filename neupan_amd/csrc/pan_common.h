@@ -33,20 +33,23 @@ struct DevParams {
 #define WP_VEC (WP_WL + 4 * 16 * 64)              // [11][32]        per-feature vectors
 #define WP_W6 (WP_VEC + 11 * 32)                  // [8][32]         Linear(32,E) rows (zero padded)
 #define WP_B6 (WP_W6 + 8 * 32)                    // [8]
-// bf16x3 split of the four 32x32 layers for v_mfma_f32_32x32x16_bf16 (dune_kernel's distance
-// keys): w = w1 + w2 + w3, each term bf16 (RNE of the running residual).  A-operand layout of
-// that MFMA: lane l holds A[i = l&31][k = 8*(l>>5) + q], q = 0..7; K-step s (0,1) of a layer
-// contracts over the features feat(8s+q, hf).  [layer 4][term 3][step 2][lane 64][8 bf16]
+// ---- key path (dune_kernel's distance keys) ----------------------------------------------------
+// The four 32x32 layers as fp16x2 split products on v_mfma_f32_32x32x16_f16: w = w1 + w2, x = x1 + x2
+// with fp16 terms (RNE of the running residual: 22-23 significant bits), product terms (2,1) (1,2)
+// (1,1) accumulated in fp32.  Weights and activations carry exact power-of-two scales chosen on the
+// host (c_api.hip) so that every fp16 term stays in the normal range and cannot overflow; LayerNorm
+// absorbs the scale (its eps is scaled alike), ReLU passes it on.
+// A-operand layout: lane l holds A[i = l&31][k = 8*(l>>5) + q], q = 0..7; K-step s (0,1) of a layer
+// contracts over the features feat(8s+q, hf).   [layer 4][term 2][step 2][lane 64][8 fp16]
+// The keys only decide WHICH points are kept (the kept rows are re-encoded exactly), so the key path
+// may reassociate: the LayerNorm mean is removed through the weights,
+//   W_c = (I - 11'/32) W,  b_c = b - mean(b)     (Linear 1, 3, 5: the layers followed by LayerNorm).
 #define WP_BF (WP_B6 + 8)
-#define WP_BF_FLOATS (4 * 3 * 2 * 64 * 4)
-// key-path extras, contiguous behind the split fragments (staged into LDS together with them).
-// The distance keys only decide WHICH points are kept (the kept rows are re-encoded exactly), so the
-// key path may reassociate: the LayerNorm mean is removed through the weights,
-//   W_c = (I - 11'/32) W,  b_c = b - mean(b)     (Linear 1, 3, 5: the layers followed by LayerNorm)
-// -- the split fragments of layers 3 and 5 in WP_BF are those of W_c.
-#define WP_KVEC (WP_BF + WP_BF_FLOATS)            // [3][32]  centred biases of Linear 1, 3, 5
-#define WP_KW1 (WP_KVEC + 3 * 32)                 // [64]     centred Linear(2,32) A-fragment (read per lane)
-#define WP_KEY_LDS_FLOATS (WP_BF_FLOATS + 3 * 32)
+#define WP_BF_FLOATS (4 * 2 * 2 * 64 * 4)
+#define WP_KVEC (WP_BF + WP_BF_FLOATS)            // [5][32]  key-path biases of Linear 1..5 (centred / scaled)
+#define WP_KSC (WP_KVEC + 5 * 32)                 // [8]      LayerNorm eps x3 (scaled), tanh output scale x3
+#define WP_KW1 (WP_KSC + 8)                       // [64]     centred Linear(2,32) A-fragment (read per lane)
+#define WP_KEY_LDS_FLOATS (WP_BF_FLOATS + 5 * 32 + 8)
 #define WP_TOTAL (WP_KW1 + 64)
 // order of the per-feature vectors
 enum { V_B1 = 0, V_G1, V_BE1, V_B2, V_B3, V_G2, V_BE2, V_B4, V_B5, V_G3, V_BE3 };
