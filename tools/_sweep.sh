@@ -1,7 +1,15 @@
 cd /root/repo
-NPA_DUNE_FP32KEYS=1 python tools/key_check.py /tmp/exact.npz 256 2>&1 | tail -1
-python tools/key_check.py /tmp/split.npz 256 /tmp/exact.npz 2>&1 | tail -3
-NPA_DUNE_FP32KEYS=1 python tools/key_dump.py 256 /tmp/exact.npy 2>&1 | grep "differing" | head -1
-python tools/key_dump.py 256 /tmp/split.npy /tmp/exact.npy 2>&1 | grep "vs exact"
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -3
-for inf in 4 1; do python bench.py --no-cpu --inflight $inf | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('RES', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['launch_ms'], d['roofline']['nrmp_qp_launch_ms'])"; done
+R=/root/repo
+timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+python bench.py > gpurun_out/r01e_bench.json 2> gpurun_out/r01e_bench.err; tail -c 400 gpurun_out/r01e_bench.json; echo
+python bench.py --inflight 1 --no-cpu | tail -1 > gpurun_out/r01e_bench_inflight1.json
+python bench.py --workload acker_2k_T20_K15 --no-cpu | tail -1 > gpurun_out/r01e_bench_acker.json
+python bench.py --workload dyna_4k_T10_K10 --no-cpu | tail -1 > gpurun_out/r01e_bench_dyna.json
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_e -o e -- python $R/bench.py --no-cpu > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_e1 -o e1 -- python $R/bench.py --no-cpu --inflight 1 > /dev/null 2>&1
+cp $(find $R/gpurun_out/prof_e -name "*kernel_stats.csv" | head -1) $R/gpurun_out/r01e_kernel_stats.csv
+cp $(find $R/gpurun_out/prof_e1 -name "*kernel_stats.csv" | head -1) $R/gpurun_out/r01e_kernel_stats_inflight1.csv
+rm -rf $R/gpurun_out/prof_e $R/gpurun_out/prof_e1
+cd $R && python tools/hbm_traffic.py > /dev/null 2>&1; cp gpurun_out/traffic.json gpurun_out/r01e_traffic.json
+head -5 gpurun_out/r01e_kernel_stats.csv; head -5 gpurun_out/r01e_kernel_stats_inflight1.csv; cat gpurun_out/r01e_traffic.json

@@ -14,3 +14,11 @@ for K in (1, 2, 3, 5, 10):
     info = pan.last_qp_info()
     print("K=%2d last-QP iterations: mean %.2f max %d  status!=0: %d  merit max %.1e" %
           (K, info[:, 4].mean(), info[:, 4].max(), (info[:, 3] != 0).sum(), info[:, 1].max()))
+pan = make_gpu_pan(cfg, iter_num=10)
+pan.forward_batch(*args)
+info = pan.last_qp_info()
+it = info[:, 4].astype(int); best = info[:, 0].astype(int)
+print("iterations histogram:", np.bincount(it).tolist())
+print("best-iterate index histogram:", np.bincount(best).tolist())
+print("iters - best:", np.bincount(it - best).tolist())
+print("status:", np.bincount(info[:, 3].astype(int)).tolist(), " merit pct50/90/100:", np.percentile(info[:, 1], [50, 90, 100]))
