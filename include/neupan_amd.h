@@ -145,6 +145,22 @@ int npa_nrmp_stage(npa_handle *h, int batch, const float *nom_s, const float *no
                    const float *lam_sorted, const float *pts_sorted, const int32_t *count,
                    float *out_s, float *out_u, float *out_d, double *qp_info, void *stream);
 
+/* npa_nrmp_backward = npa_nrmp_stage + the gradient of a scalar loss L(opt_s, opt_u, opt_d) w.r.t. the
+ * adjust parameters.  Replaces what cvxpylayers provides in the reference (the adjust parameters are
+ * created with requires_grad=True, neupan/blocks/nrmp.py:79-95; the layer is differentiated at
+ * nrmp.py:144; example/LON/LON_corridor.py:94-127 trains p_u, eta, d_max through it): one extra
+ * solve with the Newton matrix of the converged interior-point iterate (implicit differentiation of
+ * the KKT system).  Covers the direct dependence of THIS solve on (q_s[3], p_u, eta, d_max, d_min),
+ * including their appearance in gamma_a = q_s*ref_s and gamma_b = p_u*ref_us (nrmp.py:158-160).
+ *   grad_s [B][3][T+1], grad_u [B][2][T], grad_d [B][T] (may be NULL): dL/d(opt_s, opt_u, opt_d);
+ *   grad_theta [B][8]: dL/d q_s[0..2], p_u, eta, d_max, d_min, and the solver status (0 = converged). */
+int npa_nrmp_backward(npa_handle *h, int batch, const float *nom_s, const float *nom_u,
+                      const float *ref_s, const float *ref_us, const float *mu_sorted,
+                      const float *lam_sorted, const float *pts_sorted, const int32_t *count,
+                      float *out_s, float *out_u, float *out_d, const float *grad_s,
+                      const float *grad_u, const float *grad_d, float *grad_theta,
+                      double *qp_info, void *stream);
+
 /* Timing hook for bench.py: enqueue HIP events around every DUNE-stage launch of
  * subsequent npa_forward_batch calls (on the launch stream) and read back the average
  * per-launch duration in ms.  enable=0 turns it off. */

@@ -98,7 +98,18 @@ __device__ __forceinline__ double fast_rsqrt(double x) {    // x > 0
 // columns) and the columns of Phi live in registers, one matrix row per lane, every loop over
 // the horizon is unrolled and all broadcasts are v_readlane (no LDS round trip on the serial
 // chain).  TT == 0: generic horizon, same algorithm with the matrices in LDS.
-template <int TT, int MM>
+// BWD: after convergence, one more solve with the Newton matrix of the final iterate and the upstream
+// gradient as right-hand side gives dL/d(q_s, p_u, eta, d_max, d_min) (oracle/nrmp_backward.py states
+// the derivation; reference: the adjust parameters are differentiable through cvxpylayers,
+// nrmp.py:79-95, :144).  Instantiated for the generic path only, so the forward kernels are untouched.
+struct QpBackward {
+  const float* grad_s;      // [B][3][T+1]  dL/d opt_s
+  const float* grad_u;      // [B][2][T]    dL/d opt_u
+  const float* grad_d;      // [B][T]       dL/d opt_d (may be null)
+  float* grad_theta;        // [B][8]       q_s[0..2], p_u, eta, d_max, d_min, (status)
+};
+
+template <int TT, int MM, bool BWD = false>
 __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
     DevParams P, const float* cur_s_in, const float* cur_u_in, const float* __restrict__ ref_s,
     const float* __restrict__ ref_us, const float* __restrict__ mu_sorted, const float* __restrict__ lam_sorted,
@@ -107,7 +118,7 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
     float* __restrict__ out_u, float* __restrict__ out_d, float* __restrict__ out_min_distance,
     int* __restrict__ out_iters, float* __restrict__ out_nrmp_points, int* __restrict__ flags,
     float* __restrict__ state, double* __restrict__ qp_info, double* __restrict__ warm, int scene0, int nscene,
-    int wave_doubles, int wpg) {
+    int wave_doubles, int wpg, QpBackward bw) {
   extern __shared__ __attribute__((aligned(16))) double sm_all[];
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -428,6 +439,7 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
     LSYNC();
   }
   PROF(0);
+  bool adj = false;                      // BWD: the pass below is the adjoint solve
   for (it = 0; it <= QP_MAX_IT; ++it) {
     // ================= residuals =================
     phi_mul(xu, s3);
@@ -513,7 +525,14 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
     } else {
       ++stall;
     }
-    if (merit <= 1e-12 || stall >= 3 || it == QP_MAX_IT || mu < 1e-15) break;
+    if (merit <= 1e-12 || stall >= 3 || it == QP_MAX_IT || mu < 1e-15) {
+      if constexpr (BWD) {
+        if (!bw.grad_theta) break;
+        adj = true;                      // factor K' of this final iterate once more, then solve K' v = dL/dx
+      } else {
+        break;
+      }
+    }
     PROF(1);
 
     // ================= reduced KKT matrix, Cholesky =================
@@ -650,22 +669,40 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
     if (!chol_ok) { status = 3; break; }
     PROF(4);
 
+    if constexpr (BWD) {
+      if (adj) {
+        // right-hand side: r1 := -dL/dx with dL/du collecting Phi' dL/ds (s_0 is pinned); every other
+        // residual is zero.  s - ref of the final iterate is parked in `lin` for the q_s gradient.
+        const float* gs = bw.grad_s + (size_t)b * 3 * (T + 1);
+        for (int q = lane; q < 3 * T; q += QP_THREADS) {
+          int t = q / 3, k = q - 3 * t;
+          double refv = (double)__fmul_rn(P.q_s[k], rs[k * (T + 1) + t + 1]) / (P.q_s[k] != 0.f ? (double)P.q_s[k] : 1.0);
+          lin[q] = (s3[q] + cv[q]) - refv;
+          q3[q] = (double)gs[k * (T + 1) + t + 1];
+        }
+        LSYNC();
+        r1u = phi_tmul(q3);
+        if (lane < nu) r1u = -(r1u + (double)bw.grad_u[(size_t)b * 2 * T + (lane & 1) * T + (lane >> 1)]);
+        r1dr = (lane < T && bw.grad_d) ? -(double)bw.grad_d[(size_t)b * T + lane] : 0.0;
+        LSYNC();
+      }
+    }
     // ================= predictor / corrector =================
     double sigma_mu = 0, alpha = 1.0;
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < (adj ? 1 : 2); ++pass) {
       // per-row weights of the rhs, staged in dwf/dwc/dwd (overwritten by the directions below)
       //   tfw = (r4f + lf r3)/(wf + lf/ro) ; tcw = (lc r2 - r4c)/wc ; r4 = lam w [+ dw dl - sigma mu]
       for (int i = lane; i < mf; i += QP_THREADS) {
         double r4 = lf[i] * wf[i] + (pass ? dwf[i] * dlf[i] - sigma_mu : 0.0);
-        dwf[i] = (r4 + lf[i] * r3[i]) * iwf[i];
+        dwf[i] = adj ? 0.0 : (r4 + lf[i] * r3[i]) * iwf[i];
       }
       for (int i = lane; i < mcu; i += QP_THREADS) {
         double r4 = lc[i] * wc[i] + (pass ? dwc[i] * dlc[i] - sigma_mu : 0.0);
-        dwc[i] = cact[i] ? (lc[i] * r2[i] - r4) * iwc[i] : 0.0;
+        dwc[i] = (cact[i] && !adj) ? (lc[i] * r2[i] - r4) * iwc[i] : 0.0;
       }
       for (int i = lane; i < 2 * T && obs; i += QP_THREADS) {
         double r4 = ld_[i] * wd[i] + (pass ? dwd[i] * dld[i] - sigma_mu : 0.0);
-        dwd[i] = (ld_[i] * r2d[i] - r4) * iwd[i];
+        dwd[i] = adj ? 0.0 : (ld_[i] * r2d[i] - r4) * iwd[i];
       }
       LSYNC();
       double pq0 = 0, pq1 = 0, rdr = 0;
@@ -761,6 +798,37 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
       }
       LSYNC();
       PROF(7);
+    }
+    if constexpr (BWD) {
+      if (adj) {
+        // v = (dxu, dxd), Phi v in s3, D C v of the d rows in dld:  dL/dtheta = -v' d(Hx+g)/dtheta, dL/dc = D C v
+        double g0 = 0, g1 = 0, g2 = 0, gp = 0, ge = 0, gmx = 0, gmn = 0;
+        for (int q = lane; q < 3 * T; q += QP_THREADS) {
+          int k = q % 3;
+          double v = s3[q] * lin[q];
+          g0 += k == 0 ? v : 0.0; g1 += k == 1 ? v : 0.0; g2 += k == 2 ? v : 0.0;
+        }
+        for (int t = lane; t < T; t += QP_THREADS) {
+          double refu = (double)__fmul_rn(P.p_u, rus[t]) / (P.p_u != 0.f ? (double)P.p_u : 1.0);
+          gp += dxu[2 * t] * (xu[2 * t] - refu);
+          if (obs) { ge += dxd[t]; gmx += dld[2 * t]; gmn += dld[2 * t + 1]; }
+        }
+        g0 = wave_reduce<OpSum>(g0); g1 = wave_reduce<OpSum>(g1); g2 = wave_reduce<OpSum>(g2);
+        gp = wave_reduce<OpSum>(gp); ge = wave_reduce<OpSum>(ge);
+        gmx = wave_reduce<OpSum>(gmx); gmn = wave_reduce<OpSum>(gmn);
+        if (lane == 0) {
+          float* gt = bw.grad_theta + (size_t)b * 8;
+          gt[0] = (float)(-4.0 * (double)P.q_s[0] * g0);
+          gt[1] = (float)(-4.0 * (double)P.q_s[1] * g1);
+          gt[2] = (float)(-4.0 * m2 * (double)P.q_s[2] * g2);
+          gt[3] = (float)(-4.0 * pu * gp);
+          gt[4] = (float)ge;
+          gt[5] = (float)gmx;
+          gt[6] = (P.d_min > 0.f) ? (float)(-gmn) : 0.f;
+          gt[7] = (float)status;
+        }
+        break;
+      }
     }
     for (int a = lane; a < nu; a += QP_THREADS) xu[a] += alpha * dxu[a];
     for (int t = lane; t < T && obs; t += QP_THREADS) xd[t] += alpha * dxd[t];
@@ -930,10 +998,31 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
   hipLaunchKernelGGL((nrmp_qp_kernel<TTV, MMV>), dim3(nblocks), dim3(QP_THREADS * wpg), shmem, stream, P, cur_s_in, cur_u_in, \
                      ref_s, ref_us, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count, cur_s_out, cur_u_out, \
                      cur_d_out, out_s, out_u, out_d, out_min_distance, out_iters, out_nrmp_points, flags, state, \
-                     qp_info, warm, scene0, batch, wave_doubles, wpg)
+                     qp_info, warm, scene0, batch, wave_doubles, wpg, QpBackward{nullptr, nullptr, nullptr, nullptr})
   if (P.T == 10 && P.M == 10 && !force_generic) QP_LAUNCH(10, 10);
   else if (P.T == 20 && P.M == 10 && !force_generic) QP_LAUNCH(20, 10);
   else QP_LAUNCH(0, 0);
 #undef QP_LAUNCH
+  return hipGetLastError();
+}
+
+// forward solve + gradient w.r.t. the adjust parameters (generic kernel, one scene per workgroup)
+extern "C" hipError_t npa_launch_qp_backward(const DevParams& P, int batch, const float* nom_s, const float* nom_u,
+                                             const float* ref_s, const float* ref_us, const float* mu_sorted,
+                                             const float* lam_sorted, const float* pts_sorted, const int* count,
+                                             float* out_s, float* out_u, float* out_d, const float* grad_s,
+                                             const float* grad_u, const float* grad_d, float* grad_theta,
+                                             double* qp_info, hipStream_t stream) {
+  const size_t wave_bytes = npa_qp_shmem_bytes(P.T, P.M);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((nrmp_qp_kernel<0, 0, true>), dim3(batch), dim3(QP_THREADS), wave_bytes, stream, P, nom_s, nom_u, ref_s,
+                     ref_us, mu_sorted, lam_sorted, pts_sorted, (const float*)nullptr, count, out_s, out_u, out_d,
+                     (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int*)nullptr, (float*)nullptr,
+                     (int*)nullptr, (float*)nullptr, qp_info, (double*)nullptr, 0, batch,
+                     (int)(wave_bytes / sizeof(double)), 1, QpBackward{grad_s, grad_u, grad_d, grad_theta});
   return hipGetLastError();
 }

@@ -316,6 +316,10 @@ class PAN(torch.nn.Module):
         """pan.py:109-147 for one scene: (3,T+1),(2,T),(3,T+1),(T,),(2,N)|None,(2,N)|None ->
         (opt_s (3,T+1), opt_u (2,T), opt_d (1,T)|None)."""
         un = lambda t: None if t is None else (t if isinstance(t, torch.Tensor) else torch.as_tensor(np.asarray(t))).unsqueeze(0)
+        if any(p.requires_grad for p in self.nrmp_layer.adjust_parameters):
+            # LON use (example/LON/LON_corridor.py): outputs stay connected to the adjust parameters
+            s, u, d = self.forward_batch_grad(un(nom_s), un(nom_u), un(ref_s), un(ref_us), un(obs_points), un(point_velocities))
+            return s[0], u[0], (None if self.no_obs else d[0])
         out = self.forward_batch(un(nom_s), un(nom_u), un(ref_s), un(ref_us), un(obs_points), un(point_velocities))
         d = None if self.no_obs or out["opt_d"] is None else out["opt_d"][0]
         return out["opt_s"][0], out["opt_u"][0], d
@@ -391,6 +395,42 @@ class PAN(torch.nn.Module):
         torch.cuda.synchronize(dev)
         return dict(opt_s=out_s, opt_u=out_u, opt_d=out_d, info=info)
 
+    def nrmp_backward(self, nom_s, nom_u, ref_s, ref_us, stage, grad_s, grad_u, grad_d=None):
+        """One NRMP solve plus dL/d(q_s[3], p_u, eta, d_max, d_min) per scene for upstream gradients
+        (grad_s (B,3,T+1), grad_u (B,2,T), grad_d (B,1,T)|None).  Returns dict(opt_s, opt_u, opt_d,
+        grad (B,8): q_s[0..2], p_u, eta, d_max, d_min, solver status)."""
+        T = self.T
+        nom_s = self._dev(nom_s)
+        B = nom_s.shape[0]
+        nom_u, ref_s, ref_us = self._dev(nom_u, (B, 2, T)), self._dev(ref_s, (B, 3, T + 1)), self._dev(ref_us, (B, T))
+        gs, gu = self._dev(grad_s, (B, 3, T + 1)), self._dev(grad_u, (B, 2, T))
+        gd = None if grad_d is None else self._dev(grad_d).reshape(B, T).contiguous()
+        dev = self.device
+        out_s = torch.empty((B, 3, T + 1), dtype=torch.float32, device=dev)
+        out_u = torch.empty((B, 2, T), dtype=torch.float32, device=dev)
+        out_d = torch.empty((B, 1, T), dtype=torch.float32, device=dev)
+        gth = torch.zeros((B, 8), dtype=torch.float32, device=dev)
+        g = (lambda k: _ptr(stage[k])) if stage is not None else (lambda k: None)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            check(self._lib.npa_nrmp_backward(self._h, B, _ptr(nom_s), _ptr(nom_u), _ptr(ref_s), _ptr(ref_us), g("mu"),
+                                              g("lam"), g("pts"), g("count"), _ptr(out_s), _ptr(out_u), _ptr(out_d),
+                                              _ptr(gs), _ptr(gu), _ptr(gd), _ptr(gth), None, C.c_void_p(stream)),
+                  "npa_nrmp_backward")
+        return dict(opt_s=out_s, opt_u=out_u, opt_d=out_d, grad=gth)
+
+    def forward_batch_grad(self, nom_s, nom_u, ref_s, ref_us, points=None, velocities=None, n_points=None):
+        """`forward_batch` whose outputs are connected to `nrmp_layer.adjust_parameters` for autograd, as the
+        reference's are through cvxpylayers (nrmp.py:79-95, :144; example/LON/LON_corridor.py:94-127):
+        `loss(opt_s, opt_u, opt_d).backward()` fills `.grad` of q_s, p_u, eta, d_max, d_min (make them
+        `requires_grad_(True)` leaves first).  The gradient is that of the LAST NRMP solve of the PAN loop
+        (implicit differentiation of its KKT system, npa_nrmp_backward); the reference's recurrent terms
+        through the proximal centre nom_s and lam(R(nom_s)) of earlier iterations are not propagated.
+        Returns (opt_s (B,3,T+1), opt_u (B,2,T), opt_d (B,1,T)|None)."""
+        f = self.nrmp_layer
+        params = [f.q_s, f.p_u, f.eta, f.d_max, f.d_min]
+        return _PanGrad.apply(self, (nom_s, nom_u, ref_s, ref_us, points, velocities, n_points), *params)
+
     def last_qp_info(self):
         """(B,16) float64: per-scene diagnostics of the last QP solved by forward_batch
         (best iteration, merit, mu, status, iterations run)."""
@@ -405,6 +445,47 @@ class PAN(torch.nn.Module):
         a, b, n = C.c_double(), C.c_double(), C.c_int64()
         check(self._lib.npa_profile_read(self._h, C.byref(a), C.byref(b), C.byref(n)), "npa_profile_read")
         return dict(dune_ms=a.value, nrmp_ms=b.value, launches=n.value)
+
+
+class _PanGrad(torch.autograd.Function):
+    """PAN loop forward on the HIP path; backward = npa_nrmp_backward on a re-run of the last iteration."""
+
+    @staticmethod
+    def forward(ctx, pan, args, q_s, p_u, eta, d_max, d_min):
+        nom_s, nom_u, ref_s, ref_us, points, velocities, n_points = args
+        pan._push_adjust()
+        pan.forward_begin(nom_s, nom_u, ref_s, ref_us, points, velocities, n_points)
+        B, T = pan._B, pan.T
+        for k in range(pan.iter_num - 1):
+            pan.forward_iter(k)
+        # nominal trajectory the last solve linearises around (cur_s, cur_u at the head of the workspace)
+        wsf = pan._ws.view(torch.float32)
+        n_s = B * 3 * (T + 1)
+        off_u = (n_s + 3) // 4 * 4
+        snap_s = wsf[:n_s].clone().reshape(B, 3, T + 1)
+        snap_u = wsf[off_u:off_u + B * 2 * T].clone().reshape(B, 2, T)
+        pan.forward_iter(pan.iter_num - 1)
+        out = pan.forward_end()
+        ctx.pan = pan
+        ctx.args = (snap_s, snap_u, pan._dev(ref_s), pan._dev(ref_us), points, velocities, n_points)
+        ctx.qs_shape = tuple(q_s.shape)
+        ctx.no_obs = out["opt_d"] is None
+        d = out["opt_d"] if out["opt_d"] is not None else torch.zeros((B, 1, T), device=pan.device)
+        return out["opt_s"], out["opt_u"], d
+
+    @staticmethod
+    def backward(ctx, gs, gu, gd):
+        pan = ctx.pan
+        snap_s, snap_u, ref_s, ref_us, points, velocities, n_points = ctx.args
+        stage = None
+        if not pan.no_obs and points is not None:
+            stage = pan.dune_stage(snap_s, points, velocities, n_points)
+        z = lambda g, ref: torch.zeros_like(ref) if g is None else g
+        r = pan.nrmp_backward(snap_s, snap_u, ref_s, ref_us, stage, z(gs, snap_s), z(gu, snap_u),
+                              None if (gd is None or ctx.no_obs) else gd)
+        g = r["grad"].double().sum(dim=0).float().cpu()
+        gq = g[0:3].reshape(3, 1) if len(ctx.qs_shape) == 2 else g[0:3].sum().reshape(ctx.qs_shape)
+        return None, None, gq, g[3].reshape(()), g[4].reshape(()), g[5].reshape(()), g[6].reshape(())
 
 
 def forward_interleaved(planners, inputs):

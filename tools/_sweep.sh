@@ -1,15 +1,2 @@
 cd /root/repo
-R=/root/repo
-timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-python bench.py > gpurun_out/r01e_bench.json 2> gpurun_out/r01e_bench.err; tail -c 400 gpurun_out/r01e_bench.json; echo
-python bench.py --inflight 1 --no-cpu | tail -1 > gpurun_out/r01e_bench_inflight1.json
-python bench.py --workload acker_2k_T20_K15 --no-cpu | tail -1 > gpurun_out/r01e_bench_acker.json
-python bench.py --workload dyna_4k_T10_K10 --no-cpu | tail -1 > gpurun_out/r01e_bench_dyna.json
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_e -o e -- python $R/bench.py --no-cpu > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_e1 -o e1 -- python $R/bench.py --no-cpu --inflight 1 > /dev/null 2>&1
-cp $(find $R/gpurun_out/prof_e -name "*kernel_stats.csv" | head -1) $R/gpurun_out/r01e_kernel_stats.csv
-cp $(find $R/gpurun_out/prof_e1 -name "*kernel_stats.csv" | head -1) $R/gpurun_out/r01e_kernel_stats_inflight1.csv
-rm -rf $R/gpurun_out/prof_e $R/gpurun_out/prof_e1
-cd $R && python tools/hbm_traffic.py > /dev/null 2>&1; cp gpurun_out/traffic.json gpurun_out/r01e_traffic.json
-head -5 gpurun_out/r01e_kernel_stats.csv; head -5 gpurun_out/r01e_kernel_stats_inflight1.csv; cat gpurun_out/r01e_traffic.json
+timeout 600 python -m pytest tests/test_nrmp_backward.py -x -q -m gpu 2>&1 | tail -25
