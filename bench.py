@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-scenes", type=int, default=24, help="scenes timed through the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--schedule", choices=["pipeline", "groups"], default="groups",
+                    help="groups: lockstep groups of forward calls (forward_interleaved, default); pipeline: staggered forward "
+                         "calls (PanPipeline) -- measured slower with more than 3 batches in flight")
     ap.add_argument("--inflight", type=int, default=5, help="independent batches (steps) kept in flight")
     ap.add_argument("--workload", default=WORKLOAD, choices=sorted(k for k in __import__("neupan_amd.scenes", fromlist=["CONFIGS"]).CONFIGS),
                     help="scene configuration (default: the one BASELINE.json's metric is quoted on)")
@@ -94,7 +97,7 @@ def main():
     from gpu_helpers import make_gpu_pan
     from helpers import CONFIGS
     from neupan_amd.dist import gather_controls
-    from neupan_amd.pan import forward_interleaved
+    from neupan_amd.pan import PanPipeline, forward_interleaved
     from neupan_amd.scenes import make_batch
 
     cfg = CONFIGS[args.workload]
@@ -108,17 +111,25 @@ def main():
         args_dev.append([torch.from_numpy(batch[k]).to(dev) for k in ("nom_s", "nom_u", "ref_s", "ref_us", "points")])
     torch.cuda.synchronize(dev)
 
+    pipe = PanPipeline(pans)
+
     def run_steps(n):
         """n steps (= n batches of 256 scenes), `nfl` of them in flight at a time."""
         out0 = gathered = None
+        if args.schedule == "pipeline":
+            # continuous: the planners' forward calls are staggered, the DUNE stream never drains
+            outs = pipe.run([args_dev[i % nfl] for i in range(n)], reset_state=True)
+            for o in outs:
+                gathered = gather_controls(o["opt_u"], dist, world, equal_shards=True)   # RCCL all-gather when world > 1
+            return outs[0], gathered
         done = 0
-        while done < n:
+        while done < n:                      # groups of forward calls in lockstep
             g = min(nfl, n - done)
             for p in pans[:g]:
                 p.reset_stop_state()
             outs = forward_interleaved(pans[:g], args_dev[:g])
             for o in outs:
-                gathered = gather_controls(o["opt_u"], dist, world, equal_shards=True)   # RCCL all-gather when world > 1
+                gathered = gather_controls(o["opt_u"], dist, world, equal_shards=True)
             out0 = outs[0]
             done += g
         return out0, gathered

@@ -118,7 +118,16 @@ int npa_forward_batch(npa_handle *h, int batch, int n_stride,
  * each) on ONE stream: the DUNE launches of all batches stay ordered on `stream`, each batch's QP
  * chain runs on that handle's helper stream (qp_on_helper_stream != 0) and overlaps the other
  * batches' DUNE launches.  Same arguments as npa_forward_batch; buffers must stay valid until
- * the work enqueued by npa_forward_end has completed. */
+ * the work enqueued by npa_forward_end has completed.
+ * `qp_on_helper_stream` is a flag word: NPA_FWD_HELPER (1) as above; with it the staging copies
+ * also go to the helper stream (behind the previous forward's last QP on this handle), so a new
+ * forward can be begun before the previous one was joined.  NPA_FWD_RESET_STATE (2): zero the stop
+ * criterion's state buffer first (a fresh planner).
+ * npa_forward_end joins on `stream`; npa_forward_end_on(h, join_stream) makes `join_stream` wait for
+ * the results instead (NULL: no join -- the caller synchronises some other way), which keeps
+ * `stream` free for the other batches' DUNE launches. */
+#define NPA_FWD_HELPER 1
+#define NPA_FWD_RESET_STATE 2
 int npa_forward_begin(npa_handle *h, int batch, int n_stride,
                       const float *nom_s, const float *nom_u, const float *ref_s, const float *ref_us,
                       const float *points, const float *velocities, const int32_t *n_points,
@@ -128,6 +137,7 @@ int npa_forward_begin(npa_handle *h, int batch, int n_stride,
                       void *stream, int qp_on_helper_stream);
 int npa_forward_iter(npa_handle *h, int k);
 int npa_forward_end(npa_handle *h);
+int npa_forward_end_on(npa_handle *h, void *join_stream);
 
 /* Stage entry points (used by the parity tests and for profiling one stage alone).
  * npa_dune_stage  = generate_point_flow + DUNE.forward + the top-M gather:

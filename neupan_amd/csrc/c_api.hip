@@ -14,7 +14,7 @@
 extern "C" hipError_t npa_launch_encode(const DevParams& P, const float* wpack, int batch, int scene0, int t0,
                                         int n_stride, const float* cur_s, const float* points, const float* vel,
                                         const int* n_points, const int* flags, unsigned* gkeys, int n_cu,
-                                        int blocks_per_cu, hipStream_t stream);
+                                        int blocks_per_cu, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);
 extern "C" hipError_t npa_launch_select(const DevParams& P, const float* wpack, int batch, int scene0, int t0,
                                         int n_stride, const float* cur_s, const float* points, const float* vel,
                                         const int* n_points, const int* flags, const unsigned* gkeys,
@@ -330,7 +330,7 @@ extern "C" int npa_dune_stage(npa_handle* h, int batch, int n_stride, const floa
     h->stage_cand_bytes = need;
   }
   HIP_TRY(npa_launch_encode(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr,
-                            (unsigned*)h->stage_cand, h->n_cu, h->enc_blocks, (hipStream_t)stream));
+                            (unsigned*)h->stage_cand, h->n_cu, h->enc_blocks, (hipStream_t)stream, nullptr, nullptr));
   HIP_TRY(npa_launch_select(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr,
                             (const unsigned*)h->stage_cand, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count,
                             (hipStream_t)stream));
@@ -371,6 +371,23 @@ extern "C" int npa_nrmp_backward(npa_handle* h, int batch, const float* nom_s, c
   return NPA_OK;
 }
 
+// staging of one forward call: working copy of the nominal trajectory, cleared flags / counts / state
+__global__ void stage_kernel(float* __restrict__ cur_s, const float* __restrict__ nom_s, size_t ns,
+                             float* __restrict__ cur_u, const float* __restrict__ nom_u, size_t nu,
+                             int* __restrict__ flags, size_t nflag, int* __restrict__ count, size_t ncount,
+                             int* __restrict__ state, size_t nstate) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;; i += stride) {
+    bool any = false;
+    if (i < ns) { cur_s[i] = nom_s[i]; any = true; }
+    if (i < nu) { cur_u[i] = nom_u[i]; any = true; }
+    if (i < nflag) { flags[i] = 0; any = true; }
+    if (i < ncount) { count[i] = 0; any = true; }
+    if (i < nstate) { state[i] = 0; any = true; }
+    if (!any) break;
+  }
+}
+
 // ---- forward = begin + K x iter + end ------------------------------------------------------------
 // The split exists so that a host can interleave the PAN iterations of several independent
 // batches (one handle each) on ONE stream: DUNE launches of all batches stay ordered there, each
@@ -386,7 +403,7 @@ struct PendingCall {
   float* ws = nullptr;
   float* state = nullptr;
   hipStream_t stream = nullptr;
-  bool dune = false, qp_aux = false;
+  bool dune = false, qp_aux = false, staged_on_aux = false;
 };
 static std::mutex g_pending_mu;
 static std::vector<std::pair<npa_handle*, PendingCall>> g_pending;
@@ -417,12 +434,10 @@ extern "C" int npa_forward_begin(npa_handle* h, int batch, int n_stride, const f
   if (pc->active) return fail(NPA_E_ARG, "npa_forward_begin: previous forward on this handle not ended");
   hipStream_t stream = (hipStream_t)stream_;
   const int T = P.T;
+  const bool helper = (qp_on_helper_stream & NPA_FWD_HELPER) != 0;
+  const bool reset_state = (qp_on_helper_stream & NPA_FWD_RESET_STATE) != 0;
   const ScratchLayout L = npa_scratch_layout(batch, T, mdim(P), P.E, P.key_stride);
   float* ws = (float*)workspace;
-  HIP_TRY(hipMemcpyAsync(ws + L.cur_s, nom_s, (size_t)batch * 3 * (T + 1) * sizeof(float), hipMemcpyDeviceToDevice, stream));
-  HIP_TRY(hipMemcpyAsync(ws + L.cur_u, nom_u, (size_t)batch * 2 * T * sizeof(float), hipMemcpyDeviceToDevice, stream));
-  HIP_TRY(hipMemsetAsync(ws + L.flags, 0, (size_t)batch * 4 * sizeof(int), stream));
-  HIP_TRY(hipMemsetAsync(ws + L.count, 0, (size_t)batch * (T + 1) * sizeof(int), stream));
   pc->batch = batch; pc->n_stride = n_stride; pc->ref_s = ref_s; pc->ref_us = ref_us; pc->points = points;
   pc->velocities = velocities; pc->n_points = n_points; pc->out_s = out_s; pc->out_u = out_u; pc->out_d = out_d;
   pc->out_md = out_min_distance; pc->out_iters = out_iters; pc->out_np = out_nrmp_points; pc->ws = ws;
@@ -430,15 +445,38 @@ extern "C" int npa_forward_begin(npa_handle* h, int batch, int n_stride, const f
   pc->dune = P.M > 0 && points != nullptr;
   // sub-batches [lo_i, hi_i): DUNE(i,k) on `stream` in (k, i) order, QP(i,k) on aux[i]
   // (when the caller interleaves several batches the batches themselves are the pipeline stages)
-  pc->nsub = (h->n_sub > 1 && pc->dune && batch >= 16 * h->n_sub && !qp_on_helper_stream) ? h->n_sub : 1;
-  pc->qp_aux = pc->dune && (pc->nsub > 1 || (qp_on_helper_stream && h->aux[0]));
-  const size_t need_ev = (size_t)2 * pc->nsub * P.K + 1;
+  pc->nsub = (h->n_sub > 1 && pc->dune && batch >= 16 * h->n_sub && !helper) ? h->n_sub : 1;
+  pc->qp_aux = pc->dune && (pc->nsub > 1 || (helper && h->aux[0]));
+  const size_t need_ev = (size_t)2 * pc->nsub * P.K + 2;
   while (h->sync_ev.size() < need_ev) {
     hipEvent_t ev;
     HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     h->sync_ev.push_back(ev);
   }
-  if (pc->qp_aux) {
+  // staging.  With a helper stream it goes THERE: behind the last QP of the previous forward on this
+  // handle (which still owns the scratch), so the caller need not have joined that forward on `stream`.
+  pc->staged_on_aux = pc->qp_aux && pc->nsub == 1 && helper;
+  hipStream_t st = pc->staged_on_aux ? h->aux[0] : stream;
+  if (pc->staged_on_aux) {
+    HIP_TRY(hipEventRecord(h->sync_ev[1], stream));                 // the caller's inputs are ready
+    HIP_TRY(hipStreamWaitEvent(st, h->sync_ev[1], 0));
+  }
+  {
+    // one launch instead of two copies and up to three memsets (each costs tens of microseconds
+    // of stream time between the forward calls)
+    const size_t ns = (size_t)batch * 3 * (T + 1), nu2 = (size_t)batch * 2 * T;
+    const size_t nflag = (size_t)batch * 4, ncount = (size_t)batch * (T + 1);
+    const size_t nstate = reset_state ? npa_state_bytes(h, batch) / 4 : 0;
+    const size_t work = std::max(std::max(ns, nu2), std::max(std::max(nflag, ncount), nstate));
+    const int threads = 256;
+    const int blocks = (int)std::min<size_t>((work + threads - 1) / threads, 512);
+    hipLaunchKernelGGL(stage_kernel, dim3(blocks), dim3(threads), 0, st, ws + L.cur_s, nom_s, ns, ws + L.cur_u, nom_u, nu2,
+                       (int*)(ws + L.flags), nflag, (int*)(ws + L.count), ncount, (int*)state, nstate);
+    HIP_TRY(hipGetLastError());
+  }
+  if (pc->staged_on_aux) {
+    HIP_TRY(hipEventRecord(h->sync_ev[0], st));                     // staged: the first DUNE launch waits for it
+  } else if (pc->qp_aux) {
     HIP_TRY(hipEventRecord(h->sync_ev[0], stream));                 // inputs staged
     for (int i = 0; i < pc->nsub; ++i) HIP_TRY(hipStreamWaitEvent(h->aux[i], h->sync_ev[0], 0));
   }
@@ -465,23 +503,22 @@ extern "C" int npa_forward_iter(npa_handle* h, int k) {
   unsigned* gkeys = (unsigned*)(ws + L.keys);
   hipStream_t stream = pc->stream;
   auto lo = [&](int i) { return (int)((long long)batch * i / nsub); };
-  auto ev_d = [&](int i, int kk) { return h->sync_ev[1 + (size_t)2 * (kk * nsub + i)]; };
-  auto ev_q = [&](int i, int kk) { return h->sync_ev[1 + (size_t)2 * (kk * nsub + i) + 1]; };
+  auto ev_d = [&](int i, int kk) { return h->sync_ev[2 + (size_t)2 * (kk * nsub + i)]; };
+  auto ev_q = [&](int i, int kk) { return h->sync_ev[2 + (size_t)2 * (kk * nsub + i) + 1]; };
   for (int i = 0; i < nsub; ++i) {
     const int s0 = lo(i), nb = lo(i + 1) - lo(i);
     hipStream_t qs = pc->qp_aux ? h->aux[i] : stream;
     if (pc->dune) {
       if (pc->qp_aux && k > 0) HIP_TRY(hipStreamWaitEvent(stream, ev_q(i, k - 1), 0));
+      if (pc->staged_on_aux && k == 0) HIP_TRY(hipStreamWaitEvent(stream, h->sync_ev[0], 0));
       EventPair* ev = next_event(h, h->ev_dune, h->n_dune);
-      if (ev) HIP_TRY(hipEventRecord(ev->a, stream));
       const int t0 = k == 0 ? 0 : 1;
+      // the events ride on the dispatch (no marker packets between back-to-back encode launches): the
+      // completion event is the profiling stop event when profiling, else the hand-over event
+      hipEvent_t done = ev ? ev->b : (pc->qp_aux ? ev_d(i, k) : nullptr);
       HIP_TRY(npa_launch_encode(P, h->wpack, nb, s0, t0, pc->n_stride, cur_s, pc->points, pc->velocities,
-                                pc->n_points, flags, gkeys, h->n_cu, h->enc_blocks, stream));
-      if (ev) HIP_TRY(hipEventRecord(ev->b, stream));
-      if (pc->qp_aux) {
-        HIP_TRY(hipEventRecord(ev_d(i, k), stream));
-        HIP_TRY(hipStreamWaitEvent(qs, ev_d(i, k), 0));
-      }
+                                pc->n_points, flags, gkeys, h->n_cu, h->enc_blocks, stream, ev ? ev->a : nullptr, done));
+      if (pc->qp_aux) HIP_TRY(hipStreamWaitEvent(qs, done, 0));
       // selection + QP follow the encode on the helper stream (when there is one): the next
       // encode launch on `stream` -- another sub-batch or another batch in flight -- overlaps them
       HIP_TRY(npa_launch_select(P, h->wpack, nb, s0, t0, pc->n_stride, cur_s, pc->points, pc->velocities,
@@ -498,17 +535,31 @@ extern "C" int npa_forward_iter(npa_handle* h, int k) {
   return NPA_OK;
 }
 
-extern "C" int npa_forward_end(npa_handle* h) {
+static int forward_end_impl(npa_handle* h, bool join, hipStream_t join_stream) {
   if (!h) return fail(NPA_E_ARG, "npa_forward_end: null handle");
   std::lock_guard<std::mutex> lock(g_pending_mu);
   PendingCall* pc = pending_of(h, false);
   if (!pc || !pc->active) return fail(NPA_E_ARG, "npa_forward_end: no forward in progress on this handle");
   const int nsub = pc->nsub, K = h->P.K;
-  if (pc->qp_aux)                                                       // join the helper streams
+  if (pc->qp_aux && join)                                               // join the helper streams
     for (int i = 0; i < nsub; ++i)
-      HIP_TRY(hipStreamWaitEvent(pc->stream, h->sync_ev[1 + (size_t)2 * ((K - 1) * nsub + i) + 1], 0));
+      HIP_TRY(hipStreamWaitEvent(join_stream, h->sync_ev[2 + (size_t)2 * ((K - 1) * nsub + i) + 1], 0));
   pc->active = false;
   return NPA_OK;
+}
+
+extern "C" int npa_forward_end(npa_handle* h) {
+  hipStream_t s = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_pending_mu);
+    PendingCall* pc = h ? pending_of(h, false) : nullptr;
+    if (pc) s = pc->stream;
+  }
+  return forward_end_impl(h, true, s);
+}
+
+extern "C" int npa_forward_end_on(npa_handle* h, void* join_stream) {
+  return forward_end_impl(h, join_stream != nullptr, (hipStream_t)join_stream);
 }
 
 extern "C" int npa_forward_batch(npa_handle* h, int batch, int n_stride, const float* nom_s, const float* nom_u,

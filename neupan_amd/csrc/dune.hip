@@ -32,6 +32,7 @@
 //     SQ_VALU_MFMA_COEXEC_CYCLES = 0), so the VALU instruction count per tile matters as much as
 //     the 65 MFMAs.
 #include "pan_common.h"
+#include <hip/hip_ext.h>
 #include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -573,7 +574,9 @@ static int tiles_per_slice(const DevParams& P, int n_stride) {
 extern "C" hipError_t npa_launch_encode(const DevParams& P, const float* wpack, int batch, int scene0, int t0,
                                         int n_stride, const float* cur_s, const float* points, const float* vel,
                                         const int* n_points, const int* flags, unsigned* gkeys, int n_cu,
-                                        int blocks_per_cu, hipStream_t stream) {
+                                        int blocks_per_cu, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  // ev_start / ev_stop (may be null) are attached to the dispatch itself (hipExtLaunchKernelGGL): no
+  // separate marker packets on the stream, which cost ~5 us each between back-to-back launches
   const int nsl = P.T + 1 - t0;
   const int tps = tiles_per_slice(P, n_stride);
   if (tps * 32 > P.key_stride) return hipErrorInvalidValue;
@@ -603,8 +606,9 @@ extern "C" hipError_t npa_launch_encode(const DevParams& P, const float* wpack, 
 #define OCC_CASES(EE)
 #endif
 #define LAUNCH1(EE, SP, WV)                                                                                         \
-  hipLaunchKernelGGL((dune_kernel<EE, SP, WV>), dim3(blocks), dim3(64 * WV), shmem, stream, P, wpack, n_stride,     \
-                     cur_s, points, vel, n_points, flags, gkeys, tps * 32, scene0, batch, t0, chunk)
+  hipExtLaunchKernelGGL((dune_kernel<EE, SP, WV>), dim3(blocks), dim3(64 * WV), shmem, stream, ev_start, ev_stop, 0, \
+                        P, wpack, n_stride, cur_s, points, vel, n_points, flags, gkeys, tps * 32, scene0, batch, t0, \
+                        chunk)
 #define LAUNCH(EE)                                                                                                  \
   do {                                                                                                              \
     if (split && waves == 16) LAUNCH1(EE, true, 16);                                                                \

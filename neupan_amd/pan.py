@@ -243,7 +243,7 @@ class PAN(torch.nn.Module):
 
     # ------------------------------------------------------------------ batched entry
     def forward_begin(self, nom_s, nom_u, ref_s, ref_us, points=None, velocities=None, n_points=None,
-                      qp_on_helper_stream=False):
+                      qp_on_helper_stream=False, reset_state=False):
         """Stage one batch (see forward_batch for shapes) and start a forward: follow with
         forward_iter(k) for k in range(iter_num) and forward_end().  With qp_on_helper_stream the QP
         chain of this batch runs on the handle's helper stream so that another planner's DUNE
@@ -286,7 +286,7 @@ class PAN(torch.nn.Module):
                 self._h, B, max(n_stride, 1), _ptr(nom_s), _ptr(nom_u), _ptr(ref_s), _ptr(ref_us), _ptr(points),
                 _ptr(velocities), _ptr(n_points), _ptr(out_s), _ptr(out_u), _ptr(out_d), _ptr(out_md), _ptr(out_it),
                 _ptr(out_np), _ptr(ws), ws.numel(), _ptr(state), state.numel(), C.c_void_p(stream),
-                1 if qp_on_helper_stream else 0), "npa_forward_begin")
+                (1 if qp_on_helper_stream else 0) | (2 if reset_state else 0)), "npa_forward_begin")
         # keep inputs alive until the stream has consumed them
         self._last = dict(points=points, velocities=velocities, n_points=n_points, min_distance=out_md,
                           nrmp_points=out_np, used_points=use_pts, hold=(nom_s, nom_u, ref_s, ref_us))
@@ -296,9 +296,14 @@ class PAN(torch.nn.Module):
         """Enqueue PAN iteration k (DUNE launch + QP launch) of the forward started by forward_begin."""
         check(self._lib.npa_forward_iter(self._h, int(k)), "npa_forward_iter")
 
-    def forward_end(self):
-        """Join the helper streams; returns the output dict (device tensors, valid in stream order)."""
-        check(self._lib.npa_forward_end(self._h), "npa_forward_end")
+    def forward_end(self, join_stream=None):
+        """Join the helper streams; returns the output dict (device tensors, valid in stream order).
+        join_stream: a torch.cuda.Stream that waits for the results INSTEAD of the stream the forward
+        was begun on (PanPipeline: that stream stays free for the other batches' DUNE launches)."""
+        if join_stream is None:
+            check(self._lib.npa_forward_end(self._h), "npa_forward_end")
+        else:
+            check(self._lib.npa_forward_end_on(self._h, C.c_void_p(join_stream.cuda_stream)), "npa_forward_end_on")
         out, self._pending = self._pending, None
         return out
 
@@ -488,18 +493,109 @@ class _PanGrad(torch.autograd.Function):
         return None, None, gq, g[3].reshape(()), g[4].reshape(()), g[5].reshape(()), g[6].reshape(())
 
 
-def forward_interleaved(planners, inputs):
+_STREAMS = {}
+
+
+def forward_interleaved(planners, inputs, mode=None):
     """Plan several independent batches concurrently: `planners[i]` (one PAN per batch in flight,
-    same configuration) plans `inputs[i]` (the positional arguments of forward_batch).  The PAN
-    iterations are enqueued round-robin on the current stream, so the DUNE launches of all batches
-    stay ordered there while each batch's latency-bound QP runs on its planner's helper stream
-    underneath the other batches' DUNE launches.  Returns the list of output dicts."""
+    same configuration) plans `inputs[i]` (the positional arguments of forward_batch).
+    mode "events" (default): the DUNE launches of all batches are enqueued round-robin on the current
+      stream and each batch's select+QP on its planner's helper stream (one event per hand-over), so
+      DUNE launches never run beside each other.
+    mode "streams": every planner's whole chain (DUNE -> select -> QP, K times) goes to a stream of its
+      own and the hardware queues interleave the chains -- measured slower (94-113 k vs 122 k plans/s):
+      concurrent DUNE launches split the CUs and stretch each other.
+    Returns the list of output dicts (valid on the current stream)."""
+    import os
     assert len(planners) == len(inputs) and len(planners) >= 1
+    mode = mode or os.environ.get("NPA_INTERLEAVE", "events")
     K = planners[0].iter_num
-    for p, a in zip(planners, inputs):
+    for p in planners:
         assert p.iter_num == K
-        p.forward_begin(*a, qp_on_helper_stream=len(planners) > 1)
+    if mode == "events" or len(planners) == 1:
+        for p, a in zip(planners, inputs):
+            p.forward_begin(*a, qp_on_helper_stream=len(planners) > 1)
+        for k in range(K):
+            for p in planners:
+                p.forward_iter(k)
+        return [p.forward_end() for p in planners]
+    dev = planners[0].device
+    cur = torch.cuda.current_stream(dev)
+    key = (dev.index, len(planners))
+    if key not in _STREAMS:
+        _STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in planners]
+    streams = _STREAMS[key]
+    for st, p, a in zip(streams, planners, inputs):
+        st.wait_stream(cur)                      # inputs were produced on the current stream
+        with torch.cuda.stream(st):
+            p.forward_begin(*a, qp_on_helper_stream=False)
     for k in range(K):
-        for p in planners:
-            p.forward_iter(k)
-    return [p.forward_end() for p in planners]
+        for st, p in zip(streams, planners):
+            with torch.cuda.stream(st):
+                p.forward_iter(k)
+    outs = []
+    for st, p in zip(streams, planners):
+        with torch.cuda.stream(st):
+            outs.append(p.forward_end())
+        cur.wait_stream(st)
+        for t in outs[-1].values():              # allocated on `st`, consumed on the current stream
+            if isinstance(t, torch.Tensor):
+                t.record_stream(cur)
+    return outs
+
+
+class PanPipeline:
+    """Continuous form of forward_interleaved: a queue of batches flows through `planners` (one per
+    batch in flight) with the planners' PAN iterations staggered, so that the forward calls do not end
+    together.  The DUNE launches of every batch go to the current stream; a finished batch is joined on
+    a separate output stream (npa_forward_end_on) and its planner starts the next batch at once -- its
+    staging runs on the helper stream behind its last QP -- so the DUNE stream never drains between
+    forward calls.  `run` returns the output dicts in submission order, valid on the current stream.
+    Measured on one MI355X (256 scenes per batch): 120 k plans/s with 3 planners, FALLING to 104 k with 5,
+    where lockstep groups (forward_interleaved) reach 122 k -- the cause was not found; bench.py keeps the
+    groups."""
+
+    def __init__(self, planners):
+        assert len(planners) >= 1
+        self.planners = list(planners)
+        self.K = planners[0].iter_num
+        assert all(p.iter_num == self.K for p in planners)
+        self.device = planners[0].device
+        self.out_stream = torch.cuda.Stream(device=self.device)
+
+    def run(self, inputs, reset_state=True):
+        n, K = len(self.planners), self.K
+        if n == 1:
+            outs = []
+            for a in inputs:
+                if reset_state:
+                    self.planners[0].reset_stop_state()
+                outs.append(self.planners[0].forward_batch(*a))
+            return outs
+        cur = torch.cuda.current_stream(self.device)
+        pending = list(enumerate(inputs))[::-1]
+        outs = [None] * len(inputs)
+        active = [None] * n                                  # [input index, next iteration]
+        start = [(j * K) // n for j in range(n)]             # stagger of the first forwards
+        tick = 0
+        while pending or any(a is not None for a in active):
+            for j, p in enumerate(self.planners):
+                if active[j] is None:
+                    if not pending or tick < start[j]:
+                        continue
+                    idx, a = pending.pop()
+                    p.forward_begin(*a, qp_on_helper_stream=True, reset_state=reset_state)
+                    active[j] = [idx, 0]
+                idx, k = active[j]
+                p.forward_iter(k)
+                if k + 1 == K:
+                    outs[idx] = p.forward_end(join_stream=self.out_stream)
+                    for t in outs[idx].values():
+                        if isinstance(t, torch.Tensor):
+                            t.record_stream(self.out_stream)
+                    active[j] = None
+                else:
+                    active[j][1] = k + 1
+            tick += 1
+        cur.wait_stream(self.out_stream)
+        return outs

@@ -277,3 +277,24 @@ def test_other_baseline_configs_full_size(cfgname, scenes):
             assert l2(ug.cpu().numpy(), u) <= 1e-4, (cfgname, b)
             checked += 1
     assert checked >= 2
+
+
+def test_pipeline_schedule_equals_sequential():
+    """PanPipeline (staggered forward calls, staging on the helper stream, joins on an output stream) must
+    give bitwise the results of planning each batch on its own, including when a planner is reused."""
+    from gpu_helpers import make_gpu_pan
+    from neupan_amd.pan import PanPipeline
+    cfg = CONFIGS["diff_1k_T10_K10"]
+    B = 32
+    inputs = []
+    for j in range(7):
+        b = make_batch(cfg, 900 + j * B, B, 300)
+        inputs.append([b[k] for k in ("nom_s", "nom_u", "ref_s", "ref_us", "points")])
+    pipe = PanPipeline([make_gpu_pan(cfg, dune_max_num=300, iter_num=4) for _ in range(3)])
+    outs = pipe.run(inputs)
+    ref = make_gpu_pan(cfg, dune_max_num=300, iter_num=4)
+    for j in range(7):
+        ref.reset_stop_state()
+        o = ref.forward_batch(*inputs[j])
+        assert np.array_equal(o["opt_u"].cpu().numpy(), outs[j]["opt_u"].cpu().numpy()), j
+        assert np.array_equal(o["opt_s"].cpu().numpy(), outs[j]["opt_s"].cpu().numpy()), j
