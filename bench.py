@@ -125,9 +125,7 @@ def main():
         done = 0
         while done < n:                      # groups of forward calls in lockstep
             g = min(nfl, n - done)
-            for p in pans[:g]:
-                p.reset_stop_state()
-            outs = forward_interleaved(pans[:g], args_dev[:g])
+            outs = forward_interleaved(pans[:g], args_dev[:g], reset_state=True)   # fresh planners every step
             for o in outs:
                 gathered = gather_controls(o["opt_u"], dist, world, equal_shards=True)
             out0 = outs[0]

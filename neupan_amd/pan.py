@@ -278,8 +278,9 @@ class PAN(torch.nn.Module):
         out_u = torch.empty((B, 2, T), dtype=torch.float32, device=dev)
         out_d = torch.empty((B, 1, max(T, 1)), dtype=torch.float32, device=dev) if M > 0 and self.dune_max_num > 0 else None
         out_md = torch.empty((B,), dtype=torch.float32, device=dev)
-        out_it = torch.zeros((B,), dtype=torch.int32, device=dev)
-        out_np = torch.zeros((B, 2, M), dtype=torch.float32, device=dev) if not self.no_obs else None
+        # every scene's QP writes these in PAN iteration 0 at the latest: no fill kernels needed
+        out_it = torch.empty((B,), dtype=torch.int32, device=dev)
+        out_np = torch.empty((B, 2, M), dtype=torch.float32, device=dev) if not self.no_obs else None
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             check(self._lib.npa_forward_begin(
@@ -496,7 +497,7 @@ class _PanGrad(torch.autograd.Function):
 _STREAMS = {}
 
 
-def forward_interleaved(planners, inputs, mode=None):
+def forward_interleaved(planners, inputs, mode=None, reset_state=False):
     """Plan several independent batches concurrently: `planners[i]` (one PAN per batch in flight,
     same configuration) plans `inputs[i]` (the positional arguments of forward_batch).
     mode "events" (default): the DUNE launches of all batches are enqueued round-robin on the current
@@ -505,6 +506,7 @@ def forward_interleaved(planners, inputs, mode=None):
     mode "streams": every planner's whole chain (DUNE -> select -> QP, K times) goes to a stream of its
       own and the hardware queues interleave the chains -- measured slower (94-113 k vs 122 k plans/s):
       concurrent DUNE launches split the CUs and stretch each other.
+    reset_state: clear every planner's stop-criterion memory first (fresh planners), inside the staging launch.
     Returns the list of output dicts (valid on the current stream)."""
     import os
     assert len(planners) == len(inputs) and len(planners) >= 1
@@ -514,7 +516,7 @@ def forward_interleaved(planners, inputs, mode=None):
         assert p.iter_num == K
     if mode == "events" or len(planners) == 1:
         for p, a in zip(planners, inputs):
-            p.forward_begin(*a, qp_on_helper_stream=len(planners) > 1)
+            p.forward_begin(*a, qp_on_helper_stream=len(planners) > 1, reset_state=reset_state)
         for k in range(K):
             for p in planners:
                 p.forward_iter(k)
@@ -528,7 +530,7 @@ def forward_interleaved(planners, inputs, mode=None):
     for st, p, a in zip(streams, planners, inputs):
         st.wait_stream(cur)                      # inputs were produced on the current stream
         with torch.cuda.stream(st):
-            p.forward_begin(*a, qp_on_helper_stream=False)
+            p.forward_begin(*a, qp_on_helper_stream=False, reset_state=reset_state)
     for k in range(K):
         for st, p in zip(streams, planners):
             with torch.cuda.stream(st):
