@@ -102,9 +102,10 @@ def main():
 
     cfg = CONFIGS[args.workload]
     BATCH = args.batch
-    T, K, N, E = cfg.T, cfg.iter_num, cfg.n_points, 4
+    T, K, N, E = cfg.T, cfg.iter_num, cfg.n_points, 4      # E: replaced by the planner's edge count below
     nfl = max(1, args.inflight)
     pans = [make_gpu_pan(cfg, device=dev) for _ in range(nfl)]
+    E = pans[0].E
     args_dev = []
     for j in range(nfl):                    # batch j of this rank: its own 256 scenes
         batch = make_batch(cfg, (rank * nfl + j) * BATCH, BATCH)
@@ -199,7 +200,7 @@ def main():
                    "scenes_per_gpu": BATCH, "points": N, "T": T, "K": K, "M": cfg.nrmp_max_num,
                    "batches_in_flight": nfl,
                    "parallelism": f"scene-shard x{world}, RCCL all-gather of controls"},
-        "roofline": {"bound": "mfma", "kernel": "dune_kernel<4,true>" if os.environ.get("NPA_DUNE_FP32KEYS") is None else "dune_kernel<4,false>",
+        "roofline": {"bound": "mfma", "kernel": f"dune_kernel<{E},true>" if os.environ.get("NPA_DUNE_FP32KEYS") is None else f"dune_kernel<{E},false>",
                      "note": ("ALGORITHMIC fp32 flops per launch / launch time against the fp32-input MFMA peak (the arithmetic "
                               "the path is specified in).  The kernel evaluates the four 32x32 layers as fp16x2 split "
                               "products (3 v_mfma_f32_32x32x16_f16 per fp32 K-step pair, ~2^-22 relative) and re-encodes "

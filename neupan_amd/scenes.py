@@ -73,6 +73,15 @@ CONFIGS = {
         robot=dict(kinematics="diff", length=1.6, width=2.0, max_speed=[8, 1], max_acce=[8, 3]),
         adjust=dict(q_s=0.5, p_u=1.0, eta=15.0, d_max=1.0, d_min=0.1, bk=1.0, ro_obs=400),
     ),
+    # configs[4]: 8-vertex hull, 5000 pts.  The reference ships no 8-edge robot or E = 8 checkpoint: the hull is
+    # ours and the weights are a quick fit to closed-form labels (tests/golden/make_poly8_checkpoint.py)
+    "poly8_5k_T10_K10": SceneConfig(
+        name="poly8_5k_T10_K10", n_points=5000, checkpoint="poly8",
+        robot=dict(kinematics="diff", vertices=[[-0.6, -0.8], [0.6, -0.8], [1.0, -0.4], [1.0, 0.4], [0.6, 0.8],
+                                                  [-0.6, 0.8], [-1.0, 0.4], [-1.0, -0.4]],
+                   max_speed=[8, 1], max_acce=[8, 3]),
+        adjust=dict(q_s=1.0, p_u=1.0, eta=15.0, d_max=1.0, d_min=0.1, bk=0.1, ro_obs=400),
+    ),
 }
 
 

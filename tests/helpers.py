@@ -11,7 +11,10 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def ckpt_path(name):
-    return os.path.join(GOLDEN, "checkpoints", f"{name}_model_5000.pth")
+    """reference checkpoints (example/model/<name>/model_5000.pth, copied as data fixtures) or the quick fit
+    made by tests/golden/make_poly8_checkpoint.py"""
+    p = os.path.join(GOLDEN, "checkpoints", f"{name}_model_5000.pth")
+    return p if os.path.exists(p) else os.path.join(GOLDEN, "checkpoints", f"{name}_model_quick.pth")
 
 
 def golden(name):

@@ -298,3 +298,20 @@ def test_pipeline_schedule_equals_sequential():
         o = ref.forward_batch(*inputs[j])
         assert np.array_equal(o["opt_u"].cpu().numpy(), outs[j]["opt_u"].cpu().numpy()), j
         assert np.array_equal(o["opt_s"].cpu().numpy(), outs[j]["opt_s"].cpu().numpy()), j
+
+
+def test_eight_edge_robot_parity():
+    """BASELINE.json configs[4]: 8-vertex hull (E = 8 instantiations of the kernels).  The weights are
+    the quick fit of tests/golden/make_poly8_checkpoint.py: parity is 'same weights, HIP vs oracle'."""
+    from gpu_helpers import make_gpu_pan, l2
+    cfg = CONFIGS["poly8_5k_T10_K10"]
+    errs = []
+    for b in (0, 1, 2, 3):
+        sc = make_scene(cfg, b, 700)
+        pan = make_gpu_pan(cfg, dune_max_num=700, iter_num=3)
+        orc = make_oracle(cfg, dune_max_num=700, iter_num=3)
+        s, u, d = pan(sc["nom_s"], sc["nom_u"], sc["ref_s"], sc["ref_us"], sc["points"])
+        so, uo, do = orc.forward(sc["nom_s"], sc["nom_u"], sc["ref_s"], sc["ref_us"], sc["points"])
+        errs.append(l2(u.cpu().numpy(), uo))
+        assert pan.E == 8
+    assert np.median(errs) <= 1e-5 and max(errs) <= 1e-4, errs
