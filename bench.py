@@ -136,7 +136,10 @@ def main():
     args_dev = []
     for j in range(nfl):                    # batch j of this rank: its own 256 scenes
         batch = make_batch(cfg, (rank * nfl + j) * BATCH, BATCH)
-        args_dev.append([torch.from_numpy(batch[k]).to(dev) for k in ("nom_s", "nom_u", "ref_s", "ref_us", "points")])
+        a = [torch.from_numpy(batch[k]).to(dev) for k in ("nom_s", "nom_u", "ref_s", "ref_us", "points")]
+        if batch.get("velocities") is not None:            # moving points (configs[3])
+            a.append(torch.from_numpy(batch["velocities"]).to(dev))
+        args_dev.append(a)
     torch.cuda.synchronize(dev)
 
     pipe = PanPipeline(pans)
