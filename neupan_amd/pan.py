@@ -295,16 +295,18 @@ class PAN(torch.nn.Module):
 
     def forward_iter(self, k):
         """Enqueue PAN iteration k (DUNE launch + QP launch) of the forward started by forward_begin."""
-        check(self._lib.npa_forward_iter(self._h, int(k)), "npa_forward_iter")
+        with torch.cuda.device(self.device):       # the launches must see the device of the handle's streams
+            check(self._lib.npa_forward_iter(self._h, int(k)), "npa_forward_iter")
 
     def forward_end(self, join_stream=None):
         """Join the helper streams; returns the output dict (device tensors, valid in stream order).
         join_stream: a torch.cuda.Stream that waits for the results INSTEAD of the stream the forward
         was begun on (PanPipeline: that stream stays free for the other batches' DUNE launches)."""
-        if join_stream is None:
-            check(self._lib.npa_forward_end(self._h), "npa_forward_end")
-        else:
-            check(self._lib.npa_forward_end_on(self._h, C.c_void_p(join_stream.cuda_stream)), "npa_forward_end_on")
+        with torch.cuda.device(self.device):
+            if join_stream is None:
+                check(self._lib.npa_forward_end(self._h), "npa_forward_end")
+            else:
+                check(self._lib.npa_forward_end_on(self._h, C.c_void_p(join_stream.cuda_stream)), "npa_forward_end_on")
         out, self._pending = self._pending, None
         return out
 
