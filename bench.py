@@ -204,7 +204,7 @@ def main():
     dune_s = prof["dune_ms"] * 1e-3
     achieved = flops_per_launch / dune_s / 1e12 if dune_s > 0 else 0.0
 
-    # HBM bytes per dune_kernel launch from the PMC passes of tools/hbm_traffic.py (separate rocprofv3
+    # HBM bytes per dune_kernel launch from the PMC passes of tests/tools/hbm_traffic.py (separate rocprofv3
     # runs: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), committed under profiles/
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")

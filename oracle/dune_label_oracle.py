@@ -1,6 +1,6 @@
 """CPU restatement of the DUNE training-label problem.
 
-TEST INFRASTRUCTURE ONLY (tests/, tools/): never imported by the product path.
+TEST INFRASTRUCTURE ONLY (tests/, tests/tools/): never imported by the product path.
 
 Reference: neupan/blocks/dune_train.py:82-99 (problem), :137-140 (solve with ECOS), :101-107 (labels
 are cast to float32 tensors):

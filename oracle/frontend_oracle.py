@@ -1,7 +1,7 @@
 """CPU restatement of the two steps in front of PAN.forward.
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the cpu_baseline leg of
-bench.py / tools/frontend_bench.py -- never by the product path (neupan_amd/).
+bench.py / tests/tools/frontend_bench.py -- never by the product path (neupan_amd/).
 
 Pinned against outputs of the UNMODIFIED reference code run in the build container
 (tests/golden/make_golden_frontend.py -> tests/golden/frontend_*.npz, see tests/test_frontend.py).

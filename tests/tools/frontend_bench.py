@@ -1,6 +1,6 @@
 """Timing of the front-end kernels beside the CPU restatement.
 
-    python tools/frontend_bench.py            # prints one JSON object
+    python tests/tools/frontend_bench.py            # prints one JSON object
 
 GPU: average of `reps` launches between two events on the launch stream, inputs resident.
 CPU: oracle/frontend_oracle.py (the reference's algorithm, numpy/python, 1 thread) on a sample.
@@ -13,7 +13,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT)
 
 

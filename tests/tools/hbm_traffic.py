@@ -1,6 +1,6 @@
 """HBM traffic per launch of the PAN kernels from rocprofv3 PMC counters (run on the GPU box):
 
-    python tools/hbm_traffic.py            # writes gpurun_out/traffic.json
+    python tests/tools/hbm_traffic.py            # writes gpurun_out/traffic.json
 
 Two separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950, see
 /opt/skills/guides/MI355X_MICROARCH.md, "rocprofv3 PMC slots"), --kernel-trace only.
@@ -11,7 +11,7 @@ for which the doubling is the conservative (upper) figure.
 """
 import collections, csv, json, os, subprocess, sys, tempfile
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def run_pass(counter):

@@ -1,5 +1,5 @@
 // Hardware probe (gfx950): v_pk_fma_f32 whose destination pair overlaps a source pair that is read
-// with an op_sel half-swap.  hipcc --offload-arch=gfx950 -O2 tools/hw/pk_opsel_overlap.hip -o /tmp/probe && /tmp/probe
+// with an op_sel half-swap.  hipcc --offload-arch=gfx950 -O2 tests/tools/hw/pk_opsel_overlap.hip -o /tmp/probe && /tmp/probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

@@ -1,9 +1,9 @@
 """GPU diagnostic: determinism of the DUNE stage and agreement of the split-key selection with the
-exact-fp32-key selection.   python tools/key_check.py out.npz [B]      (run once per key mode)"""
+exact-fp32-key selection.   python tests/tools/key_check.py out.npz [B]      (run once per key mode)"""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from helpers import CONFIGS
 from gpu_helpers import make_gpu_pan
 from neupan_amd.scenes import make_batch

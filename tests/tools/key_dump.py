@@ -2,8 +2,8 @@
 import os, sys
 import numpy as np
 import torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from helpers import CONFIGS
 from gpu_helpers import make_gpu_pan
 from neupan_amd.scenes import make_batch

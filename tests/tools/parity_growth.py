@@ -2,7 +2,7 @@
 shows whether a large final deviation is a solver error or amplification by a non-contracting
 PAN fixed-point iteration (grows from ~1e-7 by a constant factor per iteration)."""
 import os, sys, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from gpu_helpers import make_gpu_pan
 from helpers import CONFIGS, make_oracle

@@ -1,6 +1,6 @@
 """Iteration statistics of the QP solves along the PAN iterations of one forward call."""
 import sys, os, numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from gpu_helpers import make_gpu_pan
 from helpers import CONFIGS

@@ -1,5 +1,6 @@
 import sys, os, numpy as np, torch
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from gpu_helpers import make_gpu_pan
 from helpers import CONFIGS, make_oracle
 from neupan_amd.scenes import make_batch
