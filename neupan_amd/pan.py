@@ -97,13 +97,27 @@ class _NrmpFacade:
 
 
 class _DuneFacade:
-    def __init__(self, checkpoint):
+    def __init__(self, checkpoint, pan=None):
         self.abs_checkpoint_path = checkpoint
         self.obstacle_points = None
         self.min_distance = inf
+        self._pan = pan
+        self.full_model_name = None
 
-    def train_dune(self, *a, **k):
-        raise NotImplementedError("DUNE training is outside this path (reference: neupan/blocks/dune_train.py)")
+    def train_dune(self, train_kwargs=None):
+        """dune.py:174-182: train an ObsPointNet for this robot's polygon and return the checkpoint path
+        (labels by the HIP labeller instead of ECOS, neupan_amd/dune_train.py).  Construct a new PAN with
+        `dune_checkpoint=<that path>` to plan with it (the reference asks interactively, dune.py:160-166)."""
+        from .dune_train import DuneTrain
+        kw = dict(train_kwargs or {})
+        pan = self._pan
+        name = kw.pop("model_name", getattr(pan.robot, "name", None) or "robot")
+        kw.pop("direct_train", None)
+        path = os.path.join(sys.path[0] or os.getcwd(), "model", name)
+        tr = DuneTrain(None, np.asarray(pan.robot.G, dtype=np.float32), np.asarray(pan.robot.h, dtype=np.float32), path,
+                       device=pan.device)
+        self.full_model_name = tr.start(**kw)
+        return self.full_model_name
 
     @property
     def points(self):
@@ -182,7 +196,7 @@ class PAN(torch.nn.Module):
                 wts.ln_w[i] = arr(f"MLP.{li}.weight", (32,))
                 wts.ln_b[i] = arr(f"MLP.{li}.bias", (32,))
             self._wkeep = keep
-            self.dune_layer = _DuneFacade(path)
+            self.dune_layer = _DuneFacade(path, self)
         else:
             self.dune_layer = None
 

@@ -8,6 +8,8 @@
 * frontend_scan.npz     outputs of the reference's `neupan.scan_to_point` / `scan_to_point_velocity`
                         (neupan/neupan.py:173-281), called unbound (they do not touch `self`)
 
+* dune_train_losses.npz the loss terms of the reference's `DUNETrain.train_one_epoch` (dune_train.py:302-366)
+
 The reference functions execute unmodified (numpy 2.2 in this container: NEP-50 scalar promotion).
 """
 import copy
@@ -162,6 +164,43 @@ def run_scan():
     print("frontend_scan.npz:", len(names), "cases")
 
 
+def run_dune_train_losses():
+    """dune_train_losses.npz: the four loss terms of the reference's DUNETrain.train_one_epoch(validate=True)
+    (dune_train.py:302-366) for the shipped diff network with perturbed weights, 600 labelled points, batch
+    256, np.random.seed(11) for the per-batch rotation angle."""
+    import tempfile
+
+    import torch
+    from torch.utils.data import DataLoader
+
+    from neupan.blocks.dune_train import DUNETrain, PointDataset
+    from neupan.blocks.obs_point_net import ObsPointNet as RefNet
+    from oracle import dune_label_oracle as dl
+    G = np.array([[0, -1.6], [2, 0], [0, 1.6], [-2, 0]], dtype=np.float32)
+    h = np.full((4, 1), 1.6, dtype=np.float32)
+    net = RefNet(2, 4)
+    net.load_state_dict(torch.load(os.path.join(HERE, "checkpoints", "diff_robot_default_model_5000.pth"), map_location="cpu"))
+    torch.manual_seed(3)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(0.05 * torch.randn_like(p))          # so that the losses are not ~0
+    tr = DUNETrain(net, torch.tensor(G), torch.tensor(h), tempfile.mkdtemp())
+    P = np.random.default_rng(1).uniform(-25, 25, (600, 2))
+    mu, dist = dl.labels(G.astype(np.float64), h.reshape(-1).astype(np.float64), P)
+    ds = PointDataset([torch.tensor(P[i].reshape(2, 1), dtype=torch.float32) for i in range(600)],
+                      [torch.tensor(mu[i].reshape(4, 1), dtype=torch.float32) for i in range(600)],
+                      [torch.tensor(dist[i], dtype=torch.float32) for i in range(600)])
+    np.random.seed(11)
+    net.eval()
+    with torch.no_grad():
+        out = tr.train_one_epoch(DataLoader(ds, batch_size=256), True)
+    sd = {k: v.numpy() for k, v in net.state_dict().items()}
+    np.savez_compressed(os.path.join(HERE, "dune_train_losses.npz"), points=P, mu=mu, dist=dist, losses=np.array(out),
+                        G=G, h=h, **{"w/" + k: v for k, v in sd.items()})
+    print("dune_train_losses.npz:", out)
+
+
 if __name__ == "__main__":
     run_nominal()
     run_scan()
+    run_dune_train_losses()
