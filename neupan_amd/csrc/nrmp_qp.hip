@@ -122,13 +122,15 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
   extern __shared__ __attribute__((aligned(16))) double sm_all[];
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
+  const bool low_prio = wpg < 0;          // launcher knob NPA_QP_LOWPRIO: run at the default wave priority
+  if (low_prio) wpg = -wpg;
   if (blockIdx.x * wpg + wv >= nscene) return;
   const int b = blockIdx.x * wpg + wv + scene0;
   double* sm = sm_all + (size_t)wv * wave_doubles;
   if (flags && flags[b * 4 + 0]) return;
   // this wave is a long dependent chain that shares its SIMD with throughput-bound DUNE waves of
   // the other sub-batches: win the issue arbitration, it needs few slots but needs them promptly
-  __builtin_amdgcn_s_setprio(3);
+  if (!low_prio) __builtin_amdgcn_s_setprio(3);
 
   // with TT and MM fixed every LDS offset below folds to an immediate (one base register)
   PROF_DECL
@@ -144,10 +146,14 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
 
   // ---- LDS carve (doubles) -----------------------------------------------------------
   double* Phi = sm;                           // [T][3][ldp]  s(t+1) = Phi[t] u + cv[t]
-  double* Yt = Phi + (size_t)T * 3 * ldp;     // [T][2][ldp]  S'_t Phi_xy(t)
-  double* Hm = Yt + (size_t)T * 2 * ldp;      // [nu][ldk]    constant Hessian block (lower)
-  double* Km = Hm + (size_t)nu * ldk;         // [nu][ldk]
-  double* cv = Km + (size_t)nu * ldk;         // [T][3]
+  // generic path: Yt [T][2][ldp] = S'_t Phi_xy(t), Hm / Km [nu][ldk] full matrices.
+  // fast path (TT > 0): Yt [T][6] = staging of the 3x3 P_t, Hm packed lower triangle (row a at
+  // a(a+1)/2), Km packed STRICTLY lower triangle of L (row k at k(k-1)/2) -- 31 -> 25 KB at T = 10,
+  // 93 -> 68 KB at T = 20, where it decides whether two QP workgroups fit a CU's LDS
+  double* Yt = Phi + (size_t)T * 3 * ldp;
+  double* Hm = Yt + (TT > 0 ? (size_t)T * 6 : (size_t)T * 2 * ldp);
+  double* Km = Hm + (TT > 0 ? (size_t)nu * (nu + 1) / 2 : (size_t)nu * ldk);
+  double* cv = Km + (TT > 0 ? (size_t)nu * (nu - 1) / 2 + 2 : (size_t)nu * ldk);    // [T][3]
   double* lin = cv + T * 3;                   // [T][3]  state-cost gradient at u = 0
   double* s3 = lin + T * 3;                   // [T][3]  Phi x   /  Phi dx
   double* q3 = s3 + T * 3;                    // [T][3]  operand of Phi'
@@ -279,8 +285,12 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
       acc += W0 * Pt[a] * Pt[c] + W1 * Pt[ldp + a] * Pt[ldp + c] + W2 * Pt[2 * ldp + a] * Pt[2 * ldp + c];
     }
     if (a == c && !(a & 1)) acc += 2.0 * pu * pu;
-    Hm[a * ldk + c] = acc;
-    Hm[c * ldk + a] = acc;
+    if constexpr (TT > 0) {
+      Hm[p] = acc;                          // p = a(a+1)/2 + c: the packed lower triangle
+    } else {
+      Hm[a * ldk + c] = acc;
+      Hm[c * ldk + a] = acc;
+    }
   }
   // fast path: this lane's entries of H that receive the band terms of C_u' D C_u
   double hdiag = 0, hoff = 0;
@@ -348,8 +358,8 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
   LSYNC();
   if constexpr (TT > 0) {
     if (lane < NU) {
-      hdiag = Hm[lane * ldk + lane];
-      hoff = lane >= 2 ? Hm[lane * ldk + lane - 2] : 0.0;
+      hdiag = Hm[lane * (lane + 1) / 2 + lane];
+      hoff = lane >= 2 ? Hm[lane * (lane + 1) / 2 + lane - 2] : 0.0;
     }
   }
 
@@ -567,8 +577,8 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
         double dsum = lc[2 * a] * iwc[2 * a] + lc[2 * a + 1] * iwc[2 * a + 1], doff = 0;
         if (t >= 1) { int q = 4 * T + 2 * (a - 2); double v = lc[q] * iwc[q] + lc[q + 1] * iwc[q + 1]; dsum += v; doff = v; }
         if (t <= T - 2) { int q = 4 * T + 2 * a; dsum += lc[q] * iwc[q] + lc[q + 1] * iwc[q + 1]; }
-        Hm[a * ldk + a] = hdiag + dsum;
-        if (t >= 1) Hm[a * ldk + a - 2] = hoff - doff;
+        Hm[a * (a + 1) / 2 + a] = hdiag + dsum;
+        if (t >= 1) Hm[a * (a + 1) / 2 + a - 2] = hoff - doff;
       }
       LSYNC();
       PROF(2);
@@ -583,7 +593,8 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
         const double* Ph = Phi + (size_t)i * 3 * ldp;  // Phi_i rows (zero beyond column 2i+1)
 #pragma unroll
         for (int c = 0; c < NU; ++c) {
-          arow[c] = fma(g0, Ph[c], fma(g1, Ph[ldp + c], fma(g2, Ph[2 * ldp + c], Hm[ar * ldk + c])));
+          // (entries c > ar read other rows of the packed triangle: finite, and never used)
+          arow[c] = fma(g0, Ph[c], fma(g1, Ph[ldp + c], fma(g2, Ph[2 * ldp + c], Hm[ar * (ar + 1) / 2 + c])));
         }
       }
       PROF(3);
@@ -606,12 +617,16 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
       for (int c = 0; c < NU; ++c) arow[c] = (c < lane) ? arow[c] : 0.0;
       if (lane < NU) {
 #pragma unroll
-        for (int c = 0; c < NU; ++c) Km[(size_t)lane * ldk + c] = arow[c];
+        for (int c = 0; c < NU - 1; ++c)
+          if (c < lane) Km[lane * (lane - 1) / 2 + c] = arow[c];
       }
       LSYNC();
       myinv = invd[ar];
 #pragma unroll
-      for (int k = 0; k < NU; ++k) bcol[k] = Km[(size_t)k * ldk + ar];
+      for (int k = 0; k < NU; ++k) {
+        const double v = Km[k * (k - 1) / 2 + ar];        // row k holds columns 0..k-1
+        bcol[k] = k > ar ? v : 0.0;
+      }
     } else {
     for (int q = lane; q < 2 * T * nu; q += QP_THREADS) {        // Y[t][k][c] = S'_t[k][:] Phi_xy[t][:, c]
       int tk = q / nu, c = q - tk * nu, t = tk >> 1, k = tk & 1;
@@ -958,14 +973,21 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
   }
 }
 
-extern "C" size_t npa_qp_shmem_bytes(int T, int M) {
+static bool qp_fast_path(int T, int M) { return (T == 10 || T == 20) && M == 10; }
+
+// LDS bytes of one scene; `fast` = the register-resident instantiation (packed H, L and P staging)
+extern "C" size_t npa_qp_shmem_bytes_path(int T, int M, int fast) {
   const bool obs = M > 0;
   size_t nu = 2 * T, ldp = nu + 1, mcu = 8 * T - 4, mf = obs ? (size_t)T * M : 0, npair = nu * (nu + 1) / 2;
-  size_t d = (size_t)T * 3 * ldp + (size_t)T * 2 * ldp + 2 * nu * ldp + 4 * (T * 3) + T * 12 + T * 8 + nu + T +
+  const size_t mats = fast ? (size_t)T * 6 + nu * (nu + 1) / 2 + nu * (nu - 1) / 2 + 2
+                           : (size_t)T * 2 * ldp + 2 * nu * ldp;
+  size_t d = (size_t)T * 3 * ldp + mats + 4 * (T * 3) + T * 12 + T * 8 + nu + T +
              (nu + T) + nu + T + nu + T + 9 * mf + 7 * mcu + 6 * 2 * T;
   size_t bytes = d * sizeof(double) + 2 * ((npair + 7) & ~(size_t)7) + ((mcu + 7) & ~(size_t)7);
   return (bytes + 15) & ~(size_t)15;
 }
+
+extern "C" size_t npa_qp_shmem_bytes(int T, int M) { return npa_qp_shmem_bytes_path(T, M, 0); }
 
 extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, const float* cur_s_in,
                                     const float* cur_u_in, const float* ref_s, const float* ref_us,
@@ -974,7 +996,10 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
                                     float* cur_d_out, float* out_s, float* out_u, float* out_d,
                                     float* out_min_distance, int* out_iters, float* out_nrmp_points, int* flags,
                                     float* state, double* qp_info, double* warm, hipStream_t stream) {
-  const size_t wave_bytes = npa_qp_shmem_bytes(P.T, P.M);
+  static const bool force_generic = getenv("NPA_QP_GENERIC") != nullptr;
+  static const bool low_prio = getenv("NPA_QP_LOWPRIO") != nullptr;
+  const bool fast = qp_fast_path(P.T, P.M) && !force_generic;
+  const size_t wave_bytes = npa_qp_shmem_bytes_path(P.T, P.M, fast ? 1 : 0);
   // One scene (wave) per workgroup by default: the dispatcher then spreads the QP waves of a launch
   // evenly over the CUs, so that DUNE workgroups of other batches in flight are slowed uniformly
   // (they balance inside a CU through their LDS ticket, not across CUs).  NPA_QP_WPG=2..4 packs
@@ -993,12 +1018,12 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
     hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<20, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  static const bool force_generic = getenv("NPA_QP_GENERIC") != nullptr;
 #define QP_LAUNCH(TTV, MMV)                                                                                      \
   hipLaunchKernelGGL((nrmp_qp_kernel<TTV, MMV>), dim3(nblocks), dim3(QP_THREADS * wpg), shmem, stream, P, cur_s_in, cur_u_in, \
                      ref_s, ref_us, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count, cur_s_out, cur_u_out, \
                      cur_d_out, out_s, out_u, out_d, out_min_distance, out_iters, out_nrmp_points, flags, state, \
-                     qp_info, warm, scene0, batch, wave_doubles, wpg, QpBackward{nullptr, nullptr, nullptr, nullptr})
+                     qp_info, warm, scene0, batch, wave_doubles, low_prio ? -wpg : wpg,                         \
+                     QpBackward{nullptr, nullptr, nullptr, nullptr})
   if (P.T == 10 && P.M == 10 && !force_generic) QP_LAUNCH(10, 10);
   else if (P.T == 20 && P.M == 10 && !force_generic) QP_LAUNCH(20, 10);
   else QP_LAUNCH(0, 0);
