@@ -226,7 +226,7 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
   if (e == hipSuccess) e = hipMalloc(&h->wpack, WP_TOTAL * sizeof(float));
   if (e == hipSuccess) e = hipMemcpy(h->wpack, pack.data(), WP_TOTAL * sizeof(float), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
-    delete h;
+    npa_destroy(h);                                      // releases whatever was created so far
     return fail(NPA_E_HIP, std::string("npa_create: ") + hipGetErrorString(e));
   }
   *out = h;
