@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--schedule", choices=["pipeline", "groups"], default="groups",
                     help="groups: lockstep groups of forward calls (forward_interleaved, default); pipeline: staggered forward "
                          "calls (PanPipeline) -- measured slower with more than 3 batches in flight")
+    ap.add_argument("--lanes", type=int, default=0, help="helper streams shared by the batches in flight (0 = one each)")
     ap.add_argument("--inflight", type=int, default=5, help="independent batches (steps) kept in flight")
     ap.add_argument("--workload", default=WORKLOAD, choices=sorted(k for k in __import__("neupan_amd.scenes", fromlist=["CONFIGS"]).CONFIGS),
                     help="scene configuration (default: the one BASELINE.json's metric is quoted on)")
@@ -156,7 +157,7 @@ def main():
         done = 0
         while done < n:                      # groups of forward calls in lockstep
             g = min(nfl, n - done)
-            outs = forward_interleaved(pans[:g], args_dev[:g], reset_state=True)   # fresh planners every step
+            outs = forward_interleaved(pans[:g], args_dev[:g], reset_state=True, lanes=args.lanes or None)   # fresh planners every step
             for o in outs:
                 gathered = gather_controls(o["opt_u"], dist, world, equal_shards=True)
             out0 = outs[0]

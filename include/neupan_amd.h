@@ -138,6 +138,10 @@ int npa_forward_begin(npa_handle *h, int batch, int n_stride,
 int npa_forward_iter(npa_handle *h, int k);
 int npa_forward_end(npa_handle *h);
 int npa_forward_end_on(npa_handle *h, void *join_stream);
+/* Use `stream` (caller-owned) as this handle's helper stream instead of its own; NULL restores it.
+ * Several handles may share one helper stream: their select+QP chains then run one after the other,
+ * which bounds how many QP launches co-execute with the DUNE launches (forward_interleaved's `lanes`). */
+int npa_set_helper_stream(npa_handle *h, void *stream);
 
 /* Stage entry points (used by the parity tests and for profiling one stage alone).
  * npa_dune_stage  = generate_point_flow + DUNE.forward + the top-M gather:

@@ -47,6 +47,7 @@ SYMBOLS = {
     "npa_forward_iter": (_I, [_P, _I]),
     "npa_forward_end": (_I, [_P]),
     "npa_forward_end_on": (_I, [_P, _P]),
+    "npa_set_helper_stream": (_I, [_P, _P]),
     "npa_dune_stage": (_I, [_P, _I, _I] + [_P] * 9 + [_P]),
     "npa_nrmp_stage": (_I, [_P, _I] + [_P] * 12 + [_P]),
     "npa_nrmp_backward": (_I, [_P, _I] + [_P] * 16 + [_P]),

@@ -65,6 +65,7 @@ struct npa_handle {
   // the QP's flat directions (control L2 vs oracle up to 1e-3 on some scenes) -> off by default
   bool warm_start = false;
   hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t own_aux0 = nullptr;        // the helper stream created with the handle (aux[0] may be replaced)
   std::vector<hipEvent_t> sync_ev;
   // profiling (bench.py): HIP events on the launch stream around every stage launch
   bool prof = false;
@@ -223,6 +224,7 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
   }
   for (int i = 0; i < (h->n_sub > 1 ? h->n_sub : 1) && e == hipSuccess; ++i)
     e = hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking);
+  h->own_aux0 = h->aux[0];
   if (e == hipSuccess) e = hipMalloc(&h->wpack, WP_TOTAL * sizeof(float));
   if (e == hipSuccess) e = hipMemcpy(h->wpack, pack.data(), WP_TOTAL * sizeof(float), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -240,7 +242,8 @@ extern "C" int npa_destroy(npa_handle* h) {
   for (auto& p : h->ev_dune) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto& p : h->ev_qp) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto& ev : h->sync_ev) hipEventDestroy(ev);
-  for (int i = 0; i < 4; ++i) if (h->aux[i]) hipStreamDestroy(h->aux[i]);
+  if (h->own_aux0) hipStreamDestroy(h->own_aux0);
+  for (int i = 1; i < 4; ++i) if (h->aux[i]) hipStreamDestroy(h->aux[i]);
   if (h->wpack) hipFree(h->wpack);
   if (h->stage_cand) hipFree(h->stage_cand);
   delete h;
@@ -412,6 +415,17 @@ static PendingCall* pending_of(npa_handle* h, bool create) {
   if (!create) return nullptr;
   g_pending.emplace_back(h, PendingCall());
   return &g_pending.back().second;
+}
+
+extern "C" int npa_set_helper_stream(npa_handle* h, void* stream) {
+  if (!h) return fail(NPA_E_ARG, "npa_set_helper_stream: null handle");
+  {
+    std::lock_guard<std::mutex> lock(g_pending_mu);
+    PendingCall* pc = pending_of(h, false);
+    if (pc && pc->active) return fail(NPA_E_ARG, "npa_set_helper_stream: a forward is in progress on this handle");
+  }
+  h->aux[0] = stream ? (hipStream_t)stream : h->own_aux0;
+  return NPA_OK;
 }
 
 extern "C" int npa_forward_begin(npa_handle* h, int batch, int n_stride, const float* nom_s, const float* nom_u,

@@ -307,6 +307,12 @@ class PAN(torch.nn.Module):
                           nrmp_points=out_np, used_points=use_pts, hold=(nom_s, nom_u, ref_s, ref_us))
         self._pending = dict(opt_s=out_s, opt_u=out_u, opt_d=out_d, min_distance=out_md, iters=out_it, nrmp_points=out_np)
 
+    def set_helper_stream(self, stream=None):
+        """Run this planner's select+QP chain on `stream` (a torch.cuda.Stream; None = the handle's own)."""
+        self._helper = stream                      # keep it alive
+        check(self._lib.npa_set_helper_stream(self._h, None if stream is None else C.c_void_p(stream.cuda_stream)),
+              "npa_set_helper_stream")
+
     def forward_iter(self, k):
         """Enqueue PAN iteration k (DUNE launch + QP launch) of the forward started by forward_begin."""
         with torch.cuda.device(self.device):       # the launches must see the device of the handle's streams
@@ -513,7 +519,7 @@ class _PanGrad(torch.autograd.Function):
 _STREAMS = {}
 
 
-def forward_interleaved(planners, inputs, mode=None, reset_state=False):
+def forward_interleaved(planners, inputs, mode=None, reset_state=False, lanes=None):
     """Plan several independent batches concurrently: `planners[i]` (one PAN per batch in flight,
     same configuration) plans `inputs[i]` (the positional arguments of forward_batch).
     mode "events" (default): the DUNE launches of all batches are enqueued round-robin on the current
@@ -522,6 +528,9 @@ def forward_interleaved(planners, inputs, mode=None, reset_state=False):
     mode "streams": every planner's whole chain (DUNE -> select -> QP, K times) goes to a stream of its
       own and the hardware queues interleave the chains -- measured slower (94-113 k vs 122 k plans/s):
       concurrent DUNE launches split the CUs and stretch each other.
+    lanes: number of helper streams shared by the planners' select+QP chains (planner j uses lane j % lanes);
+      default: one per planner.  Fewer lanes than planners bound how many QP launches co-execute with the
+      DUNE launches.
     reset_state: clear every planner's stop-criterion memory first (fresh planners), inside the staging launch.
     Returns the list of output dicts (valid on the current stream)."""
     import os
@@ -531,6 +540,14 @@ def forward_interleaved(planners, inputs, mode=None, reset_state=False):
     for p in planners:
         assert p.iter_num == K
     if mode == "events" or len(planners) == 1:
+        if lanes:                                    # planner j's QP chain on helper lane j % lanes
+            key = ("lanes", planners[0].device.index, int(lanes))
+            if key not in _STREAMS:
+                _STREAMS[key] = [torch.cuda.Stream(device=planners[0].device) for _ in range(int(lanes))]
+            for j, p in enumerate(planners):
+                want = _STREAMS[key][j % int(lanes)]
+                if getattr(p, "_helper", None) is not want:
+                    p.set_helper_stream(want)
         for p, a in zip(planners, inputs):
             p.forward_begin(*a, qp_on_helper_stream=len(planners) > 1, reset_state=reset_state)
         for k in range(K):
