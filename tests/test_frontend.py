@@ -106,11 +106,12 @@ def test_hip_nominal_first_call_without_velocities():
 
 
 @pytest.mark.gpu
-def test_hip_nominal_large_batch_vs_oracle():
+@pytest.mark.parametrize("kin,L,T", [("diff", 0.0, 10), ("acker", 3.0, 20), ("omni", 0.0, 10)])
+def test_hip_nominal_large_batch_vs_oracle(kin, L, T):
     """4096 robots on random polylines, both reference-sampling modes, against the oracle"""
     from neupan_amd.frontend import NominalBatch
     rng = np.random.default_rng(11)
-    B, T, dt = 4096, 10, 0.1
+    B, dt = 4096, 0.1
     curves, intervals, pidx, states, speeds = [], [], [], [], []
     for b in range(B):
         n = int(rng.integers(6, 60))
@@ -124,12 +125,12 @@ def test_hip_nominal_large_batch_vs_oracle():
         states.append([xy[k, 0] + rng.normal(0, 0.1), xy[k, 1] + rng.normal(0, 0.1), head[k] + rng.normal(0, 0.2)])
         speeds.append(float(rng.choice([2.0, 4.0, 8.0])))
     vel = np.stack([rng.uniform(-4, 6, (B, T)), rng.uniform(-1, 1, (B, T))], axis=1).astype(np.float32)
-    nb = NominalBatch(T, dt, "diff")
+    nb = NominalBatch(T, dt, kin, L)
     nb.set_curves(curves, intervals, pidx)
     nom_s, nom_u, ref_s, ref_us = (o.cpu().numpy() for o in nb.generate_nom_ref_state(np.asarray(states), vel, speeds))
     bad = 0
     for b in range(0, B, 7):
-        o = fo.generate_nom_ref_state(curves[b], pidx[b], intervals[b], np.asarray(states[b]), vel[b], speeds[b], T, dt, "diff", 0.0)
+        o = fo.generate_nom_ref_state(curves[b], pidx[b], intervals[b], np.asarray(states[b]), vel[b], speeds[b], T, dt, kin, L)
         ok = (np.abs(nom_s[b] - o[0].astype(np.float32)).max() <= _ulp32(o[0]) and
               np.abs(ref_s[b] - o[2].astype(np.float32)).max() <= _ulp32(o[2]) and
               np.array_equal(ref_us[b], o[3].astype(np.float32)))
@@ -154,6 +155,33 @@ def test_hip_scan_vs_reference_vectors():
         if n:
             assert np.abs(pts.cpu().numpy()[0, :, :n] - c["points_v"].astype(np.float32)).max() <= _ulp32(c["points_v"]), name
             assert np.array_equal(vel.cpu().numpy()[0, :, :n], c["velocity_v"].astype(np.float32)), name
+
+
+@pytest.mark.gpu
+def test_hip_scan_velocity_ragged_batch_vs_oracle():
+    from neupan_amd.frontend import scan_to_point_velocity_batch
+    rng = np.random.default_rng(6)
+    B, R = 128, 900
+    nb = rng.integers(1, R + 1, B).astype(np.int32)
+    ranges = rng.uniform(0.05, 8.0, (B, R))
+    ranges[rng.random((B, R)) < 0.15] = 8.0
+    ranges[:, ::50] = 0.1                                              # exactly range_min: kept by this variant (>=)
+    vel = rng.uniform(-1, 1, (B, 2, R))
+    states = np.column_stack([rng.uniform(-9, 9, B), rng.uniform(-9, 9, B), rng.uniform(-3.1, 3.1, B)])
+    off = np.column_stack([rng.uniform(-0.5, 0.5, B), rng.uniform(-0.5, 0.5, B), rng.uniform(-1, 1, B)])
+    ds = rng.integers(1, 4, B).astype(np.int32)
+    pts, pv, cnt = scan_to_point_velocity_batch(states, ranges, -3.0, 3.0, 0.1, 8.0, velocities=vel, scan_offset=off,
+                                                down_sample=ds, n_beams=nb)
+    pts, pv, cnt = pts.cpu().numpy(), pv.cpu().numpy(), cnt.cpu().numpy()
+    for b in range(0, B, 2):
+        o, ov = fo.scan_to_point_velocity(states[b], ranges[b, :nb[b]], -3.0, 3.0, 0.1, 8.0, vel[b][:, :nb[b]], off[b],
+                                          (-np.pi, np.pi), int(ds[b]))
+        if o is None:
+            assert cnt[b] == 0
+            continue
+        assert cnt[b] == o.shape[1]
+        assert np.abs(pts[b, :, :cnt[b]] - o.astype(np.float32)).max() <= _ulp32(o)
+        assert np.array_equal(pv[b, :, :cnt[b]], ov.astype(np.float32))
 
 
 @pytest.mark.gpu
