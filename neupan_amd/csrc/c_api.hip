@@ -52,14 +52,14 @@ struct npa_handle {
   float* wpack = nullptr;     // device
   int device = 0;
   int n_cu = 256;
-  float* stage_cand = nullptr;   // candidate scratch of npa_dune_stage (grown on demand)
+  float* stage_cand = nullptr;   // distance-key scratch of npa_dune_stage (grown on demand)
   size_t stage_cand_bytes = 0;
   // sub-batch pipelining: DUNE launches stay in order on the caller's stream, each
   // sub-batch's QP chain runs on its own helper stream so it overlaps the other
   // sub-batches' DUNE launches (the QP is latency bound and occupies one wave per scene)
   int n_sub = 1;              // sub-batches of one forward (NPA_PIPELINE); >1 rarely pays, see DESIGN.md
   int enc_blocks = 5;         // encode workgroups per CU (persistent grid = n_cu * enc_blocks; the
-                              // launcher caps it at 4 for the fp32-key variant, 115 VGPRs)
+                              // launcher caps it at 4 for the fp32-key variant, 117 VGPRs); 4-wave workgroups only
   // IPM warm start across the PAN iterations of one forward call (NPA_QP_WARM=1): fewer iterations
   // on average (12.6 -> 8.5) but a longer tail, and the iterates land at slightly different points of
   // the QP's flat directions (control L2 vs oracle up to 1e-3 on some scenes) -> off by default

@@ -116,7 +116,7 @@ __device__ __forceinline__ f32x16 layer32(const float (&w)[16], const float (&a)
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef f16x8 bf16x8;      // (name kept by the staging code: a 16-byte fragment per lane)
+
 
 // RELU = true: the split is taken of max(a, 0) (the activation of the Linear->ReLU layers)
 template <bool RELU>
@@ -352,7 +352,7 @@ __device__ __forceinline__ void load_frame(const DevParams& P, const float* __re
 // one point (two lanes) through point flow + encoder + lam/distance
 template <int E, bool SPLIT>
 __device__ __forceinline__ void point_features(const DevParams& P, const SliceFrame& F, const WaveWeights& W,
-                                               const bf16x8* wbf, const float* vec, const float* w6, const float* b6,
+                                               const f16x8* wbf, const float* vec, const float* w6, const float* b6,
                                                const float* px_row, const float* py_row, const float* vx_row,
                                                const float* vy_row, int src, int lane, float mu[E], float& gx,
                                                float& gy, float& lx, float& ly, float& dist) {
@@ -413,11 +413,11 @@ void dune_kernel(
 
   for (int i = tid; i < 11 * 32 + 8 * 32 + 8; i += 64 * WAVES) smem[i] = wpack[WP_VEC + i];
   WaveWeights W;
-  const bf16x8* wbf = nullptr;
+  const f16x8* wbf = nullptr;
   if constexpr (SPLIT) {
     float* wb = b6 + 8;                     // 16-byte aligned: (11*32 + 8*32 + 8) floats precede it
     for (int i = tid; i < WP_KEY_LDS_FLOATS; i += 64 * WAVES) wb[i] = wpack[WP_BF + i];
-    wbf = reinterpret_cast<const bf16x8*>(wb);
+    wbf = reinterpret_cast<const f16x8*>(wb);
     W.w1 = wpack[WP_KW1 + lane];
   } else {
     load_weights(wpack, lane, W);
