@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--schedule", choices=["pipeline", "groups"], default="groups",
                     help="groups: lockstep groups of forward calls (forward_interleaved, default); pipeline: staggered forward "
                          "calls (PanPipeline) -- measured slower with more than 3 batches in flight")
+    ap.add_argument("--coalesce", type=int, default=1,
+                    help="run this many in-flight batches as one forward call (larger launches); 1 = off (default)")
     ap.add_argument("--lanes", type=int, default=0, help="helper streams shared by the batches in flight (0 = one each)")
     ap.add_argument("--inflight", type=int, default=5, help="independent batches (steps) kept in flight")
     ap.add_argument("--workload", default=WORKLOAD, choices=sorted(k for k in __import__("neupan_amd.scenes", fromlist=["CONFIGS"]).CONFIGS),
@@ -157,7 +159,8 @@ def main():
         done = 0
         while done < n:                      # groups of forward calls in lockstep
             g = min(nfl, n - done)
-            outs = forward_interleaved(pans[:g], args_dev[:g], reset_state=True, lanes=args.lanes or None)   # fresh planners every step
+            outs = forward_interleaved(pans[:g], args_dev[:g], reset_state=True, lanes=args.lanes or None,
+                                       coalesce=args.coalesce)   # fresh planners every step
             for o in outs:
                 gathered = gather_controls(o["opt_u"], dist, world, equal_shards=True)
             out0 = outs[0]
@@ -229,7 +232,7 @@ def main():
                                else f"{args.workload}: batch={BATCH} synthetic scenes/GPU, {cfg.kinematics} robot, {N} pts, "
                                     f"T={T}, K={K} (iter_threshold=0), M={cfg.nrmp_max_num}, fp32 DUNE (MFMA) + fp64 QP",
                    "scenes_per_gpu": BATCH, "points": N, "T": T, "K": K, "M": cfg.nrmp_max_num,
-                   "batches_in_flight": nfl,
+                   "batches_in_flight": nfl, "coalesced_per_launch": args.coalesce,
                    "parallelism": f"scene-shard x{world}, RCCL all-gather of controls"},
         "roofline": {"bound": "mfma", "kernel": f"dune_kernel<{E},true>" if os.environ.get("NPA_DUNE_FP32KEYS") is None else f"dune_kernel<{E},false>",
                      "note": ("ALGORITHMIC fp32 flops per launch / launch time against the fp32-input MFMA peak (the arithmetic "

@@ -315,3 +315,25 @@ def test_eight_edge_robot_parity():
         errs.append(l2(u.cpu().numpy(), uo))
         assert pan.E == 8
     assert np.median(errs) <= 1e-5 and max(errs) <= 1e-4, errs
+
+
+def test_coalesced_batches_equal_sequential():
+    """forward_interleaved(coalesce=2): pairs of batches run as one forward call; every batch's result must be
+    bitwise what it is when planned alone (scenes are independent)."""
+    from gpu_helpers import make_gpu_pan
+    from neupan_amd.pan import forward_interleaved
+    cfg = CONFIGS["diff_1k_T10_K10"]
+    B = 40
+    inputs = []
+    for j in range(5):
+        b = make_batch(cfg, 1500 + j * B, B, 350)
+        inputs.append([b[k] for k in ("nom_s", "nom_u", "ref_s", "ref_us", "points")])
+    pans = [make_gpu_pan(cfg, dune_max_num=350, iter_num=3) for _ in range(5)]
+    outs = forward_interleaved(pans, inputs, coalesce=2, reset_state=True)
+    assert len(outs) == 5
+    ref = make_gpu_pan(cfg, dune_max_num=350, iter_num=3)
+    for j in range(5):
+        ref.reset_stop_state()
+        o = ref.forward_batch(*inputs[j])
+        assert np.array_equal(o["opt_u"].cpu().numpy(), outs[j]["opt_u"].cpu().numpy()), j
+        assert np.array_equal(o["min_distance"].cpu().numpy(), outs[j]["min_distance"].cpu().numpy()), j
