@@ -267,7 +267,9 @@ def main():
                           "frac_le_1e-4": float((errs <= 1e-4).mean()), "scenes": int(len(errs)),
                           "scenes_with_contracting_pan_iteration": int(conv.sum()),
                           "max_over_contracting": float(errs[conv].max()) if conv.any() else None,
-                          "note": "oracle = reference code restated + substituted fp64 QP solver (ECOS unavailable)"}
+                          "note": "oracle = reference code restated + substituted fp64 QP solver (ECOS unavailable); on the scenes whose "
+                                  "PAN iteration does not contract within K the oracle's own output moves as much under a "
+                                  "1-ulp change of its input (DESIGN.md section 5)"}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
