@@ -217,6 +217,16 @@ int npa_nominal_ref_states(int batch, int receding, int kinematics, double step_
                            const double *path, const int32_t *curve_off, const int32_t *curve_len,
                            const int32_t *point_index, const double *interval, float *nom_s,
                            float *nom_u, float *ref_s, float *ref_us, void *stream);
+/* npa_path_progress replaces InitialPath.closest_point + check_curve_arrive as check_arrive runs them
+ *   (neupan/blocks/initial_path.py:160-181, :279-287, :247-252; called at neupan/neupan.py:113):
+ *   point_index [B] is advanced to the closest of the next `ind_range` path points (first one closer than
+ *   close_threshold wins), arrived [B] = 1 when the pose is within arrive_threshold of the curve's last
+ *   point and point_index >= len - arrive_index_threshold - 2.  min_dis [B] f32 may be NULL.  Switching
+ *   to the next curve / gear stays with the host. */
+int npa_path_progress(int batch, const double *state, const double *path, const int32_t *curve_off,
+                      const int32_t *curve_len, int32_t *point_index, double close_threshold, int ind_range,
+                      double arrive_threshold, int arrive_index_threshold, float *min_dis, int32_t *arrived,
+                      void *stream);
 int npa_scan_to_points(int batch, int beam_stride, const double *ranges, const double *beam_vel,
                        const int32_t *n_beams, const npa_scan_params *params, int mode,
                        int out_stride, float *points, float *velocities, int32_t *count,

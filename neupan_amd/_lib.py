@@ -52,6 +52,7 @@ SYMBOLS = {
     "npa_nrmp_stage": (_I, [_P, _I] + [_P] * 12 + [_P]),
     "npa_nrmp_backward": (_I, [_P, _I] + [_P] * 16 + [_P]),
     "npa_nominal_ref_states": (_I, [_I, _I, _I, C.c_double, C.c_double] + [_P] * 12 + [_P]),
+    "npa_path_progress": (_I, [_I, _P, _P, _P, _P, _P, C.c_double, _I, C.c_double, _I, _P, _P, _P]),
     "npa_scan_to_points": (_I, [_I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
     "npa_dune_labels": (_I, [_I, _P, _P, C.c_int64, _P, _P, _P, _P]),
     "npa_profile_enable": (_I, [_P, _I]),

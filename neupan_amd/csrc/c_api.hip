@@ -611,6 +611,21 @@ extern "C" int npa_nominal_ref_states(int batch, int receding, int kinematics, d
   return NPA_OK;
 }
 
+extern "C" hipError_t npa_launch_progress(int batch, const double* state, const double* path, const int* curve_off,
+                                          const int* curve_len, int* point_index, double close_threshold, int ind_range,
+                                          double arrive_threshold, int arrive_index_threshold, float* min_dis,
+                                          int* arrived, hipStream_t stream);
+extern "C" int npa_path_progress(int batch, const double* state, const double* path, const int32_t* curve_off,
+                                 const int32_t* curve_len, int32_t* point_index, double close_threshold, int ind_range,
+                                 double arrive_threshold, int arrive_index_threshold, float* min_dis, int32_t* arrived,
+                                 void* stream) {
+  if (batch < 1 || !state || !path || !curve_off || !curve_len || !point_index || !arrived || ind_range < 1)
+    return fail(NPA_E_ARG, "npa_path_progress: bad argument");
+  HIP_TRY(npa_launch_progress(batch, state, path, curve_off, curve_len, point_index, close_threshold, ind_range,
+                              arrive_threshold, arrive_index_threshold, min_dis, arrived, (hipStream_t)stream));
+  return NPA_OK;
+}
+
 extern "C" int npa_scan_to_points(int batch, int beam_stride, const double* ranges, const double* beam_vel,
                                   const int32_t* n_beams, const npa_scan_params* params, int mode, int out_stride,
                                   float* points, float* velocities, int32_t* count, void* stream) {

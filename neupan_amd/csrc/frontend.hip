@@ -115,6 +115,37 @@ __global__ void nominal_kernel(int batch, int T, int kin, double dt, double L, c
   }
 }
 
+// ---- progress along the path: closest_point + check_curve_arrive, one thread per scene --------------
+__global__ void progress_kernel(int batch, const double* __restrict__ state, const double* __restrict__ path,
+                                const int* __restrict__ curve_off, const int* __restrict__ curve_len,
+                                int* __restrict__ point_index, double close_threshold, int ind_range,
+                                double arrive_threshold, int arrive_index_threshold, float* __restrict__ min_dis,
+                                int* __restrict__ arrived) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  const double* cv = path + (size_t)curve_off[b] * 4;
+  const int n = curve_len[b];
+  const double sx = state[b * 3 + 0], sy = state[b * 3 + 1];
+  int pidx = point_index[b];
+  const int start = pidx > 0 ? pidx : 0;                                   // initial_path.py:165-166
+  const int end = pidx + ind_range < n ? pidx + ind_range : n;
+  double best = __builtin_inf();
+  for (int i = start; i < end; ++i) {
+    const double dx = sx - cv[i * 4 + 0], dy = sy - cv[i * 4 + 1];
+    const double dis = sqrt(dx * dx + dy * dy);                            // util distance, __init__.py:133
+    if (dis < best) {
+      best = dis;
+      pidx = i;
+      if (dis < close_threshold) break;                                    // :176-177
+    }
+  }
+  point_index[b] = pidx;
+  if (min_dis) min_dis[b] = (float)best;
+  const double ex = sx - cv[(n - 1) * 4 + 0], ey = sy - cv[(n - 1) * 4 + 1];
+  const double ad = sqrt(ex * ex + ey * ey);                               // :281-282
+  arrived[b] = (ad < arrive_threshold && pidx >= n - arrive_index_threshold - 2) ? 1 : 0;   // :284-287
+}
+
 // ---- lidar scan -> global-frame point cloud: one workgroup per scan, ordered compaction -------
 constexpr int SCAN_THREADS = 256;
 
@@ -199,6 +230,17 @@ extern "C" hipError_t npa_launch_nominal(int batch, int T, int kin, double dt, d
   hipLaunchKernelGGL(nominal_kernel, dim3((batch + threads - 1) / threads), dim3(threads), 0, stream, batch, T, kin, dt,
                      L, state, vel, ref_speed, path, curve_off, curve_len, point_index, interval, nom_s, nom_u, ref_s,
                      ref_us);
+  return hipGetLastError();
+}
+
+extern "C" hipError_t npa_launch_progress(int batch, const double* state, const double* path, const int* curve_off,
+                                          const int* curve_len, int* point_index, double close_threshold, int ind_range,
+                                          double arrive_threshold, int arrive_index_threshold, float* min_dis,
+                                          int* arrived, hipStream_t stream) {
+  const int threads = 64;
+  hipLaunchKernelGGL(progress_kernel, dim3((batch + threads - 1) / threads), dim3(threads), 0, stream, batch, state, path,
+                     curve_off, curve_len, point_index, close_threshold, ind_range, arrive_threshold,
+                     arrive_index_threshold, min_dis, arrived);
   return hipGetLastError();
 }
 

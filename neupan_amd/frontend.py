@@ -150,6 +150,23 @@ class NominalBatch:
             raise IndexError("point_index outside its curve")
         self._pidx = torch.from_numpy(pi_.astype(np.int32)).to(self.device)
 
+    def progress(self, state, close_threshold=0.1, ind_range=10, arrive_threshold=0.1, arrive_index_threshold=1):
+        """B x `InitialPath.closest_point` + `check_curve_arrive` (initial_path.py:160-181, :279-287): advances the
+        device copy of point_index and returns (point_index [B] int32, min_distance [B] float32, arrived [B] int32)
+        device tensors.  Defaults are the reference's (:57-60)."""
+        B, dev = self.B, self.device
+        st = torch.as_tensor(np.asarray(state, dtype=np.float64) if not isinstance(state, torch.Tensor) else state)
+        st = st.to(device=dev, dtype=torch.float64).reshape(B, -1)[:, :3].contiguous()
+        md = torch.empty((B,), dtype=torch.float32, device=dev)
+        arr = torch.empty((B,), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            check(self._lib.npa_path_progress(B, _ptr(st), _ptr(self._path), _ptr(self._off), _ptr(self._len), _ptr(self._pidx),
+                                              float(close_threshold), int(ind_range), float(arrive_threshold),
+                                              int(arrive_index_threshold), _ptr(md), _ptr(arr), _stream(dev)),
+                  "npa_path_progress")
+        self._hold_p = st
+        return self._pidx, md, arr
+
     def generate_nom_ref_state(self, state, cur_vel_array, ref_speed):
         """state [B,3] (float64); cur_vel_array [B,2,T] float32 tensor/array (PAN's previous opt_u) or
         None for the first call (zeros, neupan.py:73); ref_speed scalar or [B].

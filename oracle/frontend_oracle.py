@@ -9,6 +9,7 @@ Pinned against outputs of the UNMODIFIED reference code run in the build contain
 * generate_nom_ref_state   neupan/blocks/initial_path.py:68-126  (+ motion models :388-444,
                            find_interaction_point :183-207, range_cir_seg :209-245,
                            WrapToPi util/__init__.py:98-119)
+* path_progress            closest_point + check_curve_arrive, initial_path.py:160-181, :279-287
 * scan_to_point            neupan/neupan.py:173-222
 * scan_to_point_velocity   neupan/neupan.py:224-281
 
@@ -119,6 +120,28 @@ def generate_nom_ref_state(curve, point_index, interval, state, cur_vel, ref_spe
     ref_s = np.stack(ref_l, axis=1)
     ref_us = np.array(gear, dtype=np.float64) * ref_speed
     return nom_s, np.asarray(cur_vel), ref_s, ref_us
+
+
+def path_progress(curve, point_index, state, close_threshold=0.1, ind_range=10, arrive_threshold=0.1,
+                  arrive_index_threshold=1):
+    """InitialPath.closest_point (initial_path.py:160-181) followed by check_curve_arrive (:279-287), as
+    check_arrive runs them (:247-252).  Returns (new point_index, min distance, curve arrived)."""
+    curve = np.asarray(curve, dtype=np.float64)
+    st = np.asarray(state, dtype=np.float64).reshape(-1)
+    n = curve.shape[0]
+    min_dis = np.inf
+    start, end = max(int(point_index), 0), min(int(point_index) + int(ind_range), n)
+    pidx = int(point_index)
+    for index in range(start, end):
+        dis = sqrt((st[0] - curve[index, 0]) ** 2 + (st[1] - curve[index, 1]) ** 2)      # util distance :133
+        if dis < min_dis:
+            min_dis = dis
+            pidx = index
+            if dis < close_threshold:
+                break
+    arrive_distance = float(np.linalg.norm(st[0:2] - curve[-1, 0:2]))
+    arrived = arrive_distance < arrive_threshold and pidx >= (n - arrive_index_threshold - 2)
+    return pidx, min_dis, bool(arrived)
 
 
 def _linspace(a, b, n):

@@ -8,6 +8,7 @@
 * frontend_scan.npz     outputs of the reference's `neupan.scan_to_point` / `scan_to_point_velocity`
                         (neupan/neupan.py:173-281), called unbound (they do not touch `self`)
 
+* frontend_progress.npz `InitialPath.closest_point` + `check_curve_arrive` (initial_path.py:160-181, :279-287)
 * dune_train_losses.npz the loss terms of the reference's `DUNETrain.train_one_epoch` (dune_train.py:302-366)
 
 The reference functions execute unmodified (numpy 2.2 in this container: NEP-50 scalar promotion).
@@ -164,6 +165,34 @@ def run_scan():
     print("frontend_scan.npz:", len(names), "cases")
 
 
+def run_progress():
+    """frontend_progress.npz: InitialPath.closest_point + check_curve_arrive of the reference on random poses"""
+    rng = np.random.default_rng(9)
+    robot = types.SimpleNamespace(kinematics="diff", L=0.0, max_speed=[8.0, 1.0])
+    rows = []
+    curves = {}
+    for ci, path in enumerate((line_path(30, 0.4), arc_path(40, 6.0, 1.0, 0.4 / 6.0), corner_path(1.0), line_path(6, 0.4))):
+        ip = InitialPath(10, 0.1, 4.0, robot)
+        ip.set_initial_path(copy.deepcopy(path))
+        curve = np.hstack(ip.cur_curve).T.copy()
+        curves[f"curve{ci}"] = curve
+        n = curve.shape[0]
+        for _ in range(40):
+            k0 = int(rng.integers(0, n))
+            near = int(min(n - 1, k0 + rng.integers(0, 6)))
+            st = np.array([[curve[near, 0] + rng.normal(0, 0.15)], [curve[near, 1] + rng.normal(0, 0.15)], [0.0]])
+            if rng.random() < 0.2:
+                st[0:2, 0] = curve[-1, 0:2] + rng.normal(0, 0.03, 2)            # near the end of the curve
+            thr, rng_i = float(rng.choice([0.05, 0.1, 0.3])), int(rng.choice([3, 10, 25]))
+            a_thr, a_idx = float(rng.choice([0.1, 0.2])), int(rng.choice([1, 2]))
+            ip.point_index = k0
+            md = ip.closest_point(st, thr, rng_i)
+            arr = ip.check_curve_arrive(st, a_thr, a_idx)
+            rows.append([ci, k0, st[0, 0], st[1, 0], thr, rng_i, a_thr, a_idx, ip.point_index, md, float(bool(arr))])
+    np.savez_compressed(os.path.join(HERE, "frontend_progress.npz"), rows=np.array(rows, dtype=np.float64), **curves)
+    print("frontend_progress.npz:", len(rows), "cases")
+
+
 def run_dune_train_losses():
     """dune_train_losses.npz: the four loss terms of the reference's DUNETrain.train_one_epoch(validate=True)
     (dune_train.py:302-366) for the shipped diff network with perturbed weights, 600 labelled points, batch
@@ -203,4 +232,5 @@ def run_dune_train_losses():
 if __name__ == "__main__":
     run_nominal()
     run_scan()
+    run_progress()
     run_dune_train_losses()

@@ -77,3 +77,55 @@ def test_fleet_cycles_scan_rollout_pan_vs_oracle():
         nb.set_point_index(pidx)
         for o in orcs:
             pass          # the oracle keeps its stop-criterion memory across cycles like the GPU planner
+
+
+def test_fleet_planner_cycles_arrival_and_gear_switch():
+    """FleetPlanner (neupan.forward's order on the device) against the same cycle assembled from the oracle
+    pieces, over cycles that include a robot arriving and a robot switching to its reverse-gear curve."""
+    import torch
+    from neupan_amd.fleet import FleetPlanner
+    from neupan_amd.robot import Robot
+    cfg = CONFIGS["corridor_diff_small"]
+    T, dt = cfg.T, cfg.dt
+    robot = Robot(T, dt, **cfg.robot)
+    from helpers import ckpt_path
+    fleet = FleetPlanner(robot, T, dt, 4.0, dune_checkpoint=ckpt_path(cfg.checkpoint), iter_num=2, dune_max_num=200,
+                         nrmp_max_num=cfg.nrmp_max_num, iter_threshold=0.0, adjust_kwargs=dict(cfg.adjust))
+    line = lambda n, step, y, gear, x0=0.0, sgn=1.0: [np.array([[x0 + sgn * i * step], [y], [0.0], [gear]]) for i in range(n)]
+    paths = [line(60, 0.4, 0.0, 1.0),                                         # ordinary
+             line(5, 0.4, 0.5, 1.0),                                          # short: the robot arrives
+             line(6, 0.4, -0.5, 1.0) + line(30, 0.4, -0.5, -1.0, x0=2.0, sgn=-1.0)]   # forward, then reverse gear
+    fleet.set_paths(paths)
+    B = 3
+    orcs = [make_oracle(cfg, iter_num=2, dune_max_num=200) for _ in range(B)]
+    curve_idx = [0, 0, 0]; pidx = [0, 0, 0]; arrived = [False] * B
+    curve_lists = [FleetPlanner._split_by_gear(p) for p in paths]
+    intervals = [FleetPlanner._average_interval(p) for p in paths]
+    prev_u = [np.zeros((2, T)) for _ in range(B)]
+    poses = np.array([[0.0, 0.05, 0.0], [1.55, 0.52, 0.0], [1.9, -0.48, 0.0]])
+    rng = np.random.default_rng(0)
+    pts = np.stack([np.stack([rng.uniform(2, 12, 150), rng.choice([-1, 1], 150) * rng.uniform(2.5, 4.0, 150)]) for _ in range(B)]).astype(np.float32)
+    f32 = lambda a: np.asarray(a, dtype=np.float32)
+    for cyc in range(4):
+        act, info = fleet.forward(poses, torch.from_numpy(pts))
+        act = act.cpu().numpy()
+        for b in range(B):
+            curve = curve_lists[b][curve_idx[b]]
+            pidx[b], _, arr = fo.path_progress(curve, pidx[b], poses[b])
+            if arr and not arrived[b]:
+                if curve_idx[b] + 1 >= len(curve_lists[b]):
+                    arrived[b] = True
+                else:
+                    curve_idx[b] += 1; pidx[b] = 0
+                    curve = curve_lists[b][curve_idx[b]]
+            n_s, n_u, r_s, r_us = fo.generate_nom_ref_state(curve, pidx[b], intervals[b], poses[b], prev_u[b], 4.0, T, dt, "diff", 0.0)
+            so, uo, do = orcs[b].forward(f32(n_s), f32(n_u), f32(r_s), f32(r_us), pts[b])
+            want = np.zeros(2) if arrived[b] or orcs[b].min_distance < 0.1 else uo[:, 0]
+            assert bool(info["arrive"][b]) == arrived[b], (cyc, b)
+            assert np.abs(act[b] - want).max() <= 1e-4, (cyc, b, act[b], want)
+            if not arrived[b]:
+                prev_u[b] = f32(uo)
+        for b in range(B):
+            v, w = float(act[b, 0]), float(act[b, 1])
+            poses[b] += dt * np.array([v * np.cos(poses[b, 2]), v * np.sin(poses[b, 2]), w])
+    assert arrived[1] and curve_idx[2] == 1            # the scenario exercised both events

@@ -38,6 +38,11 @@ def _scan_cases():
                       velocity_v=z[n + "/velocity_v"])
 
 
+def _progress_cases():
+    z = np.load(os.path.join(HERE, "golden", "frontend_progress.npz"))
+    return z["rows"], [z[f"curve{i}"] for i in range(4)]
+
+
 NOMINAL = list(_nominal_cases())
 SCANS = list(_scan_cases())
 
@@ -64,6 +69,15 @@ def test_oracle_scan_vs_reference(name, c):
     assert np.abs(p - c["points"]).max() <= 1e-12 * max(1.0, np.abs(c["points"]).max())
     assert np.abs(pv - c["points_v"]).max() <= 1e-12 * max(1.0, np.abs(c["points_v"]).max())
     assert np.array_equal(vv, c["velocity_v"])
+
+
+def test_oracle_path_progress_vs_reference():
+    rows, curves = _progress_cases()
+    for r in rows:
+        ci, k0, sx, sy, thr, rng_i, a_thr, a_idx, want_idx, want_md, want_arr = r
+        idx, md, arr = fo.path_progress(curves[int(ci)], int(k0), [sx, sy, 0.0], thr, int(rng_i), a_thr, int(a_idx))
+        assert idx == int(want_idx) and bool(arr) == bool(want_arr)
+        assert (np.isinf(md) and np.isinf(want_md)) or abs(md - want_md) <= 1e-13
 
 
 # ------------------------------------------------------------------------------ HIP path (-m gpu)
@@ -209,3 +223,20 @@ def test_hip_scan_ragged_batch_vs_oracle():
             continue
         assert cnt[b] == o.shape[1]
         assert np.abs(pts[b, :, :cnt[b]] - o.astype(np.float32)).max() <= _ulp32(o)
+
+
+@pytest.mark.gpu
+def test_hip_path_progress_vs_reference_vectors():
+    from neupan_amd.frontend import NominalBatch
+    rows, curves = _progress_cases()
+    # one call per distinct parameter set (the thresholds are per call, like the reference's attributes)
+    keys = sorted({tuple(r[4:8]) for r in rows})
+    for key in keys:
+        sel = [r for r in rows if tuple(r[4:8]) == key]
+        nb = NominalBatch(10, 0.1, "diff")
+        nb.set_curves([curves[int(r[0])] for r in sel], 0.4, [int(r[1]) for r in sel])
+        pidx, md, arr = nb.progress(np.array([[r[2], r[3], 0.0] for r in sel]), key[0], int(key[1]), key[2], int(key[3]))
+        pidx, md, arr = pidx.cpu().numpy(), md.cpu().numpy(), arr.cpu().numpy()
+        for j, r in enumerate(sel):
+            assert pidx[j] == int(r[8]) and bool(arr[j]) == bool(r[10])
+            assert abs(md[j] - np.float32(r[9])) <= 1e-6
