@@ -63,7 +63,29 @@ def measure(B=256, T=10, beams=1080, cpu_sample=16):
         fo.scan_to_point(poses[b], ranges[b], -np.pi, np.pi, 0.1, 10.0)
     scan_cpu_us = (time.perf_counter() - t0) / cpu_sample * 1e6
     scan_bytes = B * (beams * 8 + int(0.8 * beams) * 8 + 104)
+    # ---- a whole control cycle (neupan.forward's order) for B robots: reference defaults iter_num = 2,
+    #      <= 200 points (planner.yaml of the corridor example), 1080-beam scans
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import CONFIGS, ckpt_path
+    from neupan_amd.fleet import FleetPlanner
+    from neupan_amd.robot import Robot
+    cfg = CONFIGS["corridor_diff_small"]
+    robot = Robot(cfg.T, cfg.dt, **cfg.robot)
+    fleet = FleetPlanner(robot, cfg.T, cfg.dt, 4.0, dune_checkpoint=ckpt_path(cfg.checkpoint), iter_num=2, dune_max_num=200,
+                         nrmp_max_num=cfg.nrmp_max_num, iter_threshold=0.1, adjust_kwargs=dict(cfg.adjust))
+    fleet.set_paths([[np.array([[i * 0.4], [0.3 * (b % 5) - 0.6], [0.0], [1.0]]) for i in range(80)] for b in range(B)])
+    fposes = np.column_stack([rng.uniform(0, 2, B), rng.uniform(-0.6, 0.6, B), rng.uniform(-0.1, 0.1, B)])
+
+    def cycle():
+        pts, npts = fleet.scan_to_point(fposes, r_d, -np.pi, np.pi, 0.1, 10.0, max_points=1080)
+        fleet.forward(fposes, pts, None, npts)
+    cyc_us = _time_gpu(cycle, reps=20)
     return {
+        "fleet_cycle": {"robots": B, "us_per_cycle": round(cyc_us, 1), "robot_cycles_per_s": round(B / cyc_us * 1e6),
+                        "what": "scan->points, path progress, nominal rollout, PAN (K=2, <=200 of 1080 scan points after "
+                                "decimation, default iter_threshold), stop test; includes one host read of the arrival flags",
+                        "reference": "README: ~15 Hz per robot on an i7 CPU"},
         "nominal_ref_states": {"scenes": B, "T": T, "us_per_call": round(nom_us, 1),
                                "scenes_per_s": round(B / nom_us * 1e6), "algorithmic_bytes": nom_bytes,
                                "hbm_GBps": round(nom_bytes / nom_us * 1e-3, 3),
