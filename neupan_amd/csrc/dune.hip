@@ -481,6 +481,9 @@ void dune_kernel(
   }
 }
 
+// candidates kept in the compact list; LDS per slice stays < 9 KB so that all (T+1) slices of a CU's scenes are resident
+#define SEL_CAND_MAX 224
+
 // ---- launch 2: the M nearest of a slice, one wave per slice -----------------------------------------
 template <int E>
 __global__ __launch_bounds__(64, 4) void select_kernel(
@@ -488,13 +491,15 @@ __global__ __launch_bounds__(64, 4) void select_kernel(
     const float* __restrict__ points, const float* __restrict__ vel, const int* __restrict__ n_points,
     const int* __restrict__ flags, const unsigned* __restrict__ gkeys, int key_stride,
     float* __restrict__ mu_sorted, float* __restrict__ lam_sorted, float* __restrict__ pts_sorted,
-    float* __restrict__ dist_sorted, int* __restrict__ count, int scene0, int t0) {
+    float* __restrict__ dist_sorted, int* __restrict__ count, int scene0, int t0, int approx_keys) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* vec = smem;                       // [11][32]
   float* w6 = vec + 11 * 32;               // [8][32]
   float* b6 = w6 + 8 * 32;                 // [8]
-  int* sel = reinterpret_cast<int*>(b6 + 8);            // [NPA_MAX_M]
-  unsigned* dkey = reinterpret_cast<unsigned*>(sel + NPA_MAX_M);   // [n_use]
+  int* sel = reinterpret_cast<int*>(b6 + 8);            // [NPA_MAX_M = 32]: the candidates of this slice
+  int* cand = sel + NPA_MAX_M;                           // [SEL_CAND_MAX]: points within the margin of the M-th key
+  unsigned* ckey = reinterpret_cast<unsigned*>(cand + SEL_CAND_MAX);   // [NPA_MAX_M + SEL_CAND_MAX] exact keys of the candidates
+  unsigned* dkey = ckey + NPA_MAX_M + SEL_CAND_MAX;      // [n_use]
   const int t = blockIdx.x + t0, b = blockIdx.y + scene0, lane = threadIdx.x;
   const int j = lane & 31, hf = lane >> 5;
   const int T = P.T, M = P.M;
@@ -520,25 +525,101 @@ __global__ __launch_bounds__(64, 4) void select_kernel(
   WSYNC();
 
   const int msel = n_use < M ? n_use : M;
-  for (int m = 0; m < msel; ++m) {
-    unsigned long long best = ~0ull;
-    for (int n = lane; n < n_use; n += 64) best = umin64(best, ((unsigned long long)dkey[n] << 32) | (unsigned)n);
-    best = wave_min_u64(best);
-    const int idx = (int)(best & 0xFFFFFFFFu);
-    if (lane == 0) { sel[m] = idx; dkey[idx] = 0xFFFFFFFFu; }
+  unsigned last_key = 0;
+  auto extract = [&]() {                      // the msel smallest (key, index) pairs -> sel[0..msel)
+    for (int m = 0; m < msel; ++m) {
+      unsigned long long best = ~0ull;
+      for (int n = lane; n < n_use; n += 64) best = umin64(best, ((unsigned long long)dkey[n] << 32) | (unsigned)n);
+      best = wave_min_u64(best);
+      const int idx = (int)(best & 0xFFFFFFFFu);
+      last_key = (unsigned)(best >> 32);
+      if (lane == 0) { sel[m] = idx; dkey[idx] = 0xFFFFFFFFu; }
+      WSYNC();
+    }
+  };
+  extract();
+  // Split-precision keys (fp16x2, measured error <= 5e-6 at 30 m, i.e. 1.6e-7 relative) decide only WHO is a
+  // candidate: besides the msel smallest, every point whose key lies within 2e of the msel-th, e = 2e-5 + 1e-5|d|
+  // (>= 60x the measured error).  If |key - exact| <= e then the exact msel nearest are among the candidates;
+  // they are re-encoded exactly below and ranked on the exact (distance, index) key.
+  int ncand = msel, fellback = 0;
+  if (approx_keys && msel == M && n_use > M && last_key < 0xFFFFFFFEu) {
+    const float dM = __uint_as_float((last_key & 0x80000000u) ? (last_key & 0x7FFFFFFFu) : ~last_key);
+    const unsigned thr = ordered_key(dM + 2.0f * (2e-5f + 1e-5f * fabsf(dM)));
+    int extra = 0;                                              // points besides the msel extracted ones
+    for (int n0 = 0; n0 < n_use; n0 += 64) {
+      const int n = n0 + lane;
+      const bool hit = n < n_use && dkey[n] <= thr;            // extracted entries are 0xFFFFFFFF
+      const unsigned long long bal = __ballot(hit);
+      const int pos = extra + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+      if (hit && pos < SEL_CAND_MAX) cand[pos] = n;
+      extra += __popcll(bal);
+    }
     WSYNC();
+    if (msel + extra <= NPA_MAX_M) {                            // the usual case: everything fits one tile
+      if (lane < extra) sel[msel + lane] = cand[lane];
+      ncand = msel + extra;
+      WSYNC();
+    } else {
+      // more candidates than one tile (many points within 2e of the M-th nearest, e.g. a cluster of exact
+      // zeros inside the robot): give the candidates -- or, beyond SEL_CAND_MAX of them, the whole slice --
+      // exact keys and extract the msel smallest again
+      fellback = 1;
+      const bool all = extra > SEL_CAND_MAX;
+      const int total = all ? n_use : msel + extra;
+      auto cand_index = [&](int q) { return all ? q : (q < msel ? sel[q] : cand[q - msel]); };
+      for (int q0 = 0; q0 < total; q0 += 32) {
+        const int q = q0 + j, qc = q < total ? q : total - 1;
+        const int idx = cand_index(qc);
+        float mu_[E], gx_, gy_, lx_, ly_, d_;
+        point_features<E, false>(P, F, W, nullptr, vec, w6, b6, px_row, py_row, vx_row, vy_row,
+                                 src_index(idx, n_raw, n_use), lane, mu_, gx_, gy_, lx_, ly_, d_);
+        if (hf == 0 && q < total) {
+          if (all) dkey[idx] = ordered_key(d_);
+          else ckey[q] = ordered_key(d_);                       // compact: exact key of candidate q
+        }
+      }
+      WSYNC();
+      if (all) {
+        extract();
+      } else {
+        // the msel smallest exact (key, index) pairs among the candidates
+        int mine[(NPA_MAX_M + SEL_CAND_MAX + 63) / 64];
+#pragma unroll
+        for (int r = 0; r < (NPA_MAX_M + SEL_CAND_MAX + 63) / 64; ++r) mine[r] = (lane + 64 * r < total) ? cand_index(lane + 64 * r) : 0;
+        WSYNC();
+        for (int m2 = 0; m2 < msel; ++m2) {
+          unsigned long long best = ~0ull;
+#pragma unroll
+          for (int r = 0; r < (NPA_MAX_M + SEL_CAND_MAX + 63) / 64; ++r) {
+            const int q = lane + 64 * r;
+            if (q < total) best = umin64(best, ((unsigned long long)ckey[q] << 32) | (unsigned)mine[r]);
+          }
+          best = wave_min_u64(best);
+          const int idx = (int)(best & 0xFFFFFFFFu);
+          // retire the winner: the lane that holds it marks its compact slot
+#pragma unroll
+          for (int r = 0; r < (NPA_MAX_M + SEL_CAND_MAX + 63) / 64; ++r) {
+            const int q = lane + 64 * r;
+            if (q < total && mine[r] == idx) ckey[q] = 0xFFFFFFFFu;
+          }
+          WSYNC();
+          if (lane == 0) sel[m2] = idx;
+        }
+        WSYNC();
+      }
+      ncand = msel;
+    }
   }
-  // re-encode the selected points and emit the sorted rows; rows >= msel replicate row 0
-  const int m = j < msel ? j : 0;
+  // re-encode the candidates exactly and emit the msel nearest as sorted rows; rows >= msel replicate row 0
+  const int cj = j < ncand ? j : 0;
   float mu[E], gx, gy, lx, ly, dist;
   point_features<E, false>(P, F, W, nullptr, vec, w6, b6, px_row, py_row, vx_row, vy_row,
-                           src_index(sel[m], n_raw, n_use), lane, mu, gx, gy, lx, ly, dist);
-  // The winners were ranked on the split-precision keys; order the (at most 32) exact rows by
-  // their exact (distance, index) key so that the emitted rows are ascending in the fp32 result.
-  const unsigned long long kx = (j < msel) ? (((unsigned long long)ordered_key(dist) << 32) | (unsigned)sel[m]) : ~0ull;
+                           src_index(sel[cj], n_raw, n_use), lane, mu, gx, gy, lx, ly, dist);
+  const unsigned long long kx = (j < ncand) ? (((unsigned long long)ordered_key(dist) << 32) | (unsigned)sel[cj]) : ~0ull;
   int rank = 0;
-  for (int i = 0; i < msel; ++i) rank += readlane_u64(kx, i) < kx ? 1 : 0;
-  if (hf == 0 && j < msel) {
+  for (int i = 0; i < ncand; ++i) rank += readlane_u64(kx, i) < kx ? 1 : 0;
+  if (hf == 0 && j < ncand && rank < msel) {
     size_t o = orow * M + rank;
 #pragma unroll
     for (int e = 0; e < E; ++e) mu_sorted[o * E + e] = mu[e];
@@ -548,7 +629,7 @@ __global__ __launch_bounds__(64, 4) void select_kernel(
   }
   // rows >= msel replicate the nearest row (padding rule of nrmp.py:258-259): the lane holding it
   // (rank 0) writes the copies
-  if (hf == 0 && j < msel && rank == 0) {
+  if (hf == 0 && j < ncand && rank == 0) {
     for (int q = msel; q < M; ++q) {
       size_t o = orow * M + q;
 #pragma unroll
@@ -558,7 +639,7 @@ __global__ __launch_bounds__(64, 4) void select_kernel(
       dist_sorted[o] = dist;
     }
   }
-  if (lane == 0) count[orow] = msel;
+  if (lane == 0) count[orow] = approx_keys == 2 ? (msel | (ncand << 8) | (fellback << 16)) : msel;
 }
 
 // ---- host-side launchers (called from c_api.hip) --------------------------------------------------
@@ -637,12 +718,13 @@ extern "C" hipError_t npa_launch_select(const DevParams& P, const float* wpack, 
                                         int* count, hipStream_t stream) {
   const int nsl = P.T + 1 - t0;
   const int tps = tiles_per_slice(P, n_stride);
-  const size_t shmem = (11 * 32 + 8 * 32 + 8) * sizeof(float) + NPA_MAX_M * sizeof(int) +
+  static const int approx = getenv("NPA_DUNE_FP32KEYS") != nullptr ? 0 : (getenv("NPA_SEL_DEBUG") ? 2 : (getenv("NPA_SEL_NOMARGIN") ? 0 : 1));      // the keys are split-precision ones
+  const size_t shmem = (11 * 32 + 8 * 32 + 8) * sizeof(float) + (2 * NPA_MAX_M + 2 * SEL_CAND_MAX) * sizeof(int) +
                        ((size_t)tps * 32 * sizeof(unsigned) + 15) / 16 * 16;
 #define LAUNCH(EE)                                                                                                  \
   hipLaunchKernelGGL(select_kernel<EE>, dim3(nsl, batch), dim3(64), shmem, stream, P, wpack, n_stride, cur_s, points, \
                      vel, n_points, flags, gkeys, tps * 32, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count,  \
-                     scene0, t0)
+                     scene0, t0, approx)
   switch (P.E) {
     case 3: LAUNCH(3); break;
     case 4: LAUNCH(4); break;

@@ -337,3 +337,24 @@ def test_coalesced_batches_equal_sequential():
         o = ref.forward_batch(*inputs[j])
         assert np.array_equal(o["opt_u"].cpu().numpy(), outs[j]["opt_u"].cpu().numpy()), j
         assert np.array_equal(o["min_distance"].cpu().numpy(), outs[j]["min_distance"].cpu().numpy()), j
+
+
+def test_split_key_selection_equals_exact_key_selection():
+    """The fp16x2 distance keys only nominate candidates (select_kernel re-encodes every point within a margin
+    of the M-th key exactly and ranks on the exact result), so the emitted rows must be BITWISE those of the
+    exact-fp32-key build on every slice.  The exact-key run happens in a subprocess (the key mode is read once
+    per process from NPA_DUNE_FP32KEYS)."""
+    import os, subprocess, sys, tempfile
+    from gpu_helpers import make_gpu_pan
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(tempfile.mkdtemp(), "exact.npz")
+    env = dict(os.environ, NPA_DUNE_FP32KEYS="1")
+    subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "key_check.py"), out, "192"], check=True, env=env,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=root)
+    exact = np.load(out)
+    cfg = CONFIGS["diff_1k_T10_K10"]
+    pan = make_gpu_pan(cfg)
+    batch = make_batch(cfg, 1000, 192)
+    r = {k: v.cpu().numpy() for k, v in pan.dune_stage(batch["nom_s"], batch["points"]).items()}
+    for k in ("mu", "lam", "pts", "dist", "count"):
+        assert np.array_equal(r[k], exact[k]), k
