@@ -167,13 +167,18 @@ int npa_nrmp_stage(npa_handle *h, int batch, const float *nom_s, const float *no
  * the KKT system).  Covers the direct dependence of THIS solve on (q_s[3], p_u, eta, d_max, d_min),
  * including their appearance in gamma_a = q_s*ref_s and gamma_b = p_u*ref_us (nrmp.py:158-160).
  *   grad_s [B][3][T+1], grad_u [B][2][T], grad_d [B][T] (may be NULL): dL/d(opt_s, opt_u, opt_d);
- *   grad_theta [B][8]: dL/d q_s[0..2], p_u, eta, d_max, d_min, and the solver status (0 = converged). */
+ *   grad_theta [B][8]: dL/d q_s[0..2], p_u, eta, d_max, d_min, and the solver status (0 = converged);
+ *   grad_nom_s [B][3][T+1] (may be NULL): dL/d nom_s as the PROXIMAL CENTRE of this solve (robot.py:178), the one
+ *   input besides theta that the reference keeps on its autograd graph between PAN iterations (A/B/C are rebuilt
+ *   from python floats, robot.py:272-316; mu under no_grad, dune.py:81; R from python floats, pan.py:207).
+ *   Feeding it back as grad_s of the previous iteration's solve (grad_u = 0) chains the gradient through the
+ *   whole PAN loop, as PAN.forward_batch_grad does. */
 int npa_nrmp_backward(npa_handle *h, int batch, const float *nom_s, const float *nom_u,
                       const float *ref_s, const float *ref_us, const float *mu_sorted,
                       const float *lam_sorted, const float *pts_sorted, const int32_t *count,
                       float *out_s, float *out_u, float *out_d, const float *grad_s,
                       const float *grad_u, const float *grad_d, float *grad_theta,
-                      double *qp_info, void *stream);
+                      float *grad_nom_s, double *qp_info, void *stream);
 
 /* Timing hook for bench.py: enqueue HIP events around every DUNE-stage launch of
  * subsequent npa_forward_batch calls (on the launch stream) and read back the average

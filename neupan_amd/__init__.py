@@ -1,6 +1,6 @@
 """neupan_amd -- MI355X-native PAN inner solver (drop-in for neupan.blocks.PAN).
 
-    from neupan_amd import PAN, Robot, FleetPlanner, NominalBatch, scan_to_point_batch, DuneTrain
+    from neupan_amd import neupan, PAN, Robot, FleetPlanner, NominalBatch, scan_to_point_batch, DuneTrain
 """
 from .robot import Robot  # noqa: F401
 from .scenes import CONFIGS, SceneConfig, make_batch, make_scene  # noqa: F401
@@ -10,7 +10,7 @@ _LAZY = {"PAN": ("pan", "PAN"), "forward_interleaved": ("pan", "forward_interlea
          "FleetPlanner": ("fleet", "FleetPlanner"), "NominalBatch": ("frontend", "NominalBatch"),
          "scan_to_point_batch": ("frontend", "scan_to_point_batch"),
          "scan_to_point_velocity_batch": ("frontend", "scan_to_point_velocity_batch"),
-         "DuneTrain": ("dune_train", "DuneTrain")}      # (dune_labels.dune_labels: import it from its module)
+         "DuneTrain": ("dune_train", "DuneTrain"), "neupan": ("planner", "neupan")}      # (dune_labels.dune_labels: import it from its module)
 
 
 def __getattr__(name):

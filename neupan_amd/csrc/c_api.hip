@@ -359,18 +359,18 @@ extern "C" hipError_t npa_launch_qp_backward(const DevParams& P, int batch, cons
                                              const float* lam_sorted, const float* pts_sorted, const int* count,
                                              float* out_s, float* out_u, float* out_d, const float* grad_s,
                                              const float* grad_u, const float* grad_d, float* grad_theta,
-                                             double* qp_info, hipStream_t stream);
+                                             float* grad_nom_s, double* qp_info, hipStream_t stream);
 extern "C" int npa_nrmp_backward(npa_handle* h, int batch, const float* nom_s, const float* nom_u, const float* ref_s,
                                  const float* ref_us, const float* mu_sorted, const float* lam_sorted,
                                  const float* pts_sorted, const int32_t* count, float* out_s, float* out_u, float* out_d,
                                  const float* grad_s, const float* grad_u, const float* grad_d, float* grad_theta,
-                                 double* qp_info, void* stream) {
+                                 float* grad_nom_s, double* qp_info, void* stream) {
   if (!h || batch < 1 || !nom_s || !nom_u || !ref_s || !ref_us || !out_s || !out_u || !grad_s || !grad_u || !grad_theta)
     return fail(NPA_E_ARG, "npa_nrmp_backward: bad argument");
   if (h->P.M > 0 && (!mu_sorted || !lam_sorted || !pts_sorted || !count || !out_d))
     return fail(NPA_E_ARG, "npa_nrmp_backward: obstacle arrays required when nrmp_max_num > 0");
   HIP_TRY(npa_launch_qp_backward(h->P, batch, nom_s, nom_u, ref_s, ref_us, mu_sorted, lam_sorted, pts_sorted, count,
-                                 out_s, out_u, out_d, grad_s, grad_u, grad_d, grad_theta, qp_info, (hipStream_t)stream));
+                                 out_s, out_u, out_d, grad_s, grad_u, grad_d, grad_theta, grad_nom_s, qp_info, (hipStream_t)stream));
   return NPA_OK;
 }
 

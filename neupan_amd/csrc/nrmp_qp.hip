@@ -107,6 +107,7 @@ struct QpBackward {
   const float* grad_u;      // [B][2][T]    dL/d opt_u
   const float* grad_d;      // [B][T]       dL/d opt_d (may be null)
   float* grad_theta;        // [B][8]       q_s[0..2], p_u, eta, d_max, d_min, (status)
+  float* grad_nom_s;        // [B][3][T+1]  dL/d(proximal centre) = bk Phi v, column 0 = 0 (may be null)
 };
 
 template <int TT, int MM, bool BWD = false>
@@ -828,6 +829,15 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
           gp += dxu[2 * t] * (xu[2 * t] - refu);
           if (obs) { ge += dxd[t]; gmx += dld[2 * t]; gmn += dld[2 * t + 1]; }
         }
+        if (bw.grad_nom_s) {
+          // the only input of this solve that the reference keeps on its autograd graph besides theta:
+          // para_s in 0.5 bk |s - para_s|^2 (robot.py:178); d(Hx+g)/dpara_s[:,t] = -bk Phi_t'
+          float* gn = bw.grad_nom_s + (size_t)b * 3 * (T + 1);
+          for (int q = lane; q < 3 * (T + 1); q += QP_THREADS) {
+            int k = q / (T + 1), t = q - k * (T + 1);
+            gn[q] = (t == 0) ? 0.f : (float)((double)P.bk * s3[(t - 1) * 3 + k]);
+          }
+        }
         g0 = wave_reduce<OpSum>(g0); g1 = wave_reduce<OpSum>(g1); g2 = wave_reduce<OpSum>(g2);
         gp = wave_reduce<OpSum>(gp); ge = wave_reduce<OpSum>(ge);
         gmx = wave_reduce<OpSum>(gmx); gmn = wave_reduce<OpSum>(gmn);
@@ -1023,7 +1033,7 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
                      ref_s, ref_us, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count, cur_s_out, cur_u_out, \
                      cur_d_out, out_s, out_u, out_d, out_min_distance, out_iters, out_nrmp_points, flags, state, \
                      qp_info, warm, scene0, batch, wave_doubles, low_prio ? -wpg : wpg,                         \
-                     QpBackward{nullptr, nullptr, nullptr, nullptr})
+                     QpBackward{nullptr, nullptr, nullptr, nullptr, nullptr})
   if (P.T == 10 && P.M == 10 && !force_generic) QP_LAUNCH(10, 10);
   else if (P.T == 20 && P.M == 10 && !force_generic) QP_LAUNCH(20, 10);
   else QP_LAUNCH(0, 0);
@@ -1037,7 +1047,7 @@ extern "C" hipError_t npa_launch_qp_backward(const DevParams& P, int batch, cons
                                              const float* lam_sorted, const float* pts_sorted, const int* count,
                                              float* out_s, float* out_u, float* out_d, const float* grad_s,
                                              const float* grad_u, const float* grad_d, float* grad_theta,
-                                             double* qp_info, hipStream_t stream) {
+                                             float* grad_nom_s, double* qp_info, hipStream_t stream) {
   const size_t wave_bytes = npa_qp_shmem_bytes(P.T, P.M);
   static bool attr_set = false;
   if (!attr_set) {
@@ -1048,6 +1058,6 @@ extern "C" hipError_t npa_launch_qp_backward(const DevParams& P, int batch, cons
                      ref_us, mu_sorted, lam_sorted, pts_sorted, (const float*)nullptr, count, out_s, out_u, out_d,
                      (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int*)nullptr, (float*)nullptr,
                      (int*)nullptr, (float*)nullptr, qp_info, (double*)nullptr, 0, batch,
-                     (int)(wave_bytes / sizeof(double)), 1, QpBackward{grad_s, grad_u, grad_d, grad_theta});
+                     (int)(wave_bytes / sizeof(double)), 1, QpBackward{grad_s, grad_u, grad_d, grad_theta, grad_nom_s});
   return hipGetLastError();
 }

@@ -100,11 +100,17 @@ class FleetPlanner:
         # 2. nominal / reference states from the previous plan
         nom_s, nom_u, ref_s, ref_us = self.nb.generate_nom_ref_state(st, self.cur_vel, self.ref_speed)
         # 3. PAN
-        out = self.pan.forward_batch(nom_s, nom_u, ref_s, ref_us, points, velocities, n_points)
+        if any(p.requires_grad for p in self.pan.nrmp_layer.adjust_parameters):
+            # LON use (example/LON/LON_corridor.py:94-127): the plan stays connected to the adjust parameters
+            gs, gu, gd = self.pan.forward_batch_grad(nom_s, nom_u, ref_s, ref_us, points, velocities, n_points)
+            out = dict(self.pan.last_out, opt_s=gs, opt_u=gu, opt_d=None if self.pan.no_obs else gd)
+        else:
+            out = self.pan.forward_batch(nom_s, nom_u, ref_s, ref_us, points, velocities, n_points)
         opt_u = out["opt_u"]
         done = torch.from_numpy(self.arrived.copy()).to(dev)
         # 4. warm start (arrived robots keep theirs: the reference returns before this line)
-        self.cur_vel = opt_u if self.cur_vel is None else torch.where(done[:, None, None], self.cur_vel, opt_u)
+        warm = opt_u.detach()
+        self.cur_vel = warm if self.cur_vel is None else torch.where(done[:, None, None], self.cur_vel, warm)
         # 5. stop test and action
         md = out["min_distance"]
         stop = md < self.collision_threshold

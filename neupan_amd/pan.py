@@ -328,6 +328,7 @@ class PAN(torch.nn.Module):
             else:
                 check(self._lib.npa_forward_end_on(self._h, C.c_void_p(join_stream.cuda_stream)), "npa_forward_end_on")
         out, self._pending = self._pending, None
+        self.last_out = out
         return out
 
     def forward_batch(self, nom_s, nom_u, ref_s, ref_us, points=None, velocities=None, n_points=None):
@@ -426,7 +427,8 @@ class PAN(torch.nn.Module):
     def nrmp_backward(self, nom_s, nom_u, ref_s, ref_us, stage, grad_s, grad_u, grad_d=None):
         """One NRMP solve plus dL/d(q_s[3], p_u, eta, d_max, d_min) per scene for upstream gradients
         (grad_s (B,3,T+1), grad_u (B,2,T), grad_d (B,1,T)|None).  Returns dict(opt_s, opt_u, opt_d,
-        grad (B,8): q_s[0..2], p_u, eta, d_max, d_min, solver status)."""
+        grad (B,8): q_s[0..2], p_u, eta, d_max, d_min, solver status; grad_nom_s (B,3,T+1): dL/d(the proximal
+        centre), the upstream grad_s of the previous PAN iteration's solve)."""
         T = self.T
         nom_s = self._dev(nom_s)
         B = nom_s.shape[0]
@@ -438,22 +440,25 @@ class PAN(torch.nn.Module):
         out_u = torch.empty((B, 2, T), dtype=torch.float32, device=dev)
         out_d = torch.empty((B, 1, T), dtype=torch.float32, device=dev)
         gth = torch.zeros((B, 8), dtype=torch.float32, device=dev)
+        gns = torch.zeros((B, 3, T + 1), dtype=torch.float32, device=dev)
         g = (lambda k: _ptr(stage[k])) if stage is not None else (lambda k: None)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             check(self._lib.npa_nrmp_backward(self._h, B, _ptr(nom_s), _ptr(nom_u), _ptr(ref_s), _ptr(ref_us), g("mu"),
                                               g("lam"), g("pts"), g("count"), _ptr(out_s), _ptr(out_u), _ptr(out_d),
-                                              _ptr(gs), _ptr(gu), _ptr(gd), _ptr(gth), None, C.c_void_p(stream)),
+                                              _ptr(gs), _ptr(gu), _ptr(gd), _ptr(gth), _ptr(gns), None, C.c_void_p(stream)),
                   "npa_nrmp_backward")
-        return dict(opt_s=out_s, opt_u=out_u, opt_d=out_d, grad=gth)
+        return dict(opt_s=out_s, opt_u=out_u, opt_d=out_d, grad=gth, grad_nom_s=gns)
 
     def forward_batch_grad(self, nom_s, nom_u, ref_s, ref_us, points=None, velocities=None, n_points=None):
         """`forward_batch` whose outputs are connected to `nrmp_layer.adjust_parameters` for autograd, as the
         reference's are through cvxpylayers (nrmp.py:79-95, :144; example/LON/LON_corridor.py:94-127):
         `loss(opt_s, opt_u, opt_d).backward()` fills `.grad` of q_s, p_u, eta, d_max, d_min (make them
-        `requires_grad_(True)` leaves first).  The gradient is that of the LAST NRMP solve of the PAN loop
-        (implicit differentiation of its KKT system, npa_nrmp_backward); the reference's recurrent terms
-        through the proximal centre nom_s and lam(R(nom_s)) of earlier iterations are not propagated.
+        `requires_grad_(True)` leaves first).  The gradient follows the reference's autograd graph through the
+        whole PAN loop: every executed NRMP solve contributes its direct dependence on the parameters (implicit
+        differentiation of its KKT system, npa_nrmp_backward) and hands dL/d(its proximal centre) to the solve of
+        the iteration before -- the one recurrent path the reference keeps (A/B/C, mu, lam are detached there:
+        robot.py:272-316, dune.py:81, pan.py:207).  `recurrent=False` on the planner keeps only the last solve.
         Returns (opt_s (B,3,T+1), opt_u (B,2,T), opt_d (B,1,T)|None)."""
         f = self.nrmp_layer
         params = [f.q_s, f.p_u, f.eta, f.d_max, f.d_min]
@@ -476,7 +481,8 @@ class PAN(torch.nn.Module):
 
 
 class _PanGrad(torch.autograd.Function):
-    """PAN loop forward on the HIP path; backward = npa_nrmp_backward on a re-run of the last iteration."""
+    """PAN loop forward on the HIP path; backward = npa_nrmp_backward on re-runs of the executed iterations, last
+    to first, chained through the proximal centre."""
 
     @staticmethod
     def forward(ctx, pan, args, q_s, p_u, eta, d_max, d_min):
@@ -484,18 +490,21 @@ class _PanGrad(torch.autograd.Function):
         pan._push_adjust()
         pan.forward_begin(nom_s, nom_u, ref_s, ref_us, points, velocities, n_points)
         B, T = pan._B, pan.T
-        for k in range(pan.iter_num - 1):
-            pan.forward_iter(k)
-        # nominal trajectory the last solve linearises around (cur_s, cur_u at the head of the workspace)
+        # nominal trajectory each solve linearises around (cur_s, cur_u at the head of the workspace)
         wsf = pan._ws.view(torch.float32)
         n_s = B * 3 * (T + 1)
         off_u = (n_s + 3) // 4 * 4
-        snap_s = wsf[:n_s].clone().reshape(B, 3, T + 1)
-        snap_u = wsf[off_u:off_u + B * 2 * T].clone().reshape(B, 2, T)
-        pan.forward_iter(pan.iter_num - 1)
+        first = 0 if getattr(pan, "recurrent", True) else pan.iter_num - 1
+        snaps = []
+        for k in range(pan.iter_num):
+            if k >= first:
+                snaps.append((k, wsf[:n_s].clone().reshape(B, 3, T + 1), wsf[off_u:off_u + B * 2 * T].clone().reshape(B, 2, T)))
+            pan.forward_iter(k)
         out = pan.forward_end()
         ctx.pan = pan
-        ctx.args = (snap_s, snap_u, pan._dev(ref_s), pan._dev(ref_us), points, velocities, n_points)
+        ctx.snaps = snaps
+        ctx.iters = out["iters"].clone()
+        ctx.args = (pan._dev(ref_s), pan._dev(ref_us), points, velocities, n_points)
         ctx.qs_shape = tuple(q_s.shape)
         ctx.no_obs = out["opt_d"] is None
         d = out["opt_d"] if out["opt_d"] is not None else torch.zeros((B, 1, T), device=pan.device)
@@ -504,14 +513,29 @@ class _PanGrad(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gs, gu, gd):
         pan = ctx.pan
-        snap_s, snap_u, ref_s, ref_us, points, velocities, n_points = ctx.args
-        stage = None
-        if not pan.no_obs and points is not None:
-            stage = pan.dune_stage(snap_s, points, velocities, n_points)
-        z = lambda g, ref: torch.zeros_like(ref) if g is None else g
-        r = pan.nrmp_backward(snap_s, snap_u, ref_s, ref_us, stage, z(gs, snap_s), z(gu, snap_u),
-                              None if (gd is None or ctx.no_obs) else gd)
-        g = r["grad"].double().sum(dim=0).float().cpu()
+        ref_s, ref_us, points, velocities, n_points = ctx.args
+        B, T, dev = ctx.iters.shape[0], pan.T, pan.device
+        gs = torch.zeros((B, 3, T + 1), device=dev) if gs is None else gs.contiguous()
+        gu = torch.zeros((B, 2, T), device=dev) if gu is None else gu.contiguous()
+        gd = None if (gd is None or ctx.no_obs) else gd.contiguous()
+        tot = torch.zeros((B, 7), dtype=torch.float64, device=dev)
+        for k, snap_s, snap_u in reversed(ctx.snaps):
+            ran = ctx.iters > k                        # scenes whose stop test ended the loop earlier skip this solve
+            if not bool(ran.any()):
+                continue
+            stage = None
+            if not pan.no_obs and points is not None:
+                stage = pan.dune_stage(snap_s, points, velocities, n_points)
+            r = pan.nrmp_backward(snap_s, snap_u, ref_s, ref_us, stage, gs, gu, gd)
+            tot += torch.where(ran[:, None], r["grad"][:, :7].double(), torch.zeros_like(tot))
+            m = ran[:, None, None]
+            gs = torch.where(m, r["grad_nom_s"], gs)
+            gu = torch.where(m, torch.zeros_like(gu), gu)
+            if gd is not None:
+                gd = torch.where(m, torch.zeros_like(gd), gd)
+            if not bool((gs != 0).any()):
+                break
+        g = tot.sum(dim=0).float().cpu()
         gq = g[0:3].reshape(3, 1) if len(ctx.qs_shape) == 2 else g[0:3].sum().reshape(ctx.qs_shape)
         return None, None, gq, g[3].reshape(()), g[4].reshape(()), g[5].reshape(()), g[6].reshape(())
 

@@ -21,9 +21,18 @@ q_s*ref_s and p_u*ref_us are themselves functions of q_s, p_u -- nrmp.py:158-160
     p_u   : 4 p_u (u_0t - ref_us_t) on entry (0,t)
     eta   : g_d = -eta
     d_max : c of the rows d_t <= d_max;   d_min: c = -max(d_min, 0) of the rows -d_t <= -d_min
-Only this direct dependence of ONE solve is covered: inside PAN.forward the reference's autograd
-also reaches earlier iterations through the proximal centre nom_s and lam(R(nom_s)); those
-recurrent terms are not part of this row.
+    nom_s : the proximal centre, 0.5 bk |s - nom_s|^2 (nrmp.py:350): d(Hx+g)/dnom_s[:,t] = -bk Phi_t^T,
+            so dL/dnom_s[:,t] = bk Phi_t v   (t >= 1; column 0 is the pinned start state)
+
+Recurrence inside PAN.forward (`pan_backward`).  Iteration k+1 receives iteration k's solution as
+nom_s / nom_u (pan.py:137).  What of that stays on the reference's autograd graph:
+  * para_s = nom_s, the proximal centre and the pinned start (robot.py:100, :178, :234)      -- ON the graph
+  * A_t, B_t, C_t: built with torch.Tensor([[python floats]]) (robot.py:272-316)              -- detached
+  * mu: evaluated under torch.no_grad() (dune.py:81); R: torch.tensor([[...]]) (pan.py:207),
+    hence lam, fa, fb                                                                         -- detached
+  * nom_u: only enters A, B, C                                                                -- detached
+So the reference's gradient is the chain  theta -> s_1 -> (prox centre of solve 2) -> s_2 -> ... -> s_K
+plus every solve's direct dependence on theta; `pan_backward` runs it in reverse.
 """
 from __future__ import annotations
 
@@ -60,11 +69,12 @@ def backward_ipm(pb: NrmpProblem, gs, gu, gd, tol=1e-12):
     v = np.linalg.solve(K, gx)
     dc = Dc * (C @ v)
     mask = pb.state_weight()
-    out = dict(q_s=np.zeros(3), p_u=0.0, eta=0.0, d_max=0.0, d_min=0.0)
+    out = dict(q_s=np.zeros(3), p_u=0.0, eta=0.0, d_max=0.0, d_min=0.0, nom_s=np.zeros((3, T + 1)))
     ref = pb.qref_s / np.where(pb.q_s == 0, 1.0, pb.q_s)[:, None]
     for t in range(1, T + 1):
         sv = Phi[t] @ v[:nu]                                   # state image of v
         out["q_s"] += -4.0 * mask * pb.q_s * sv * (s[:, t] - ref[:, t])
+        out["nom_s"][:, t] = pb.bk * sv
     ref_us = pb.puref / (pb.p_u if pb.p_u != 0 else 1.0)
     out["p_u"] = float(-4.0 * pb.p_u * np.sum(v[0:nu:2] * (u[0] - ref_us)))
     if not pb.no_obs:
@@ -103,4 +113,66 @@ def backward_fd(pb: NrmpProblem, gs, gu, gd, eps=1e-6):
                   loss(_with(pb, p_u=pb.p_u - eps, puref=(pb.p_u - eps) * ref_us))) / (2 * eps)
     for k in ("eta", "d_max", "d_min"):
         out[k] = (loss(_with(pb, **{k: getattr(pb, k) + eps})) - loss(_with(pb, **{k: getattr(pb, k) - eps}))) / (2 * eps)
+    out["nom_s"] = np.zeros((3, pb.T + 1))
+    for k in range(3):
+        for t in range(1, pb.T + 1):                      # the proximal centre only: A, B, C, fa, fb stay as recorded
+            def pert(h):
+                n = pb.nom_s.copy(); n[k, t] += h
+                return _with(pb, nom_s=n)
+            out["nom_s"][k, t] = (loss(pert(eps)) - loss(pert(-eps))) / (2 * eps)
+    return out
+
+
+THETA = ("q_s", "p_u", "eta", "d_max", "d_min")
+
+
+def pan_backward(pbs, gs, gu, gd):
+    """Gradient of L(s_K, u_K, d_K) w.r.t. the adjust parameters through ALL solves of one PAN.forward call
+    (`pbs`: the K NrmpProblems in execution order), following the reference's autograd graph (module docstring)."""
+    tot = dict(q_s=np.zeros(3), p_u=0.0, eta=0.0, d_max=0.0, d_min=0.0)
+    for pb in reversed(pbs):
+        r = backward_ipm(pb, gs, gu, gd)
+        for k in THETA:
+            tot[k] = tot[k] + r[k]
+        gs, gu, gd = r["nom_s"], np.zeros_like(np.asarray(gu, dtype=np.float64)), None
+    return tot
+
+
+def pan_backward_fd(pbs, gs, gu, gd, eps=1e-5):
+    """central differences over the same graph: solve k+1's proximal centre moves with solve k's state trajectory
+    (columns 1..T; the fp32 cast between iterations, nrmp.py:145-148, is not differentiated), everything the
+    reference detaches stays as recorded"""
+    ref = pbs[0].qref_s / pbs[0].q_s[:, None]
+    ref_us = pbs[0].puref / pbs[0].p_u
+    th0 = dict(q_s=pbs[0].q_s.copy(), p_u=pbs[0].p_u, eta=pbs[0].eta, d_max=pbs[0].d_max, d_min=pbs[0].d_min)
+    base = [solve_nrmp_qp(pb)[0] for pb in pbs]
+
+    def loss(th):
+        shift = None
+        for pb, s0 in zip(pbs, base):
+            q = np.asarray(th["q_s"], dtype=np.float64)
+            p = _with(pb, q_s=q, qref_s=q[:, None] * ref, p_u=th["p_u"], puref=th["p_u"] * ref_us, eta=th["eta"],
+                      d_max=th["d_max"], d_min=th["d_min"])
+            if shift is not None:
+                n = pb.nom_s.copy(); n[:, 1:] += shift[:, 1:]
+                p.nom_s = n
+            s, u, d = solve_nrmp_qp(p)
+            shift = s - s0
+        L = float(np.sum(gs * s) + np.sum(gu * u))
+        if d is not None and gd is not None:
+            L += float(np.sum(np.asarray(gd).reshape(-1) * np.asarray(d).reshape(-1)))
+        return L
+
+    def diff(key, idx=None):
+        def at(h):
+            th = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in th0.items()}
+            if idx is None:
+                th[key] = th[key] + h
+            else:
+                th[key][idx] += h
+            return loss(th)
+        return (at(eps) - at(-eps)) / (2 * eps)
+    out = dict(q_s=np.array([diff("q_s", i) for i in range(3)]))
+    for k in ("p_u", "eta", "d_max", "d_min"):
+        out[k] = diff(k)
     return out

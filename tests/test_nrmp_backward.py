@@ -71,6 +71,9 @@ def test_hip_gradient_vs_oracle():
         ref = nb.backward_ipm(pb, gs.astype(np.float64), gu.astype(np.float64), gd.astype(np.float64))
         want = np.array([*ref["q_s"], ref["p_u"], ref["eta"], ref["d_max"], ref["d_min"]])
         worst.append(np.abs(g[:7] - want).max() / max(1.0, np.abs(want).max()))
+        gn = r["grad_nom_s"].cpu().numpy()[0]
+        assert np.all(gn[:, 0] == 0)
+        worst.append(np.abs(gn - ref["nom_s"]).max() / max(1.0, np.abs(ref["nom_s"]).max()))
     worst = np.sort(worst)
     # the GPU nominal differs from the oracle's by fp32 rounding; weakly active rows amplify that in the gradient
     assert worst[len(worst) // 2] <= 1e-3 and worst[-1] <= 5e-2, worst
@@ -97,3 +100,64 @@ def test_autograd_fills_adjust_parameter_gradients():
     # same numbers as the plain forward
     out = make_gpu_pan(cfg, iter_num=3).forward_batch(batch["nom_s"], batch["nom_u"], batch["ref_s"], batch["ref_us"], batch["points"])
     assert np.array_equal(out["opt_u"].cpu().numpy(), u.detach().cpu().numpy())
+
+
+def test_oracle_recurrent_gradient_vs_finite_differences():
+    """the chain through the proximal centres of all K solves (what the reference's autograd graph carries,
+    oracle/nrmp_backward.py docstring) against central differences over the same graph"""
+    cfg, data = _problems("diff_1k_T10_K10", range(4), iters=3)
+    rng = np.random.default_rng(5)
+    errs, rec = [], []
+    for sc, orc, pbs in data:
+        assert len(pbs) == 3
+        T = pbs[0].T
+        gs, gu, gd = rng.standard_normal((3, T + 1)), rng.standard_normal((2, T)), rng.standard_normal((1, T))
+        one = nb.backward_ipm(pbs[-1], gs, gu, gd)
+        # single-solve sensitivity to the proximal centre
+        f1 = nb.backward_fd(pbs[-1], gs, gu, gd, 1e-5)
+        errs.append(np.abs(one["nom_s"] - f1["nom_s"]).max() / max(1.0, np.abs(f1["nom_s"]).max()))
+        a, f = nb.pan_backward(pbs, gs, gu, gd), nb.pan_backward_fd(pbs, gs, gu, gd, 1e-5)
+        errs.append(max(np.abs(np.atleast_1d(a[k]) - np.atleast_1d(f[k])).max() / max(1.0, np.abs(np.atleast_1d(f[k])).max())
+                        for k in a))
+        rec.append(max(np.abs(np.atleast_1d(a[k]) - np.atleast_1d(one[k])).max() for k in a))
+    errs = np.sort(errs)
+    assert errs[len(errs) // 2] <= 1e-4 and errs[-1] <= 5e-2, errs
+    assert max(rec) > 1e-3            # the recurrent terms are not negligible: the test exercises them
+
+
+@pytest.mark.gpu
+def test_hip_recurrent_gradient_vs_oracle():
+    """autograd through PAN.forward_batch_grad (all K solves chained through the proximal centre) against
+    oracle.nrmp_backward.pan_backward on the oracle's own K problems of the same scenes"""
+    import torch
+    from gpu_helpers import make_gpu_pan
+    K = 3
+    cfg, data = _problems("diff_1k_T10_K10", range(8), iters=K)
+    rng = np.random.default_rng(2)
+    worst, rec = [], []
+    for sc, orc, pbs in data:
+        T = pbs[0].T
+        gs, gu, gd = (rng.standard_normal((3, T + 1)).astype(np.float32), rng.standard_normal((2, T)).astype(np.float32),
+                      rng.standard_normal((1, T)).astype(np.float32))
+        grads = {}
+        for recurrent in (True, False):
+            pan = make_gpu_pan(cfg, iter_num=K)
+            pan.recurrent = recurrent
+            f = pan.nrmp_layer
+            params = [f.q_s, f.p_u, f.eta, f.d_max, f.d_min]
+            for p in params:
+                p.requires_grad_(True)
+            s, u, d = pan.forward_batch_grad(sc["nom_s"][None], sc["nom_u"][None], sc["ref_s"][None], sc["ref_us"][None],
+                                             sc["points"][None])
+            dev = s.device
+            loss = (s[0] * torch.from_numpy(gs).to(dev)).sum() + (u[0] * torch.from_numpy(gu).to(dev)).sum() + \
+                   (d[0] * torch.from_numpy(gd).to(dev)).sum()
+            loss.backward()
+            grads[recurrent] = np.array([float(p.grad.sum()) for p in params])
+        ref = nb.pan_backward(pbs, gs.astype(np.float64), gu.astype(np.float64), gd.astype(np.float64))
+        want = np.array([ref["q_s"].sum(), ref["p_u"], ref["eta"], ref["d_max"], ref["d_min"]])
+        worst.append(np.abs(grads[True] - want).max() / max(1.0, np.abs(want).max()))
+        rec.append(np.abs(grads[True] - grads[False]).max())
+    worst = np.sort(worst)
+    assert worst[len(worst) // 2] <= 1e-3 and worst[-1] <= 5e-2, worst
+    assert max(rec) > 1e-3                       # the chained terms are there
