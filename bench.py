@@ -226,6 +226,8 @@ def main():
         except Exception:
             traffic = None
 
+    km = pans[0].key_mode()
+    nf16 = 8 if km["key_terms"] == 1 else 24
     line = {
         "metric": "MPC plans/sec (node), diff robot, 1k pts, T=10, K=10; ctrl L2 vs ref" if args.workload == WORKLOAD
                   else f"MPC plans/sec (node), workload {args.workload}; ctrl L2 vs ref",
@@ -239,22 +241,25 @@ def main():
                    "scenes_per_gpu": BATCH, "points": N, "T": T, "K": K, "M": cfg.nrmp_max_num,
                    "batches_in_flight": nfl, "coalesced_per_launch": args.coalesce,
                    "parallelism": f"scene-shard x{world}, RCCL all-gather of controls"},
-        "roofline": {"bound": "mfma", "kernel": f"dune_kernel<{E},true>" if os.environ.get("NPA_DUNE_FP32KEYS") is None else f"dune_kernel<{E},false>",
+        "roofline": {"bound": "mfma", "kernel": f"dune_kernel<{E},{km['key_terms']}>",
                      "note": ("ALGORITHMIC fp32 flops per launch / launch time against the fp32-input MFMA peak (the arithmetic "
-                              "the path is specified in).  The kernel evaluates the four 32x32 layers as fp16x2 split "
-                              "products (3 v_mfma_f32_32x32x16_f16 per fp32 K-step pair, ~2^-22 relative) and re-encodes "
-                              "the emitted rows with the exact fp32 MFMA, so frac can exceed 1; `executed` prices the "
-                              "MFMA flops it really issues against the fp16 peak.  The binding unit is the VALU "
-                              "(LayerNorm/tanh/split: ~550 VALU instructions per 32-point tile), see DESIGN.md")
-                             if os.environ.get("NPA_DUNE_FP32KEYS") is None else "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+                              "the path is specified in).  The kernel computes distance KEYS with the four 32x32 layers as "
+                              + ("single fp16 products (2 v_mfma_f32_32x32x16_f16 per layer)" if km["key_terms"] == 1 else
+                                 "fp16x2 split products (6 v_mfma_f32_32x32x16_f16 per layer)") +
+                              "; the keys only nominate candidates (margin = 6 x the key error measured for the checkpoint at "
+                              "npa_create), the emitted rows are re-encoded with the exact fp32 MFMA, so frac can exceed 1; "
+                              "`executed` prices the MFMA flops it really issues against the fp16 peak.  The binding unit is "
+                              "the VALU (LayerNorm/tanh/conversions), see DESIGN.md")
+                             if km["key_terms"] != 0 else "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+                     "key_mode": km,
                      "achieved": round(achieved, 3),
                      "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                      "traffic": traffic, "flops_per_launch": int(flops_per_launch),
-                     "executed": ({"mfma": "v_mfma_f32_32x32x16_f16 x24 + v_mfma_f32_32x32x2_f32 x1 per tile",
-                                   "tflops": round(achieved * (24 * 32768 + 4096) / (32 * (8320 + 64 * E)), 2),
+                     "executed": ({"mfma": f"v_mfma_f32_32x32x16_f16 x{nf16} + v_mfma_f32_32x32x2_f32 x1 per tile",
+                                   "tflops": round(achieved * (nf16 * 32768 + 4096) / (32 * (8320 + 64 * E)), 2),
                                    "peak": PEAK_F16_MFMA_TFLOPS,
-                                   "frac": round(achieved * (24 * 32768 + 4096) / (32 * (8320 + 64 * E)) / PEAK_F16_MFMA_TFLOPS, 4)}
-                                  if os.environ.get("NPA_DUNE_FP32KEYS") is None else None),
+                                   "frac": round(achieved * (nf16 * 32768 + 4096) / (32 * (8320 + 64 * E)) / PEAK_F16_MFMA_TFLOPS, 4)}
+                                  if km["key_terms"] != 0 else None),
                      "launch_ms": round(prof["dune_ms"], 4), "launches_timed": prof["launches"],
                      "nrmp_qp_launch_ms": round(prof["nrmp_ms"], 4)},
     }

@@ -79,6 +79,13 @@ typedef struct npa_handle npa_handle;
 int npa_create(const npa_config *cfg, const npa_dune_weights *w, npa_handle **out);
 int npa_destroy(npa_handle *h);
 
+/* How this handle computes the distance KEYS that nominate the nrmp_max_num nearest points of a slice (the rows it
+ * emits are always re-encoded with the exact fp32 encoder; dune.py:100 argsort is reproduced on those):
+ *   key_terms 1 = single fp16 products, 3 = fp16x2 split products, 0 = exact fp32 encoder;
+ *   measured_error = max |key - exact| / (1 + |exact|) over a 256 x 256 grid of the training square, measured by
+ *   npa_create for THIS checkpoint; margin_e0 = the candidate margin built from it (NPA_KEY_SAFETY x, default 6). */
+int npa_key_mode(const npa_handle *h, int *key_terms, float *measured_error, float *margin_e0);
+
 /* Replaces NRMP.update_adjust_parameters_value (nrmp.py:170-217). */
 int npa_set_adjust(npa_handle *h, const float q_s[3], float p_u, float eta, float d_max, float d_min);
 

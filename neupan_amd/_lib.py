@@ -38,6 +38,7 @@ _P, _I, _SZ = C.c_void_p, C.c_int, C.c_size_t
 SYMBOLS = {
     "npa_create": (_I, [C.POINTER(NpaConfig), C.POINTER(NpaDuneWeights), C.POINTER(_P)]),
     "npa_destroy": (_I, [_P]),
+    "npa_key_mode": (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "npa_set_adjust": (_I, [_P, C.POINTER(C.c_float * 3), C.c_float, C.c_float, C.c_float, C.c_float]),
     "npa_workspace_bytes": (_SZ, [_P, _I]),
     "npa_state_bytes": (_SZ, [_P, _I]),

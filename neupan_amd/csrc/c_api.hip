@@ -14,12 +14,15 @@
 extern "C" hipError_t npa_launch_encode(const DevParams& P, const float* wpack, int batch, int scene0, int t0,
                                         int n_stride, const float* cur_s, const float* points, const float* vel,
                                         const int* n_points, const int* flags, unsigned* gkeys, int n_cu,
-                                        int blocks_per_cu, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);
+                                        int blocks_per_cu, int key_terms, hipStream_t stream, hipEvent_t ev_start,
+                                        hipEvent_t ev_stop);
+extern "C" hipError_t npa_launch_key_calib(const DevParams& P, const float* wpack, int key_terms, int nside, float half,
+                                           unsigned* out, hipStream_t stream);
 extern "C" hipError_t npa_launch_select(const DevParams& P, const float* wpack, int batch, int scene0, int t0,
                                         int n_stride, const float* cur_s, const float* points, const float* vel,
                                         const int* n_points, const int* flags, const unsigned* gkeys,
                                         float* mu_sorted, float* lam_sorted, float* pts_sorted, float* dist_sorted,
-                                        int* count, hipStream_t stream);
+                                        int* count, int key_terms, float e0, unsigned* stats, hipStream_t stream);
 extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, const float* cur_s_in,
                                     const float* cur_u_in, const float* ref_s, const float* ref_us, const float* mu_sorted,
                                     const float* lam_sorted, const float* pts_sorted, const float* dist_sorted,
@@ -64,6 +67,20 @@ struct npa_handle {
   // on average (12.6 -> 8.5) but a longer tail, and the iterates land at slightly different points of
   // the QP's flat directions (control L2 vs oracle up to 1e-3 on some scenes) -> off by default
   bool warm_start = false;
+  // distance keys (dune_kernel): 1 = single fp16 products, 3 = fp16x2 split products, 0 = the exact fp32 encoder.
+  // key_e0: select_kernel's candidate margin e0 (1 + |d|), a multiple of the key error measured at creation
+  int key_terms = 1;
+  float key_e0 = 0.f, key_err = 0.f;
+  // key_auto: both reduced-precision modes are calibrated and the handle switches between them by what the
+  // single-product keys cost in select_kernel (tiles it had to re-encode because more candidates fell inside the
+  // margin than one tile holds -- walls at constant distance, dense clouds), see key_policy()
+  bool key_auto = false;
+  float e0_mode[2] = {0.f, 0.f}, err_mode[2] = {0.f, 0.f};        // [0] single, [1] split
+  unsigned* sel_stats_dev = nullptr;     // cumulative overflow tiles (select_kernel)
+  unsigned* sel_stats_host = nullptr;    // pinned copy, refreshed behind every forward call
+  unsigned stats_mark = 0;
+  unsigned long long tiles_window = 0;
+  int calls_window = 0, hold = 0;
   hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
   hipStream_t own_aux0 = nullptr;        // the helper stream created with the handle (aux[0] may be replaced)
   std::vector<hipEvent_t> sync_ev;
@@ -227,6 +244,47 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
   h->own_aux0 = h->aux[0];
   if (e == hipSuccess) e = hipMalloc(&h->wpack, WP_TOTAL * sizeof(float));
   if (e == hipSuccess) e = hipMemcpy(h->wpack, pack.data(), WP_TOTAL * sizeof(float), hipMemcpyHostToDevice);
+  // Key mode and candidate margin.  The reduced-precision key path only nominates candidates (select_kernel
+  // re-encodes them exactly), so its error decides nothing but how many candidates there are -- PROVIDED the
+  // margin covers it.  The error is a property of the checkpoint: measure it here on a 1024 x 1024 grid over the
+  // training square (|x|, |y| <= 25 m) and set e0 = NPA_KEY_SAFETY (default 5) x the largest |key - exact| / (1 + |exact|).
+  // Single fp16 products are used when that margin stays below 5e-2, else the
+  // fp16x2 split products, else the exact encoder.  NPA_DUNE_FP32KEYS=1 / NPA_KEY_TERMS=1|3 force a mode.
+  if (e == hipSuccess && need_w) {
+    int forced = -1;
+    if (getenv("NPA_DUNE_FP32KEYS")) forced = 0;
+    else if (const char* env = getenv("NPA_KEY_TERMS")) { int v = atoi(env); if (v == 1 || v == 3) forced = v; }
+    double safety = 5.0;
+    if (const char* env = getenv("NPA_KEY_SAFETY")) { double v = atof(env); if (v >= 1.0 && v <= 1e3) safety = v; }
+    h->key_terms = 0;
+    unsigned* dmax = nullptr;
+    e = hipMalloc(&dmax, sizeof(unsigned));
+    const int modes[2] = {1, 3};
+    const float floor_e0[2] = {1e-4f, 2e-5f}, cap_e0[2] = {5e-2f, 1e-3f};
+    bool ok[2] = {false, false};
+    for (int m = 0; m < 2 && e == hipSuccess && forced != 0; ++m) {
+      if (forced > 0 && forced != modes[m]) continue;
+      unsigned bits = 0;
+      e = hipMemset(dmax, 0, sizeof(unsigned));
+      if (e == hipSuccess) e = npa_launch_key_calib(P, h->wpack, modes[m], 1024, 25.0f, dmax, nullptr);
+      if (e == hipSuccess) e = hipMemcpy(&bits, dmax, sizeof(unsigned), hipMemcpyDeviceToHost);
+      if (e != hipSuccess) break;
+      float err;
+      memcpy(&err, &bits, sizeof(err));
+      h->err_mode[m] = err;
+      h->e0_mode[m] = std::max((float)(safety * err), floor_e0[m]);
+      ok[m] = h->e0_mode[m] <= cap_e0[m] || forced == modes[m];
+    }
+    if (dmax) hipFree(dmax);
+    const int pick = ok[0] ? 0 : (ok[1] ? 1 : -1);
+    if (pick >= 0) { h->key_terms = modes[pick]; h->key_err = h->err_mode[pick]; h->key_e0 = h->e0_mode[pick]; }
+    h->key_auto = forced < 0 && ok[0] && ok[1] && getenv("NPA_KEY_NOAUTO") == nullptr;
+    if (e == hipSuccess) e = hipMalloc(&h->sel_stats_dev, sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(h->sel_stats_dev, 0, sizeof(unsigned));
+    if (e == hipSuccess) e = hipHostMalloc(&h->sel_stats_host, sizeof(unsigned), hipHostMallocDefault);
+    if (e == hipSuccess) *h->sel_stats_host = 0;
+    if (const char* env = getenv("NPA_SEL_E0")) h->key_e0 = (float)atof(env);
+  }
   if (e != hipSuccess) {
     npa_destroy(h);                                      // releases whatever was created so far
     return fail(NPA_E_HIP, std::string("npa_create: ") + hipGetErrorString(e));
@@ -245,8 +303,18 @@ extern "C" int npa_destroy(npa_handle* h) {
   if (h->own_aux0) hipStreamDestroy(h->own_aux0);
   for (int i = 1; i < 4; ++i) if (h->aux[i]) hipStreamDestroy(h->aux[i]);
   if (h->wpack) hipFree(h->wpack);
+  if (h->sel_stats_dev) hipFree(h->sel_stats_dev);
+  if (h->sel_stats_host) hipHostFree(h->sel_stats_host);
   if (h->stage_cand) hipFree(h->stage_cand);
   delete h;
+  return NPA_OK;
+}
+
+extern "C" int npa_key_mode(const npa_handle* h, int* key_terms, float* measured_error, float* margin_e0) {
+  if (!h) return fail(NPA_E_ARG, "npa_key_mode: null handle");
+  if (key_terms) *key_terms = h->key_terms;
+  if (measured_error) *measured_error = h->key_err;
+  if (margin_e0) *margin_e0 = h->key_e0;
   return NPA_OK;
 }
 
@@ -333,10 +401,11 @@ extern "C" int npa_dune_stage(npa_handle* h, int batch, int n_stride, const floa
     h->stage_cand_bytes = need;
   }
   HIP_TRY(npa_launch_encode(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr,
-                            (unsigned*)h->stage_cand, h->n_cu, h->enc_blocks, (hipStream_t)stream, nullptr, nullptr));
+                            (unsigned*)h->stage_cand, h->n_cu, h->enc_blocks, h->key_terms, (hipStream_t)stream, nullptr,
+                            nullptr));
   HIP_TRY(npa_launch_select(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr,
                             (const unsigned*)h->stage_cand, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count,
-                            (hipStream_t)stream));
+                            h->key_terms, h->key_e0, h->sel_stats_dev, (hipStream_t)stream));
   return NPA_OK;
 }
 
@@ -428,6 +497,35 @@ extern "C" int npa_set_helper_stream(npa_handle* h, void* stream) {
   return NPA_OK;
 }
 
+// Single fp16 products make the key launch ~25 % cheaper but put more points inside select_kernel's margin; when
+// they do not fit the final tile the slice re-encodes them exactly, ~3 key-tile units per tile.  Every 8 forward
+// calls compare the two: if the re-encoded tiles cost more than the saving, use the split products for the next
+// 256 calls, then try again.  (The outputs are bitwise the same in either mode; only the time differs.)  The
+// counter is read from a pinned copy that trails the device by a call or two -- good enough for a policy.
+static void key_policy(npa_handle* h, int batch, int n_stride) {
+  if (!h->key_auto) return;
+  const DevParams& P = h->P;
+  const unsigned now = *(volatile unsigned*)h->sel_stats_host;
+  if (h->key_terms == 3) {
+    if (--h->hold > 0) return;
+    h->key_terms = 1; h->key_err = h->err_mode[0]; h->key_e0 = h->e0_mode[0];
+    h->stats_mark = now; h->tiles_window = 0; h->calls_window = 0;
+  } else if (h->calls_window >= 8) {
+    const unsigned redone = now - h->stats_mark;
+    static const bool dbg = getenv("NPA_KEY_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[npa key policy] re-encoded tiles %u vs key tiles %llu (ratio %.4f)\n", redone, h->tiles_window,
+                     (double)redone / (double)std::max<unsigned long long>(h->tiles_window, 1));
+    if ((unsigned long long)redone * 12ull > h->tiles_window) {
+      h->key_terms = 3; h->key_err = h->err_mode[1]; h->key_e0 = h->e0_mode[1]; h->hold = 256;
+      return;
+    }
+    h->stats_mark = now; h->tiles_window = 0; h->calls_window = 0;
+  }
+  const int n_use = n_stride < P.dune_max_num ? n_stride : P.dune_max_num;
+  h->tiles_window += (unsigned long long)batch * ((n_use + 31) / 32) * ((P.T + 1) + (size_t)(P.K - 1) * P.T);
+  ++h->calls_window;
+}
+
 extern "C" int npa_forward_begin(npa_handle* h, int batch, int n_stride, const float* nom_s, const float* nom_u,
                                  const float* ref_s, const float* ref_us, const float* points,
                                  const float* velocities, const int32_t* n_points, float* out_s, float* out_u,
@@ -457,6 +555,7 @@ extern "C" int npa_forward_begin(npa_handle* h, int batch, int n_stride, const f
   pc->out_md = out_min_distance; pc->out_iters = out_iters; pc->out_np = out_nrmp_points; pc->ws = ws;
   pc->state = (float*)state; pc->stream = stream;
   pc->dune = P.M > 0 && points != nullptr;
+  if (pc->dune) key_policy(h, batch, n_stride);
   // sub-batches [lo_i, hi_i): DUNE(i,k) on `stream` in (k, i) order, QP(i,k) on aux[i]
   // (when the caller interleaves several batches the batches themselves are the pipeline stages)
   pc->nsub = (h->n_sub > 1 && pc->dune && batch >= 16 * h->n_sub && !helper) ? h->n_sub : 1;
@@ -531,12 +630,12 @@ extern "C" int npa_forward_iter(npa_handle* h, int k) {
       // completion event is the profiling stop event when profiling, else the hand-over event
       hipEvent_t done = ev ? ev->b : (pc->qp_aux ? ev_d(i, k) : nullptr);
       HIP_TRY(npa_launch_encode(P, h->wpack, nb, s0, t0, pc->n_stride, cur_s, pc->points, pc->velocities,
-                                pc->n_points, flags, gkeys, h->n_cu, h->enc_blocks, stream, ev ? ev->a : nullptr, done));
+                                pc->n_points, flags, gkeys, h->n_cu, h->enc_blocks, h->key_terms, stream, ev ? ev->a : nullptr, done));
       if (pc->qp_aux) HIP_TRY(hipStreamWaitEvent(qs, done, 0));
       // selection + QP follow the encode on the helper stream (when there is one): the next
       // encode launch on `stream` -- another sub-batch or another batch in flight -- overlaps them
       HIP_TRY(npa_launch_select(P, h->wpack, nb, s0, t0, pc->n_stride, cur_s, pc->points, pc->velocities,
-                                pc->n_points, flags, gkeys, mu, lam, pts, dist, count, qs));
+                                pc->n_points, flags, gkeys, mu, lam, pts, dist, count, h->key_terms, h->key_e0, h->sel_stats_dev, qs));
     }
     EventPair* ev = next_event(h, h->ev_qp, h->n_qp);
     if (ev) HIP_TRY(hipEventRecord(ev->a, qs));
@@ -545,6 +644,8 @@ extern "C" int npa_forward_iter(npa_handle* h, int k) {
                           pc->state, qp_info, h->warm_start ? warm : nullptr, qs));
     if (ev) HIP_TRY(hipEventRecord(ev->b, qs));
     if (pc->qp_aux) HIP_TRY(hipEventRecord(ev_q(i, k), qs));
+    if (h->key_auto && pc->dune && k == P.K - 1 && i == nsub - 1)      // behind the hand-over event: nobody waits for it
+      HIP_TRY(hipMemcpyAsync(h->sel_stats_host, h->sel_stats_dev, sizeof(unsigned), hipMemcpyDeviceToHost, qs));
   }
   return NPA_OK;
 }

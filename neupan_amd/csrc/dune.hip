@@ -140,8 +140,23 @@ __device__ __forceinline__ void split2(const float (&a)[16], f16x8 (&x1)[2], f16
 }
 
 // wl: LDS image of one layer's split A-fragments [term 2][step 2][lane 64] x 16 B
-template <bool RELU>
+// TERMS = 3: the split product above.  TERMS = 1: leading fp16 terms only (2^-11 relative per factor): two MFMAs and
+// eight conversions per layer; usable because the keys only nominate candidates (select_kernel's margin).
+template <bool RELU, int TERMS>
 __device__ __forceinline__ f32x16 layer32_f16x2(const f16x8* wl, int lane, const float (&a)[16], f32x16 acc) {
+  if constexpr (TERMS == 1) {
+    f16x8 x[2];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      f16x2 b1 = __builtin_convertvector(f32x2_t{a[2 * p], a[2 * p + 1]}, f16x2);       // v_cvt_pk_f16_f32
+      if constexpr (RELU) b1 = __builtin_elementwise_max(b1, f16x2{(_Float16)0.f, (_Float16)0.f});   // v_pk_max_f16
+      const int s = p >> 2, q = (2 * p) & 7;
+      x[s][q] = b1.x; x[s][q + 1] = b1.y;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[(0 * 2 + s) * 64 + lane], x[s], acc, 0, 0, 0);
+    return acc;
+  }
   f16x8 x1[2], x2[2];
   split2<RELU>(a, x1, x2);
 #pragma unroll
@@ -191,7 +206,7 @@ __device__ __forceinline__ void ln_tanh_centred(f32x16 acc, const float* g, cons
 }
 
 // LDS image of the key path: split fragments, then kvec [5][32], then ksc [8] (pan_common.h)
-template <int E>
+template <int E, int TERMS>
 __device__ __forceinline__ void encode_tile_keys(float kw1, const f16x8* wbf, const float* vec, const float* w6,
                                                  const float* b6, float p0x, float p0y, int lane, float mu[E]) {
   const int hf = lane >> 5;
@@ -206,21 +221,21 @@ __device__ __forceinline__ void encode_tile_keys(float kw1, const f16x8* wbf, co
   }
   // the ReLU of Linear 2 / Linear 4 is applied inside the split of the following layer
   {
-    f32x16 acc = layer32_f16x2<false>(wbf + 0 * LSTR, lane, a, bias_init(kvec + 1 * 32, hf));
+    f32x16 acc = layer32_f16x2<false, TERMS>(wbf + 0 * LSTR, lane, a, bias_init(kvec + 1 * 32, hf));
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = acc[r];
   }
   {
-    f32x16 acc = layer32_f16x2<true>(wbf + 1 * LSTR, lane, a, bias_init(kvec + 2 * 32, hf));
+    f32x16 acc = layer32_f16x2<true, TERMS>(wbf + 1 * LSTR, lane, a, bias_init(kvec + 2 * 32, hf));
     ln_tanh_centred(acc, vec + V_G2 * 32, vec + V_BE2 * 32, hf, ksc[1], ksc[4], a);
   }
   {
-    f32x16 acc = layer32_f16x2<false>(wbf + 2 * LSTR, lane, a, bias_init(kvec + 3 * 32, hf));
+    f32x16 acc = layer32_f16x2<false, TERMS>(wbf + 2 * LSTR, lane, a, bias_init(kvec + 3 * 32, hf));
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = acc[r];
   }
   {
-    f32x16 acc = layer32_f16x2<true>(wbf + 3 * LSTR, lane, a, bias_init(kvec + 4 * 32, hf));
+    f32x16 acc = layer32_f16x2<true, TERMS>(wbf + 3 * LSTR, lane, a, bias_init(kvec + 4 * 32, hf));
     ln_tanh_centred(acc, vec + V_G3 * 32, vec + V_BE3 * 32, hf, ksc[2], ksc[5], a);
   }
   // output layer: two features per packed FMA (rows of Linear 6 as stored for the exact path)
@@ -350,7 +365,7 @@ __device__ __forceinline__ void load_frame(const DevParams& P, const float* __re
 }
 
 // one point (two lanes) through point flow + encoder + lam/distance
-template <int E, bool SPLIT>
+template <int E, int SPLIT>      // 0: exact fp32 encoder; 3 / 1: key path with that many fp16 product terms
 __device__ __forceinline__ void point_features(const DevParams& P, const SliceFrame& F, const WaveWeights& W,
                                                const f16x8* wbf, const float* vec, const float* w6, const float* b6,
                                                const float* px_row, const float* py_row, const float* vx_row,
@@ -367,7 +382,7 @@ __device__ __forceinline__ void point_features(const DevParams& P, const SliceFr
   float dx = __fsub_rn(gx, F.tx), dy = __fsub_rn(gy, F.ty);
   float p0x = fmaf(F.c, dx, __fmul_rn(F.s, dy));
   float p0y = fmaf(F.c, dy, -__fmul_rn(F.s, dx));
-  if constexpr (SPLIT) encode_tile_keys<E>(W.w1, wbf, vec, w6, b6, p0x, p0y, lane, mu);   // W.w1 = centred fragment
+  if constexpr (SPLIT != 0) encode_tile_keys<E, SPLIT>(W.w1, wbf, vec, w6, b6, p0x, p0y, lane, mu);   // W.w1 = centred fragment
   else encode_tile<E>(W, vec, w6, b6, p0x, p0y, lane, mu);
   lx = 0.f; ly = 0.f; dist = 0.f;
 #pragma unroll
@@ -392,7 +407,7 @@ __device__ __forceinline__ void load_weights(const float* __restrict__ wpack, in
 // WAVES = waves per workgroup.  4: five workgroups per CU (<= 96 VGPRs).  16: ONE workgroup per CU,
 // 4 waves per SIMD at <= 72 VGPRs and a single LDS copy of the weight fragments, which leaves room
 // (216 VGPRs per SIMD, 130 KB LDS) for a QP workgroup of another batch to be co-resident.
-template <int E, bool SPLIT, int WAVES>
+template <int E, int SPLIT, int WAVES>
 __global__ __attribute__((amdgpu_flat_work_group_size(64 * WAVES, 64 * WAVES), amdgpu_waves_per_eu(WAVES >= 8 ? 7 : 4)))
 void dune_kernel(
     DevParams P, const float* __restrict__ wpack, int n_stride, const float* __restrict__ cur_s,
@@ -414,7 +429,7 @@ void dune_kernel(
   for (int i = tid; i < 11 * 32 + 8 * 32 + 8; i += 64 * WAVES) smem[i] = wpack[WP_VEC + i];
   WaveWeights W;
   const f16x8* wbf = nullptr;
-  if constexpr (SPLIT) {
+  if constexpr (SPLIT != 0) {
     float* wb = b6 + 8;                     // 16-byte aligned: (11*32 + 8*32 + 8) floats precede it
     for (int i = tid; i < WP_KEY_LDS_FLOATS; i += 64 * WAVES) wb[i] = wpack[WP_BF + i];
     wbf = reinterpret_cast<const f16x8*>(wb);
@@ -481,25 +496,22 @@ void dune_kernel(
   }
 }
 
-// candidates kept in the compact list; LDS per slice stays < 9 KB so that all (T+1) slices of a CU's scenes are resident
-#define SEL_CAND_MAX 224
-
 // ---- launch 2: the M nearest of a slice, one wave per slice -----------------------------------------
+// LDS per slice stays < 9 KB at 1000 points so that all (T+1) slices of a CU's scenes are resident.
 template <int E>
 __global__ __launch_bounds__(64, 4) void select_kernel(
     DevParams P, const float* __restrict__ wpack, int n_stride, const float* __restrict__ cur_s,
     const float* __restrict__ points, const float* __restrict__ vel, const int* __restrict__ n_points,
     const int* __restrict__ flags, const unsigned* __restrict__ gkeys, int key_stride,
     float* __restrict__ mu_sorted, float* __restrict__ lam_sorted, float* __restrict__ pts_sorted,
-    float* __restrict__ dist_sorted, int* __restrict__ count, int scene0, int t0, int approx_keys) {
+    float* __restrict__ dist_sorted, int* __restrict__ count, int scene0, int t0, int approx_keys, float e0,
+    unsigned* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* vec = smem;                       // [11][32]
   float* w6 = vec + 11 * 32;               // [8][32]
   float* b6 = w6 + 8 * 32;                 // [8]
   int* sel = reinterpret_cast<int*>(b6 + 8);            // [NPA_MAX_M = 32]: the candidates of this slice
-  int* cand = sel + NPA_MAX_M;                           // [SEL_CAND_MAX]: points within the margin of the M-th key
-  unsigned* ckey = reinterpret_cast<unsigned*>(cand + SEL_CAND_MAX);   // [NPA_MAX_M + SEL_CAND_MAX] exact keys of the candidates
-  unsigned* dkey = ckey + NPA_MAX_M + SEL_CAND_MAX;      // [n_use]
+  unsigned* dkey = reinterpret_cast<unsigned*>(sel + NPA_MAX_M);   // [n_use] keys; later the candidate list + their exact keys
   const int t = blockIdx.x + t0, b = blockIdx.y + scene0, lane = threadIdx.x;
   const int j = lane & 31, hf = lane >> 5;
   const int T = P.T, M = P.M;
@@ -538,74 +550,69 @@ __global__ __launch_bounds__(64, 4) void select_kernel(
     }
   };
   extract();
-  // Split-precision keys (fp16x2, measured error <= 5e-6 at 30 m, i.e. 1.6e-7 relative) decide only WHO is a
-  // candidate: besides the msel smallest, every point whose key lies within 2e of the msel-th, e = 2e-5 + 1e-5|d|
-  // (>= 60x the measured error).  If |key - exact| <= e then the exact msel nearest are among the candidates;
-  // they are re-encoded exactly below and ranked on the exact (distance, index) key.
+  // Reduced-precision keys decide only WHO is a candidate: besides the msel smallest, every point whose key lies
+  // within 2e of the msel-th, e = e0 (1 + |d|) with e0 = a multiple of the key error MEASURED for this checkpoint
+  // when the handle was created (key_calib_kernel).  If |key - exact| <= e then the exact msel nearest are among
+  // the candidates; they are re-encoded exactly below and ranked on the exact (distance, index) key.
   int ncand = msel, fellback = 0;
   if (approx_keys && msel == M && n_use > M && last_key < 0xFFFFFFFEu) {
     const float dM = __uint_as_float((last_key & 0x80000000u) ? (last_key & 0x7FFFFFFFu) : ~last_key);
-    const unsigned thr = ordered_key(dM + 2.0f * (2e-5f + 1e-5f * fabsf(dM)));
+    const unsigned thr = ordered_key(dM + 2.0f * e0 * (1.0f + fabsf(dM)));
+    // compact the indices of the points inside the window IN PLACE over the keys already scanned (slot <= index)
     int extra = 0;                                              // points besides the msel extracted ones
     for (int n0 = 0; n0 < n_use; n0 += 64) {
       const int n = n0 + lane;
       const bool hit = n < n_use && dkey[n] <= thr;            // extracted entries are 0xFFFFFFFF
       const unsigned long long bal = __ballot(hit);
       const int pos = extra + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
-      if (hit && pos < SEL_CAND_MAX) cand[pos] = n;
+      if (hit) dkey[pos] = (unsigned)n;
       extra += __popcll(bal);
     }
     WSYNC();
     if (msel + extra <= NPA_MAX_M) {                            // the usual case: everything fits one tile
-      if (lane < extra) sel[msel + lane] = cand[lane];
+      if (lane < extra) sel[msel + lane] = (int)dkey[lane];
       ncand = msel + extra;
       WSYNC();
     } else {
-      // more candidates than one tile (many points within 2e of the M-th nearest, e.g. a cluster of exact
-      // zeros inside the robot): give the candidates -- or, beyond SEL_CAND_MAX of them, the whole slice --
-      // exact keys and extract the msel smallest again
+      // more candidates than one tile (many points within 2e of the M-th nearest: a wall at constant distance,
+      // a cluster of exact zeros inside the robot): exact keys for the candidates -- stored behind the list -- or,
+      // when the list takes more than half the slice, for the whole slice; then the msel smallest again
       fellback = 1;
-      const bool all = extra > SEL_CAND_MAX;
+      const bool all = 2 * extra + msel > n_use;
       const int total = all ? n_use : msel + extra;
-      auto cand_index = [&](int q) { return all ? q : (q < msel ? sel[q] : cand[q - msel]); };
+      unsigned* ckey = dkey + extra;                            // [total] exact keys of the candidates (compact form)
+      auto cand_index = [&](int q) { return all ? q : (q < msel ? sel[q] : (int)dkey[q - msel]); };
       for (int q0 = 0; q0 < total; q0 += 32) {
         const int q = q0 + j, qc = q < total ? q : total - 1;
         const int idx = cand_index(qc);
         float mu_[E], gx_, gy_, lx_, ly_, d_;
-        point_features<E, false>(P, F, W, nullptr, vec, w6, b6, px_row, py_row, vx_row, vy_row,
-                                 src_index(idx, n_raw, n_use), lane, mu_, gx_, gy_, lx_, ly_, d_);
+        point_features<E, 0>(P, F, W, nullptr, vec, w6, b6, px_row, py_row, vx_row, vy_row,
+                             src_index(idx, n_raw, n_use), lane, mu_, gx_, gy_, lx_, ly_, d_);
         if (hf == 0 && q < total) {
           if (all) dkey[idx] = ordered_key(d_);
-          else ckey[q] = ordered_key(d_);                       // compact: exact key of candidate q
+          else ckey[q] = ordered_key(d_);
         }
       }
       WSYNC();
+      if (stats && lane == 0) atomicAdd(stats, (unsigned)((total + 31) / 32));
       if (all) {
         extract();
       } else {
-        // the msel smallest exact (key, index) pairs among the candidates
-        int mine[(NPA_MAX_M + SEL_CAND_MAX + 63) / 64];
-#pragma unroll
-        for (int r = 0; r < (NPA_MAX_M + SEL_CAND_MAX + 63) / 64; ++r) mine[r] = (lane + 64 * r < total) ? cand_index(lane + 64 * r) : 0;
-        WSYNC();
+        // the msel smallest exact (key, index) pairs among the candidates; lane m keeps the m-th winner
+        int mywin = 0;
         for (int m2 = 0; m2 < msel; ++m2) {
           unsigned long long best = ~0ull;
-#pragma unroll
-          for (int r = 0; r < (NPA_MAX_M + SEL_CAND_MAX + 63) / 64; ++r) {
-            const int q = lane + 64 * r;
-            if (q < total) best = umin64(best, ((unsigned long long)ckey[q] << 32) | (unsigned)mine[r]);
+          int bq = -1;
+          for (int q = lane; q < total; q += 64) {
+            const unsigned long long v = ((unsigned long long)ckey[q] << 32) | (unsigned)cand_index(q);
+            if (v < best) { best = v; bq = q; }
           }
-          best = wave_min_u64(best);
-          const int idx = (int)(best & 0xFFFFFFFFu);
-          // retire the winner: the lane that holds it marks its compact slot
-#pragma unroll
-          for (int r = 0; r < (NPA_MAX_M + SEL_CAND_MAX + 63) / 64; ++r) {
-            const int q = lane + 64 * r;
-            if (q < total && mine[r] == idx) ckey[q] = 0xFFFFFFFFu;
-          }
+          const unsigned long long win = wave_min_u64(best);
+          if (best == win && bq >= 0) ckey[bq] = 0xFFFFFFFFu;   // (key, index) pairs are distinct: one lane retires it
+          if (lane == m2) mywin = (int)(win & 0xFFFFFFFFu);
           WSYNC();
-          if (lane == 0) sel[m2] = idx;
         }
+        if (lane < msel) sel[lane] = mywin;                     // sel[] was read through cand_index until here
         WSYNC();
       }
       ncand = msel;
@@ -614,7 +621,7 @@ __global__ __launch_bounds__(64, 4) void select_kernel(
   // re-encode the candidates exactly and emit the msel nearest as sorted rows; rows >= msel replicate row 0
   const int cj = j < ncand ? j : 0;
   float mu[E], gx, gy, lx, ly, dist;
-  point_features<E, false>(P, F, W, nullptr, vec, w6, b6, px_row, py_row, vx_row, vy_row,
+  point_features<E, 0>(P, F, W, nullptr, vec, w6, b6, px_row, py_row, vx_row, vy_row,
                            src_index(sel[cj], n_raw, n_use), lane, mu, gx, gy, lx, ly, dist);
   const unsigned long long kx = (j < ncand) ? (((unsigned long long)ordered_key(dist) << 32) | (unsigned)sel[cj]) : ~0ull;
   int rank = 0;
@@ -655,7 +662,9 @@ static int tiles_per_slice(const DevParams& P, int n_stride) {
 extern "C" hipError_t npa_launch_encode(const DevParams& P, const float* wpack, int batch, int scene0, int t0,
                                         int n_stride, const float* cur_s, const float* points, const float* vel,
                                         const int* n_points, const int* flags, unsigned* gkeys, int n_cu,
-                                        int blocks_per_cu, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                                        int blocks_per_cu, int key_terms, hipStream_t stream, hipEvent_t ev_start,
+                                        hipEvent_t ev_stop) {
+  // key_terms: 0 = exact fp32 encoder for the keys, 3 = fp16x2 split products, 1 = single fp16 products
   // ev_start / ev_stop (may be null) are attached to the dispatch itself (hipExtLaunchKernelGGL): no
   // separate marker packets on the stream, which cost ~5 us each between back-to-back launches
   const int nsl = P.T + 1 - t0;
@@ -664,7 +673,7 @@ extern "C" hipError_t npa_launch_encode(const DevParams& P, const float* wpack, 
   const long long tiles = (long long)batch * nsl * tps;
   if (tiles >= (1ll << 31)) return hipErrorInvalidValue;
   // resident workgroups (4-wave form): blocks_per_cu per CU; the exact-fp32 variant needs 117 VGPRs
-  static const bool split = getenv("NPA_DUNE_FP32KEYS") == nullptr;   // default: fp16x2 split keys
+  const bool split = key_terms != 0, single = key_terms == 1;
   if (!split && blocks_per_cu > 4) blocks_per_cu = 4;
   // one 16-wave workgroup per CU once every wave has a few tiles to stream; small launches keep
   // 4-wave workgroups (more CUs busy).  NPA_ENC_WAVES=4 forces the small form.
@@ -682,7 +691,7 @@ extern "C" hipError_t npa_launch_encode(const DevParams& P, const float* wpack, 
   static const int chunk_env = getenv("NPA_ENC_CHUNK") ? atoi(getenv("NPA_ENC_CHUNK")) : 2;
   const int chunk = chunk_env < 1 ? 1 : chunk_env;
 #ifdef NPA_OCC_EXPERIMENT
-#define OCC_CASES(EE) else if (split && waves == 8) LAUNCH1(EE, true, 8); else if (split && waves == 12) LAUNCH1(EE, true, 12);
+#define OCC_CASES(EE) else if (split && waves == 8) LAUNCH1(EE, 3, 8); else if (split && waves == 12) LAUNCH1(EE, 3, 12);
 #else
 #define OCC_CASES(EE)
 #endif
@@ -692,10 +701,12 @@ extern "C" hipError_t npa_launch_encode(const DevParams& P, const float* wpack, 
                         chunk)
 #define LAUNCH(EE)                                                                                                  \
   do {                                                                                                              \
-    if (split && waves == 16) LAUNCH1(EE, true, 16);                                                                \
+    if (single && waves == 16) LAUNCH1(EE, 1, 16);                                                                  \
+    else if (single) LAUNCH1(EE, 1, DUNE_WAVES);                                                                    \
+    else if (split && waves == 16) LAUNCH1(EE, 3, 16);                                                              \
     OCC_CASES(EE)                                                                                                   \
-    else if (split) LAUNCH1(EE, true, DUNE_WAVES);                                                                  \
-    else LAUNCH1(EE, false, DUNE_WAVES);                                                                            \
+    else if (split) LAUNCH1(EE, 3, DUNE_WAVES);                                                                     \
+    else LAUNCH1(EE, 0, DUNE_WAVES);                                                                                \
   } while (0)
   switch (P.E) {
     case 3: LAUNCH(3); break;
@@ -715,16 +726,80 @@ extern "C" hipError_t npa_launch_select(const DevParams& P, const float* wpack, 
                                         int n_stride, const float* cur_s, const float* points, const float* vel,
                                         const int* n_points, const int* flags, const unsigned* gkeys,
                                         float* mu_sorted, float* lam_sorted, float* pts_sorted, float* dist_sorted,
-                                        int* count, hipStream_t stream) {
+                                        int* count, int key_terms, float e0, unsigned* stats, hipStream_t stream) {
+  // key_terms != 0: the keys are reduced-precision ones, candidates within the margin e0 (1 + |d|) are re-ranked
   const int nsl = P.T + 1 - t0;
   const int tps = tiles_per_slice(P, n_stride);
-  static const int approx = getenv("NPA_DUNE_FP32KEYS") != nullptr ? 0 : (getenv("NPA_SEL_DEBUG") ? 2 : (getenv("NPA_SEL_NOMARGIN") ? 0 : 1));      // the keys are split-precision ones
-  const size_t shmem = (11 * 32 + 8 * 32 + 8) * sizeof(float) + (2 * NPA_MAX_M + 2 * SEL_CAND_MAX) * sizeof(int) +
+  static const int dbg = getenv("NPA_SEL_DEBUG") ? 2 : (getenv("NPA_SEL_NOMARGIN") ? 0 : 1);
+  const int approx = key_terms == 0 ? 0 : dbg;
+  const size_t shmem = (11 * 32 + 8 * 32 + 8) * sizeof(float) + NPA_MAX_M * sizeof(int) +
                        ((size_t)tps * 32 * sizeof(unsigned) + 15) / 16 * 16;
 #define LAUNCH(EE)                                                                                                  \
   hipLaunchKernelGGL(select_kernel<EE>, dim3(nsl, batch), dim3(64), shmem, stream, P, wpack, n_stride, cur_s, points, \
                      vel, n_points, flags, gkeys, tps * 32, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count,  \
-                     scene0, t0, approx)
+                     scene0, t0, approx, e0, stats)
+  switch (P.E) {
+    case 3: LAUNCH(3); break;
+    case 4: LAUNCH(4); break;
+    case 5: LAUNCH(5); break;
+    case 6: LAUNCH(6); break;
+    case 7: LAUNCH(7); break;
+    case 8: LAUNCH(8); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef LAUNCH
+  return hipGetLastError();
+}
+
+// ---- key-error calibration (npa_create) ------------------------------------------------------------
+// The distance of a point depends on its robot-frame position only, so the error of the reduced-precision key
+// path is a property of the checkpoint: evaluate both encoders on a grid over the square the DUNE models are
+// trained on (|x|, |y| <= 25 m, dune_train.py data_range) and return max |key - exact| / (1 + |exact|).
+template <int E, int TERMS>
+__global__ __launch_bounds__(256) void key_calib_kernel(DevParams P, const float* __restrict__ wpack, float lo, float step,
+                                                        int nside, unsigned* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* vec = smem;
+  float* w6 = vec + 11 * 32;
+  float* b6 = w6 + 8 * 32;
+  float* wb = b6 + 8;
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hf = lane >> 5;
+  for (int i = tid; i < 11 * 32 + 8 * 32 + 8; i += blockDim.x) smem[i] = wpack[WP_VEC + i];
+  for (int i = tid; i < WP_KEY_LDS_FLOATS; i += blockDim.x) wb[i] = wpack[WP_BF + i];
+  __syncthreads();
+  const f16x8* wbf = reinterpret_cast<const f16x8*>(wb);
+  WaveWeights W;
+  load_weights(wpack, lane, W);
+  const float kw1 = wpack[WP_KW1 + lane];
+  const int tile = blockIdx.x * (blockDim.x >> 6) + (tid >> 6);
+  const int n = tile * 32 + j, total = nside * nside;
+  const int nc = n < total ? n : total - 1;
+  const float p0x = lo + step * (float)(nc % nside), p0y = lo + step * (float)(nc / nside);
+  float mk[E], me[E];
+  encode_tile_keys<E, TERMS>(kw1, wbf, vec, w6, b6, p0x, p0y, lane, mk);
+  encode_tile<E>(W, vec, w6, b6, p0x, p0y, lane, me);
+  float dk = 0.f, de = 0.f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const float tmp = __fsub_rn(fmaf(P.G[e][0], p0x, __fmul_rn(P.G[e][1], p0y)), P.h[e]);
+    dk = fmaf(mk[e], tmp, dk);
+    de = fmaf(me[e], tmp, de);
+  }
+  float rel = fabsf(dk - de) / (1.0f + fabsf(de));
+  if (!(rel == rel)) rel = 1e30f;                            // NaN anywhere disqualifies the mode
+  if (hf == 0 && n < total) atomicMax(out, __float_as_uint(rel));
+}
+
+extern "C" hipError_t npa_launch_key_calib(const DevParams& P, const float* wpack, int key_terms, int nside, float half,
+                                           unsigned* out, hipStream_t stream) {
+  const int tiles = (nside * nside + 31) / 32, blocks = (tiles + 3) / 4;
+  const float lo = -half, step = 2.0f * half / (float)(nside - 1);
+  const size_t shmem = (11 * 32 + 8 * 32 + 8 + WP_KEY_LDS_FLOATS) * sizeof(float);
+#define LAUNCH(EE)                                                                                                   \
+  do {                                                                                                               \
+    if (key_terms == 1) hipLaunchKernelGGL((key_calib_kernel<EE, 1>), dim3(blocks), dim3(256), shmem, stream, P, wpack, lo, step, nside, out); \
+    else hipLaunchKernelGGL((key_calib_kernel<EE, 3>), dim3(blocks), dim3(256), shmem, stream, P, wpack, lo, step, nside, out); \
+  } while (0)
   switch (P.E) {
     case 3: LAUNCH(3); break;
     case 4: LAUNCH(4); break;

@@ -464,6 +464,14 @@ class PAN(torch.nn.Module):
         params = [f.q_s, f.p_u, f.eta, f.d_max, f.d_min]
         return _PanGrad.apply(self, (nom_s, nom_u, ref_s, ref_us, points, velocities, n_points), *params)
 
+    def key_mode(self):
+        """How the distance keys are computed for this checkpoint (npa_key_mode): dict(key_terms, measured_error, margin_e0)."""
+        if self.no_obs:
+            return dict(key_terms=0, measured_error=0.0, margin_e0=0.0)
+        kt, er, e0 = C.c_int(), C.c_float(), C.c_float()
+        check(self._lib.npa_key_mode(self._h, C.byref(kt), C.byref(er), C.byref(e0)), "npa_key_mode")
+        return dict(key_terms=kt.value, measured_error=er.value, margin_e0=e0.value)
+
     def last_qp_info(self):
         """(B,16) float64: per-scene diagnostics of the last QP solved by forward_batch
         (best iteration, merit, mu, status, iterations run)."""

@@ -339,22 +339,62 @@ def test_coalesced_batches_equal_sequential():
         assert np.array_equal(o["min_distance"].cpu().numpy(), outs[j]["min_distance"].cpu().numpy()), j
 
 
-def test_split_key_selection_equals_exact_key_selection():
-    """The fp16x2 distance keys only nominate candidates (select_kernel re-encodes every point within a margin
-    of the M-th key exactly and ranks on the exact result), so the emitted rows must be BITWISE those of the
-    exact-fp32-key build on every slice.  The exact-key run happens in a subprocess (the key mode is read once
-    per process from NPA_DUNE_FP32KEYS)."""
+@pytest.mark.parametrize("cfgname,B", [("diff_1k_T10_K10", 192), ("acker_2k_T20_K15", 32), ("dyna_4k_T10_K10", 24),
+                                       ("poly8_5k_T10_K10", 16)])
+def test_reduced_precision_key_selection_equals_exact_key_selection(cfgname, B):
+    """The reduced-precision distance keys only nominate candidates (select_kernel re-encodes every point within a
+    margin of the M-th key exactly and ranks on the exact result; the margin is a multiple of the key error that
+    npa_create measured for the checkpoint), so the emitted rows must be BITWISE those of the exact-fp32-key build
+    on every slice.  The exact-key run happens in a subprocess (NPA_DUNE_FP32KEYS is read when a handle is created)."""
     import os, subprocess, sys, tempfile
     from gpu_helpers import make_gpu_pan
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = os.path.join(tempfile.mkdtemp(), "exact.npz")
     env = dict(os.environ, NPA_DUNE_FP32KEYS="1")
-    subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "key_check.py"), out, "192"], check=True, env=env,
+    subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "key_check.py"), out, str(B), "-", cfgname], check=True,
+                   env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=root)
+    exact = np.load(out)
+    cfg = CONFIGS[cfgname]
+    pan = make_gpu_pan(cfg)
+    km = pan.key_mode()
+    assert km["key_terms"] in (1, 3) and km["margin_e0"] >= 4.9 * km["measured_error"] > 0, km
+    batch = make_batch(cfg, 1000, B)
+    r = {k: v.cpu().numpy() for k, v in pan.dune_stage(batch["nom_s"], batch["points"], batch.get("velocities")).items()}
+    for k in ("mu", "lam", "pts", "dist", "count"):
+        assert np.array_equal(r[k], exact[k]), k
+
+
+def test_selection_with_many_near_ties_equals_exact_key_selection():
+    """Walls at constant distance and tight blobs put far more points inside the key margin than one tile holds
+    (select_kernel's compact and whole-slice paths); the emitted rows must still be bitwise those of the exact-key
+    build, and a full forward on such scenes must agree with the exact-key build too."""
+    import os, subprocess, sys, tempfile
+    from gpu_helpers import make_gpu_pan, wall_batch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(tempfile.mkdtemp(), "exact.npz")
+    env = dict(os.environ, NPA_DUNE_FP32KEYS="1", KEY_CHECK_WALLS="1")
+    subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "key_check.py"), out, "64"], check=True, env=env,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=root)
     exact = np.load(out)
     cfg = CONFIGS["diff_1k_T10_K10"]
     pan = make_gpu_pan(cfg)
-    batch = make_batch(cfg, 1000, 192)
-    r = {k: v.cpu().numpy() for k, v in pan.dune_stage(batch["nom_s"], batch["points"]).items()}
+    batch = wall_batch(cfg, 64)
+    r = {k: v.cpu().numpy() for k, v in pan.dune_stage(batch["nom_s"], batch["points"], None, batch["n_points"]).items()}
     for k in ("mu", "lam", "pts", "dist", "count"):
         assert np.array_equal(r[k], exact[k]), k
+    # the scenes do what they are for: near-ties far beyond one tile
+    d = r["dist"]
+    assert (np.abs(d[:, :, 9] - d[:, :, 0]) < 5e-3).mean() > 0.3
+    # the mode switch of the handle (npa_create's key_auto) leaves the plan untouched: 20 calls cross an evaluation
+    args = [batch[k] for k in ("nom_s", "nom_u", "ref_s", "ref_us", "points")]
+    first = None
+    modes = set()
+    for rep in range(20):
+        pan.reset_stop_state()
+        o = pan.forward_batch(*args, None, batch["n_points"])
+        u = o["opt_u"].cpu().numpy()
+        modes.add(pan.key_mode()["key_terms"])
+        if first is None:
+            first = u
+        assert np.array_equal(u, first), rep
+    assert modes <= {1, 3}
