@@ -223,7 +223,7 @@ class neupan(torch.nn.Module):
             self.info["arrive"] = True
             return np.zeros((2, 1)), self.info
         opt_s, opt_u = fi["opt_s"][0], fi["opt_u"][0]
-        opt_s_np, opt_u_np = opt_s.cpu().numpy(), opt_u.cpu().numpy()
+        opt_s_np, opt_u_np = opt_s.detach().cpu().numpy(), opt_u.detach().cpu().numpy()       # tensor_to_np
         self.cur_vel_array = opt_u_np
         ref_s_np = fi["ref_s"][0].cpu().numpy()
         self.info["state_tensor"], self.info["vel_tensor"] = opt_s, opt_u

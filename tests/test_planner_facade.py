@@ -142,11 +142,11 @@ def test_lon_style_step_through_the_facade(tmp_path):
         assert np.array_equal(action, action0)
         loss = 10 * (50 - torch.sum(info["distance_tensor"]))
         loss.backward()
-        before = [float(p) for p in (p_u, eta, d_max)]
+        before = [p.item() for p in (p_u, eta, d_max)]
         assert all(p.grad is not None and np.isfinite(float(p.grad)) for p in (p_u, eta, d_max))
-        assert float(eta.grad) < 0                         # a larger eta buys more clearance
+        assert eta.grad.item() < 0                         # a larger eta buys more clearance
         opt.step()
-        assert float(eta) > before[1]
+        assert eta.item() > before[1]
         action, info = planner(state, pts)                 # the updated values are what the next cycle solves with
         assert np.isfinite(action).all() and not np.array_equal(action, action0)
     finally:
