@@ -13,23 +13,25 @@
 
 extern "C" hipError_t npa_launch_encode(const DevParams& P, const float* wpack, int batch, int scene0, int t0,
                                         int n_stride, const float* cur_s, const float* points, const float* vel,
-                                        const int* n_points, const int* flags, unsigned* gkeys, int n_cu,
-                                        int blocks_per_cu, int key_terms, hipStream_t stream, hipEvent_t ev_start,
-                                        hipEvent_t ev_stop);
+                                        const int* n_points, const int* flags, unsigned* gkeys, const float* trig,
+                                        int n_cu, int blocks_per_cu, int key_terms, hipStream_t stream,
+                                        hipEvent_t ev_start, hipEvent_t ev_stop);
+extern "C" hipError_t npa_launch_trig(const float* cur_s, int batch, int T, float* trig, hipStream_t stream);
 extern "C" hipError_t npa_launch_key_calib(const DevParams& P, const float* wpack, int key_terms, int nside, float half,
                                            unsigned* out, hipStream_t stream);
 extern "C" hipError_t npa_launch_select(const DevParams& P, const float* wpack, int batch, int scene0, int t0,
                                         int n_stride, const float* cur_s, const float* points, const float* vel,
                                         const int* n_points, const int* flags, const unsigned* gkeys,
-                                        float* mu_sorted, float* lam_sorted, float* pts_sorted, float* dist_sorted,
-                                        int* count, int key_terms, float e0, unsigned* stats, hipStream_t stream);
+                                        const float* trig, float* mu_sorted, float* lam_sorted, float* pts_sorted,
+                                        float* dist_sorted, int* count, int key_terms, float e0, unsigned* stats,
+                                        hipStream_t stream);
 extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, const float* cur_s_in,
                                     const float* cur_u_in, const float* ref_s, const float* ref_us, const float* mu_sorted,
                                     const float* lam_sorted, const float* pts_sorted, const float* dist_sorted,
                                     const int* count, float* cur_s_out, float* cur_u_out, float* cur_d_out,
                                     float* out_s, float* out_u, float* out_d, float* out_min_distance,
                                     int* out_iters, float* out_nrmp_points, int* flags, float* state,
-                                    double* qp_info, double* warm, hipStream_t stream);
+                                    double* qp_info, double* warm, float* trig_out, hipStream_t stream);
 extern "C" size_t npa_qp_shmem_bytes(int T, int M);
 extern "C" hipError_t npa_launch_nominal(int batch, int T, int kin, double dt, double L, const double* state,
                                          const float* vel, const double* ref_speed, const double* path,
@@ -392,7 +394,8 @@ extern "C" int npa_dune_stage(npa_handle* h, int batch, int n_stride, const floa
   // key scratch (+ one work counter) owned by the handle (the stage entry point is a
   // test/profiling hook, the production path carves both from the caller's workspace)
   const size_t key_bytes = (size_t)batch * (h->P.T + 1) * h->P.key_stride * sizeof(unsigned);
-  const size_t need = key_bytes + 64;
+  const size_t trig_bytes = ((size_t)batch * (h->P.T + 1) * 2 * sizeof(float) + 63) / 64 * 64;
+  const size_t need = key_bytes + trig_bytes + 64;
   if (need > h->stage_cand_bytes) {
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     if (h->stage_cand) HIP_TRY(hipFree(h->stage_cand));
@@ -400,11 +403,13 @@ extern "C" int npa_dune_stage(npa_handle* h, int batch, int n_stride, const floa
     HIP_TRY(hipMalloc(&h->stage_cand, need));
     h->stage_cand_bytes = need;
   }
+  float* trig = reinterpret_cast<float*>(reinterpret_cast<char*>(h->stage_cand) + key_bytes);
+  HIP_TRY(npa_launch_trig(nom_s, batch, h->P.T, trig, (hipStream_t)stream));
   HIP_TRY(npa_launch_encode(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr,
-                            (unsigned*)h->stage_cand, h->n_cu, h->enc_blocks, h->key_terms, (hipStream_t)stream, nullptr,
-                            nullptr));
+                            (unsigned*)h->stage_cand, trig, h->n_cu, h->enc_blocks, h->key_terms, (hipStream_t)stream,
+                            nullptr, nullptr));
   HIP_TRY(npa_launch_select(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr,
-                            (const unsigned*)h->stage_cand, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count,
+                            (const unsigned*)h->stage_cand, trig, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count,
                             h->key_terms, h->key_e0, h->sel_stats_dev, (hipStream_t)stream));
   return NPA_OK;
 }
@@ -419,7 +424,7 @@ extern "C" int npa_nrmp_stage(npa_handle* h, int batch, const float* nom_s, cons
     return fail(NPA_E_ARG, "npa_nrmp_stage: obstacle arrays required when nrmp_max_num > 0");
   HIP_TRY(npa_launch_qp(h->P, batch, 0, nom_s, nom_u, ref_s, ref_us, mu_sorted, lam_sorted, pts_sorted, nullptr, count,
                         out_s, out_u, out_d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                        qp_info, nullptr, (hipStream_t)stream));
+                        qp_info, nullptr, nullptr, (hipStream_t)stream));
   return NPA_OK;
 }
 
@@ -447,11 +452,17 @@ extern "C" int npa_nrmp_backward(npa_handle* h, int batch, const float* nom_s, c
 __global__ void stage_kernel(float* __restrict__ cur_s, const float* __restrict__ nom_s, size_t ns,
                              float* __restrict__ cur_u, const float* __restrict__ nom_u, size_t nu,
                              int* __restrict__ flags, size_t nflag, int* __restrict__ count, size_t ncount,
-                             int* __restrict__ state, size_t nstate) {
+                             int* __restrict__ state, size_t nstate, float* __restrict__ trig, int T) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;; i += stride) {
     bool any = false;
     if (i < ns) { cur_s[i] = nom_s[i]; any = true; }
+    if (i < ncount) {                       // ncount = scenes x (T+1): one heading each
+      const size_t b = i / (size_t)(T + 1), t = i - b * (size_t)(T + 1);
+      float c, sn;
+      npa_trig(nom_s[b * 3 * (size_t)(T + 1) + 2 * (size_t)(T + 1) + t], c, sn);
+      trig[2 * i] = c; trig[2 * i + 1] = sn;
+    }
     if (i < nu) { cur_u[i] = nom_u[i]; any = true; }
     if (i < nflag) { flags[i] = 0; any = true; }
     if (i < ncount) { count[i] = 0; any = true; }
@@ -584,7 +595,7 @@ extern "C" int npa_forward_begin(npa_handle* h, int batch, int n_stride, const f
     const int threads = 256;
     const int blocks = (int)std::min<size_t>((work + threads - 1) / threads, 512);
     hipLaunchKernelGGL(stage_kernel, dim3(blocks), dim3(threads), 0, st, ws + L.cur_s, nom_s, ns, ws + L.cur_u, nom_u, nu2,
-                       (int*)(ws + L.flags), nflag, (int*)(ws + L.count), ncount, (int*)state, nstate);
+                       (int*)(ws + L.flags), nflag, (int*)(ws + L.count), ncount, (int*)state, nstate, ws + L.trig, T);
     HIP_TRY(hipGetLastError());
   }
   if (pc->staged_on_aux) {
@@ -630,18 +641,20 @@ extern "C" int npa_forward_iter(npa_handle* h, int k) {
       // completion event is the profiling stop event when profiling, else the hand-over event
       hipEvent_t done = ev ? ev->b : (pc->qp_aux ? ev_d(i, k) : nullptr);
       HIP_TRY(npa_launch_encode(P, h->wpack, nb, s0, t0, pc->n_stride, cur_s, pc->points, pc->velocities,
-                                pc->n_points, flags, gkeys, h->n_cu, h->enc_blocks, h->key_terms, stream, ev ? ev->a : nullptr, done));
+                                pc->n_points, flags, gkeys, ws + L.trig, h->n_cu, h->enc_blocks, h->key_terms, stream,
+                                ev ? ev->a : nullptr, done));
       if (pc->qp_aux) HIP_TRY(hipStreamWaitEvent(qs, done, 0));
       // selection + QP follow the encode on the helper stream (when there is one): the next
       // encode launch on `stream` -- another sub-batch or another batch in flight -- overlaps them
       HIP_TRY(npa_launch_select(P, h->wpack, nb, s0, t0, pc->n_stride, cur_s, pc->points, pc->velocities,
-                                pc->n_points, flags, gkeys, mu, lam, pts, dist, count, h->key_terms, h->key_e0, h->sel_stats_dev, qs));
+                                pc->n_points, flags, gkeys, ws + L.trig, mu, lam, pts, dist, count, h->key_terms, h->key_e0,
+                                h->sel_stats_dev, qs));
     }
     EventPair* ev = next_event(h, h->ev_qp, h->n_qp);
     if (ev) HIP_TRY(hipEventRecord(ev->a, qs));
     HIP_TRY(npa_launch_qp(P, nb, s0, cur_s, cur_u, pc->ref_s, pc->ref_us, mu, lam, pts, dist, count, cur_s, cur_u,
                           cur_d, pc->out_s, pc->out_u, pc->out_d, pc->out_md, pc->out_iters, pc->out_np, flags,
-                          pc->state, qp_info, h->warm_start ? warm : nullptr, qs));
+                          pc->state, qp_info, h->warm_start ? warm : nullptr, pc->dune ? ws + L.trig : nullptr, qs));
     if (ev) HIP_TRY(hipEventRecord(ev->b, qs));
     if (pc->qp_aux) HIP_TRY(hipEventRecord(ev_q(i, k), qs));
     if (h->key_auto && pc->dune && k == P.K - 1 && i == nsub - 1)      // behind the hand-over event: nobody waits for it

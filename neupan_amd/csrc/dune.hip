@@ -342,15 +342,17 @@ __device__ __forceinline__ int src_index(int n, int n_raw, int n_use) {
 
 // frame of a slice: robot pose at horizon step t, (-R)G^T
 template <int E>
-__device__ __forceinline__ void load_frame(const DevParams& P, const float* __restrict__ cur_s, int b, int t,
-                                           SliceFrame& F) {
+__device__ __forceinline__ void load_frame(const DevParams& P, const float* __restrict__ cur_s,
+                                           const float* __restrict__ trig, int b, int t, SliceFrame& F) {
+  // cos / sin come from the table written together with cur_s (stage_kernel, the QP's write-out, trig_kernel): the
+  // fp64 libm evaluation costs ~250 slow VALU instructions, which a wave of dune_kernel would otherwise pay for
+  // every work ticket (nearly every ticket of a wave lands in a new slice)
   const int T = P.T;
   const float* s = cur_s + (size_t)b * 3 * (T + 1);
-  float th = s[2 * (T + 1) + t];
   F.tx = s[t];
   F.ty = s[(T + 1) + t];
-  F.c = (float)cos((double)th);
-  F.s = (float)sin((double)th);
+  F.c = trig[((size_t)b * (T + 1) + t) * 2];
+  F.s = trig[((size_t)b * (T + 1) + t) * 2 + 1];
   F.tstep = (float)t;
 #pragma unroll
   for (int e = 0; e < E; ++e) {     // (-R) @ G^T, R = [[c,-s],[s,c]]
@@ -413,7 +415,7 @@ void dune_kernel(
     DevParams P, const float* __restrict__ wpack, int n_stride, const float* __restrict__ cur_s,
     const float* __restrict__ points, const float* __restrict__ vel, const int* __restrict__ n_points,
     const int* __restrict__ flags, unsigned* __restrict__ gkeys, int key_stride, int scene0, int nscene, int t0,
-    int chunk) {
+    int chunk, const float* __restrict__ trig) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ int wg_ticket_s;
   int* wg_ticket = &wg_ticket_s;
@@ -478,7 +480,7 @@ void dune_kernel(
       n_use = n_raw < P.dune_max_num ? n_raw : P.dune_max_num;
       skip = (flags && flags[b * 4 + 0]) || n_use <= 0;     // converged scene (pan.py:144-145) / no points
       if (!skip) {
-        load_frame<E>(P, cur_s, b, t, F);
+        load_frame<E>(P, cur_s, trig, b, t, F);
         px_row = points + (size_t)b * 2 * n_stride;
         py_row = px_row + n_stride;
         vx_row = vel ? vel + (size_t)b * 2 * n_stride : nullptr;
@@ -505,13 +507,14 @@ __global__ __launch_bounds__(64, 4) void select_kernel(
     const int* __restrict__ flags, const unsigned* __restrict__ gkeys, int key_stride,
     float* __restrict__ mu_sorted, float* __restrict__ lam_sorted, float* __restrict__ pts_sorted,
     float* __restrict__ dist_sorted, int* __restrict__ count, int scene0, int t0, int approx_keys, float e0,
-    unsigned* __restrict__ stats) {
+    unsigned* __restrict__ stats, const float* __restrict__ trig) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* vec = smem;                       // [11][32]
   float* w6 = vec + 11 * 32;               // [8][32]
   float* b6 = w6 + 8 * 32;                 // [8]
   int* sel = reinterpret_cast<int*>(b6 + 8);            // [NPA_MAX_M = 32]: the candidates of this slice
-  unsigned* dkey = reinterpret_cast<unsigned*>(sel + NPA_MAX_M);   // [n_use] keys; later the candidate list + their exact keys
+  int* lst = sel + NPA_MAX_M;                           // [64]: short list of the first extraction
+  unsigned* dkey = reinterpret_cast<unsigned*>(lst + 64);          // [n_use] keys; later the candidate list + their exact keys
   const int t = blockIdx.x + t0, b = blockIdx.y + scene0, lane = threadIdx.x;
   const int j = lane & 31, hf = lane >> 5;
   const int T = P.T, M = P.M;
@@ -529,7 +532,7 @@ __global__ __launch_bounds__(64, 4) void select_kernel(
   WaveWeights W;
   load_weights(wpack, lane, W);
   SliceFrame F;
-  load_frame<E>(P, cur_s, b, t, F);
+  load_frame<E>(P, cur_s, trig, b, t, F);
   const float* px_row = points + (size_t)b * 2 * n_stride;
   const float* py_row = px_row + n_stride;
   const float* vx_row = vel ? vel + (size_t)b * 2 * n_stride : nullptr;
@@ -549,7 +552,40 @@ __global__ __launch_bounds__(64, 4) void select_kernel(
       WSYNC();
     }
   };
-  extract();
+  // First extraction without msel full passes: the msel-th smallest of the 64 per-lane minima bounds the msel-th
+  // smallest key from above (each of those lanes holds a key that small), found by bisection on its bits (one
+  // compare + scalar popcount per bit); one more pass lists the keys up to that bound -- msel plus a few for
+  // unstructured data -- and the list is ranked in registers.  Long lists (heavy ties) take the plain loop.
+  auto extract_short = [&]() -> bool {
+    unsigned lmin = 0xFFFFFFFFu;
+    for (int n = lane; n < n_use; n += 64) lmin = min(lmin, dkey[n]);
+    unsigned bound = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+      const unsigned trial = bound | ((1u << bit) - 1u);
+      if (__popcll(__ballot(lmin <= trial)) < msel) bound |= 1u << bit;
+    }
+    int L = 0;
+    for (int n0 = 0; n0 < n_use; n0 += 64) {
+      const int n = n0 + lane;
+      const bool hit = n < n_use && dkey[n] <= bound;
+      const unsigned long long bal = __ballot(hit);
+      const int pos = L + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+      if (hit && pos < 64) lst[pos] = n;
+      L += __popcll(bal);
+    }
+    if (L > 64 || L < msel) return false;
+    WSYNC();
+    const int idx = lane < L ? lst[lane] : 0;
+    const unsigned long long v = lane < L ? (((unsigned long long)dkey[idx] << 32) | (unsigned)idx) : ~0ull;
+    int rk = 0;
+    for (int i = 0; i < L; ++i) rk += readlane_u64(v, i) < v ? 1 : 0;
+    if (lane < L && rk < msel) { sel[rk] = idx; dkey[idx] = 0xFFFFFFFFu; }
+    const unsigned long long lastb = __ballot(lane < L && rk == msel - 1);
+    last_key = (unsigned)(readlane_u64(v, (int)__builtin_ctzll(lastb)) >> 32);
+    WSYNC();
+    return true;
+  };
+  if (!extract_short()) extract();
   // Reduced-precision keys decide only WHO is a candidate: besides the msel smallest, every point whose key lies
   // within 2e of the msel-th, e = e0 (1 + |d|) with e0 = a multiple of the key error MEASURED for this checkpoint
   // when the handle was created (key_calib_kernel).  If |key - exact| <= e then the exact msel nearest are among
@@ -661,9 +697,9 @@ static int tiles_per_slice(const DevParams& P, int n_stride) {
 
 extern "C" hipError_t npa_launch_encode(const DevParams& P, const float* wpack, int batch, int scene0, int t0,
                                         int n_stride, const float* cur_s, const float* points, const float* vel,
-                                        const int* n_points, const int* flags, unsigned* gkeys, int n_cu,
-                                        int blocks_per_cu, int key_terms, hipStream_t stream, hipEvent_t ev_start,
-                                        hipEvent_t ev_stop) {
+                                        const int* n_points, const int* flags, unsigned* gkeys, const float* trig,
+                                        int n_cu, int blocks_per_cu, int key_terms, hipStream_t stream,
+                                        hipEvent_t ev_start, hipEvent_t ev_stop) {
   // key_terms: 0 = exact fp32 encoder for the keys, 3 = fp16x2 split products, 1 = single fp16 products
   // ev_start / ev_stop (may be null) are attached to the dispatch itself (hipExtLaunchKernelGGL): no
   // separate marker packets on the stream, which cost ~5 us each between back-to-back launches
@@ -698,7 +734,7 @@ extern "C" hipError_t npa_launch_encode(const DevParams& P, const float* wpack, 
 #define LAUNCH1(EE, SP, WV)                                                                                         \
   hipExtLaunchKernelGGL((dune_kernel<EE, SP, WV>), dim3(blocks), dim3(64 * WV), shmem, stream, ev_start, ev_stop, 0, \
                         P, wpack, n_stride, cur_s, points, vel, n_points, flags, gkeys, tps * 32, scene0, batch, t0, \
-                        chunk)
+                        chunk, trig)
 #define LAUNCH(EE)                                                                                                  \
   do {                                                                                                              \
     if (single && waves == 16) LAUNCH1(EE, 1, 16);                                                                  \
@@ -725,19 +761,20 @@ extern "C" hipError_t npa_launch_encode(const DevParams& P, const float* wpack, 
 extern "C" hipError_t npa_launch_select(const DevParams& P, const float* wpack, int batch, int scene0, int t0,
                                         int n_stride, const float* cur_s, const float* points, const float* vel,
                                         const int* n_points, const int* flags, const unsigned* gkeys,
-                                        float* mu_sorted, float* lam_sorted, float* pts_sorted, float* dist_sorted,
-                                        int* count, int key_terms, float e0, unsigned* stats, hipStream_t stream) {
+                                        const float* trig, float* mu_sorted, float* lam_sorted, float* pts_sorted,
+                                        float* dist_sorted, int* count, int key_terms, float e0, unsigned* stats,
+                                        hipStream_t stream) {
   // key_terms != 0: the keys are reduced-precision ones, candidates within the margin e0 (1 + |d|) are re-ranked
   const int nsl = P.T + 1 - t0;
   const int tps = tiles_per_slice(P, n_stride);
   static const int dbg = getenv("NPA_SEL_DEBUG") ? 2 : (getenv("NPA_SEL_NOMARGIN") ? 0 : 1);
   const int approx = key_terms == 0 ? 0 : dbg;
-  const size_t shmem = (11 * 32 + 8 * 32 + 8) * sizeof(float) + NPA_MAX_M * sizeof(int) +
+  const size_t shmem = (11 * 32 + 8 * 32 + 8) * sizeof(float) + (NPA_MAX_M + 64) * sizeof(int) +
                        ((size_t)tps * 32 * sizeof(unsigned) + 15) / 16 * 16;
 #define LAUNCH(EE)                                                                                                  \
   hipLaunchKernelGGL(select_kernel<EE>, dim3(nsl, batch), dim3(64), shmem, stream, P, wpack, n_stride, cur_s, points, \
                      vel, n_points, flags, gkeys, tps * 32, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count,  \
-                     scene0, t0, approx, e0, stats)
+                     scene0, t0, approx, e0, stats, trig)
   switch (P.E) {
     case 3: LAUNCH(3); break;
     case 4: LAUNCH(4); break;
@@ -810,5 +847,21 @@ extern "C" hipError_t npa_launch_key_calib(const DevParams& P, const float* wpac
     default: return hipErrorInvalidValue;
   }
 #undef LAUNCH
+  return hipGetLastError();
+}
+
+// (cos, sin) table for a nominal trajectory that no kernel of ours wrote (npa_dune_stage)
+__global__ void trig_kernel(const float* __restrict__ cur_s, int nscene, int T, float* __restrict__ trig) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nscene * (T + 1)) return;
+  const int b = i / (T + 1), t = i - b * (T + 1);
+  float c, s;
+  npa_trig(cur_s[(size_t)b * 3 * (T + 1) + 2 * (T + 1) + t], c, s);
+  trig[2 * (size_t)i] = c;
+  trig[2 * (size_t)i + 1] = s;
+}
+extern "C" hipError_t npa_launch_trig(const float* cur_s, int batch, int T, float* trig, hipStream_t stream) {
+  const int n = batch * (T + 1);
+  hipLaunchKernelGGL(trig_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cur_s, batch, T, trig);
   return hipGetLastError();
 }

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
     float* __restrict__ out_u, float* __restrict__ out_d, float* __restrict__ out_min_distance,
     int* __restrict__ out_iters, float* __restrict__ out_nrmp_points, int* __restrict__ flags,
     float* __restrict__ state, double* __restrict__ qp_info, double* __restrict__ warm, int scene0, int nscene,
-    int wave_doubles, int wpg, QpBackward bw) {
+    int wave_doubles, int wpg, QpBackward bw, float* __restrict__ trig_out) {
   extern __shared__ __attribute__((aligned(16))) double sm_all[];
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -881,6 +881,13 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
     so[q] = fv;
     if (out_s) out_s[(size_t)b * 3 * (T + 1) + q] = fv;
   }
+  if (trig_out)                         // the next iteration's DUNE launches read the rotation from this table
+    for (int t = lane; t <= T; t += QP_THREADS) {
+      float c, sn;
+      npa_trig(stage[2 * (T + 1) + t], c, sn);
+      trig_out[((size_t)b * (T + 1) + t) * 2] = c;
+      trig_out[((size_t)b * (T + 1) + t) * 2 + 1] = sn;
+    }
   for (int q = lane; q < 2 * T; q += QP_THREADS) {
     int k = q / T, t = q - k * T;
     float fv = (float)xbest[2 * t + k];
@@ -1005,7 +1012,8 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
                                     const float* dist_sorted, const int* count, float* cur_s_out, float* cur_u_out,
                                     float* cur_d_out, float* out_s, float* out_u, float* out_d,
                                     float* out_min_distance, int* out_iters, float* out_nrmp_points, int* flags,
-                                    float* state, double* qp_info, double* warm, hipStream_t stream) {
+                                    float* state, double* qp_info, double* warm, float* trig_out,
+                                    hipStream_t stream) {
   static const bool force_generic = getenv("NPA_QP_GENERIC") != nullptr;
   static const bool low_prio = getenv("NPA_QP_LOWPRIO") != nullptr;
   const bool fast = qp_fast_path(P.T, P.M) && !force_generic;
@@ -1033,7 +1041,7 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
                      ref_s, ref_us, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count, cur_s_out, cur_u_out, \
                      cur_d_out, out_s, out_u, out_d, out_min_distance, out_iters, out_nrmp_points, flags, state, \
                      qp_info, warm, scene0, batch, wave_doubles, low_prio ? -wpg : wpg,                         \
-                     QpBackward{nullptr, nullptr, nullptr, nullptr, nullptr})
+                     QpBackward{nullptr, nullptr, nullptr, nullptr, nullptr}, trig_out)
   if (P.T == 10 && P.M == 10 && !force_generic) QP_LAUNCH(10, 10);
   else if (P.T == 20 && P.M == 10 && !force_generic) QP_LAUNCH(20, 10);
   else QP_LAUNCH(0, 0);
@@ -1058,6 +1066,6 @@ extern "C" hipError_t npa_launch_qp_backward(const DevParams& P, int batch, cons
                      ref_us, mu_sorted, lam_sorted, pts_sorted, (const float*)nullptr, count, out_s, out_u, out_d,
                      (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int*)nullptr, (float*)nullptr,
                      (int*)nullptr, (float*)nullptr, qp_info, (double*)nullptr, 0, batch,
-                     (int)(wave_bytes / sizeof(double)), 1, QpBackward{grad_s, grad_u, grad_d, grad_theta, grad_nom_s});
+                     (int)(wave_bytes / sizeof(double)), 1, QpBackward{grad_s, grad_u, grad_d, grad_theta, grad_nom_s}, (float*)nullptr);
   return hipGetLastError();
 }

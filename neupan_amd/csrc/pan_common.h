@@ -66,9 +66,17 @@ __host__ __device__ inline size_t npa_state_floats(int T, int M, int E) {
 // cur_s [B][3][T+1]  cur_u [B][2][T]  cur_d [B][T]  mu [B][T+1][M][E]  lam [B][T+1][M][2]
 // pts [B][T+1][M][2]  dist [B][T+1][M]  count [B][T+1] (int)
 // flags [B][4] (int: done, iters, warm-start valid)  warm [B][nwarm] (double: x, multipliers)
+// trig [B][T+1][2] (float: cos, sin of the nominal heading of every horizon step, written by whoever writes cur_s)
 // keys [B][T+1][key_stride] (uint: order-preserving distance key of every point of every slice)
+// pan.py:207 builds R from torch.cos / torch.sin of the fp32 heading... the reference's values are those of the
+// fp64 libm on the fp32 angle, rounded to fp32; ONE definition so that every producer of the table agrees bitwise
+__device__ inline void npa_trig(float th, float& c, float& s) {
+  c = (float)cos((double)th);
+  s = (float)sin((double)th);
+}
+
 struct ScratchLayout {
-  size_t cur_s, cur_u, cur_d, mu, lam, pts, dist, count, flags, warm, qp_info, keys, total;
+  size_t cur_s, cur_u, cur_d, mu, lam, pts, dist, count, flags, warm, qp_info, trig, keys, total;
 };
 __host__ __device__ inline size_t npa_warm_doubles(int T, int M) {   // per scene
   return (size_t)2 * T + T + (size_t)T * M + (8 * T - 4) + 2 * T;
@@ -89,6 +97,7 @@ __host__ __device__ inline ScratchLayout npa_scratch_layout(int B, int T, int M,
   o = (o + 3) & ~(size_t)3;                       // 16-byte alignment for the doubles
   L.warm = take((size_t)B * npa_warm_doubles(T, M) * 2);
   L.qp_info = take((size_t)B * 16 * 2);          // per-scene solver diagnostics of the last QP (16 doubles)
+  L.trig = take((size_t)B * (T + 1) * 2);        // (cos, sin) of every nominal heading, see npa_trig()
   L.keys = take((size_t)B * (T + 1) * key_stride);
   L.total = o;
   return L;
