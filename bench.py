@@ -24,7 +24,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # The interleaved schedule is sensitive to how HIP maps streams onto hardware queues: with the runtime's
 # default of 4 the five helper streams share three queues, which measures best (2/3/4/5/6/8 queues:
@@ -129,11 +128,19 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from gpu_helpers import make_gpu_pan
-    from helpers import CONFIGS
+    # the measured leg imports the product only; tests/helpers (and with it oracle/) is touched by cpu_baseline alone
     from neupan_amd.dist import gather_controls
-    from neupan_amd.pan import PanPipeline, forward_interleaved
-    from neupan_amd.scenes import make_batch
+    from neupan_amd.pan import PAN, PanPipeline, forward_interleaved
+    from neupan_amd.robot import Robot
+    from neupan_amd.scenes import CONFIGS, make_batch
+
+    def make_gpu_pan(cfg, device):
+        ck = os.path.join(ROOT, "tests", "golden", "checkpoints", f"{cfg.checkpoint}_model_5000.pth")
+        if not os.path.exists(ck):              # the 8-edge stand-in: tests/golden/make_poly8_checkpoint.py
+            ck = os.path.join(ROOT, "tests", "golden", "checkpoints", f"{cfg.checkpoint}_model_quick.pth")
+        return PAN(cfg.T, cfg.dt, Robot(cfg.T, cfg.dt, **cfg.robot), iter_num=cfg.iter_num, dune_max_num=cfg.n_points,
+                   nrmp_max_num=cfg.nrmp_max_num, iter_threshold=0.0, dune_checkpoint=ck, adjust_kwargs=dict(cfg.adjust),
+                   device=device)
 
     cfg = CONFIGS[args.workload]
     BATCH = args.batch
