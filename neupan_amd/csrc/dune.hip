@@ -715,10 +715,6 @@ extern "C" hipError_t npa_launch_encode(const DevParams& P, const float* wpack, 
   // 4-wave workgroups (more CUs busy).  NPA_ENC_WAVES=4 forces the small form.
   static const bool small_only = getenv("NPA_ENC_WAVES") && atoi(getenv("NPA_ENC_WAVES")) == 4;
   int waves = (split && !small_only && tiles >= (long long)n_cu * 16 * 4) ? 16 : DUNE_WAVES;
-#ifdef NPA_OCC_EXPERIMENT
-  static const int wexp = getenv("NPA_ENC_WAVES") ? atoi(getenv("NPA_ENC_WAVES")) : 0;
-  if (split && (wexp == 8 || wexp == 12)) waves = wexp;
-#endif
   const int slots = waves >= 8 ? n_cu : n_cu * blocks_per_cu;
   int blocks = (int)((tiles + waves - 1) / waves);
   if (blocks > slots) blocks = slots;
@@ -726,11 +722,6 @@ extern "C" hipError_t npa_launch_encode(const DevParams& P, const float* wpack, 
   const size_t shmem = (11 * 32 + 8 * 32 + 8) * sizeof(float) + (split ? WP_KEY_LDS_FLOATS * sizeof(float) : 0);
   static const int chunk_env = getenv("NPA_ENC_CHUNK") ? atoi(getenv("NPA_ENC_CHUNK")) : 2;
   const int chunk = chunk_env < 1 ? 1 : chunk_env;
-#ifdef NPA_OCC_EXPERIMENT
-#define OCC_CASES(EE) else if (split && waves == 8) LAUNCH1(EE, 3, 8); else if (split && waves == 12) LAUNCH1(EE, 3, 12);
-#else
-#define OCC_CASES(EE)
-#endif
 #define LAUNCH1(EE, SP, WV)                                                                                         \
   hipExtLaunchKernelGGL((dune_kernel<EE, SP, WV>), dim3(blocks), dim3(64 * WV), shmem, stream, ev_start, ev_stop, 0, \
                         P, wpack, n_stride, cur_s, points, vel, n_points, flags, gkeys, tps * 32, scene0, batch, t0, \
@@ -740,7 +731,6 @@ extern "C" hipError_t npa_launch_encode(const DevParams& P, const float* wpack, 
     if (single && waves == 16) LAUNCH1(EE, 1, 16);                                                                  \
     else if (single) LAUNCH1(EE, 1, DUNE_WAVES);                                                                    \
     else if (split && waves == 16) LAUNCH1(EE, 3, 16);                                                              \
-    OCC_CASES(EE)                                                                                                   \
     else if (split) LAUNCH1(EE, 3, DUNE_WAVES);                                                                     \
     else LAUNCH1(EE, 0, DUNE_WAVES);                                                                                \
   } while (0)
