@@ -41,7 +41,9 @@ PEAK_F16_MFMA_TFLOPS = 2500.0           # dense fp16/bf16 MFMA, same table
 
 def _cpu_worker(job):
     """One worker process of the CPU baseline: the oracle, single-threaded, on its share of the scenes.
-    Returns (list of (scene, u, moving), seconds spent planning)."""
+    Returns (list of (scene, u, self_sensitivity), seconds spent planning).  self_sensitivity: how far the oracle's
+    own control output moves when every obstacle coordinate of its input changes by one float32 ulp (a second,
+    untimed run) -- where that is large the reference algorithm itself has no well-defined answer to compare with."""
     workload, scenes = job
     os.environ["OMP_NUM_THREADS"] = os.environ["MKL_NUM_THREADS"] = os.environ["OPENBLAS_NUM_THREADS"] = "1"
     import numpy as _np
@@ -58,16 +60,19 @@ def _cpu_worker(job):
     cfg = CONFIGS[workload]
     out = []
     make_oracle(cfg)                                   # imports / checkpoint load outside the timed part
-    t0 = time.perf_counter()
+    spent = 0.0
     for b in scenes:
         sc = make_scene(cfg, b)
+        t0 = time.perf_counter()
         orc = make_oracle(cfg)
         s, u, d = orc.forward(sc["nom_s"], sc["nom_u"], sc["ref_s"], sc["ref_us"], sc["points"], sc["velocities"])
-        # does the oracle's own PAN iteration still move at the last step?  (a non-contracting
-        # fixed-point iteration amplifies 1e-7 differences by a constant factor per iteration)
-        mv = float(_np.linalg.norm(orc.trace[-1][1] - orc.trace[-2][1])) if len(orc.trace) > 1 else 0.0
-        out.append((b, u, mv))
-    return out, time.perf_counter() - t0
+        spent += time.perf_counter() - t0
+        # a PAN iteration that does not contract within K amplifies 1e-7 differences by a constant factor per
+        # iteration: measure that on the oracle itself (not part of the timed baseline)
+        pts = _np.nextafter(sc["points"], _np.float32(_np.inf))
+        s2, u2, d2 = make_oracle(cfg).forward(sc["nom_s"], sc["nom_u"], sc["ref_s"], sc["ref_us"], pts, sc["velocities"])
+        out.append((b, u, float(_np.linalg.norm(u - u2))))
+    return out, spent
 
 
 def cpu_baseline(workload, n_scenes, u_gpu, cores):
@@ -275,18 +280,23 @@ def main():
         ncore = args.cpu_cores if args.cpu_cores > 0 else min(os.cpu_count() or 1, 32)
         cpu_rate, errs, moving, ncore = cpu_baseline(args.workload, args.cpu_scenes, u_gpu, ncore)
         errs, moving = np.array(errs), np.array(moving)
-        conv = moving <= 1.0
+        conv = moving <= 1e-4                       # oracle output stable under a 1-ulp change of its input
+        worst = np.argsort(-errs)[:5]
         line["cpu_baseline"] = {"value": round(cpu_rate, 3), "unit": "plans/s", "cores": ncore, "kind": "port",
                                 "sample": f"first {args.cpu_scenes} scenes of the same workload, K={K} each, "
                                           f"oracle/pan_oracle.py (numpy fp32 + fp64 IPM), {ncore} worker processes x 1 thread "
                                           f"(host has {os.cpu_count()} cores)"}
         line["parity"] = {"ctrl_l2_vs_oracle_median": float(np.median(errs)), "max": float(errs.max()),
                           "frac_le_1e-4": float((errs <= 1e-4).mean()), "scenes": int(len(errs)),
-                          "scenes_with_contracting_pan_iteration": int(conv.sum()),
-                          "max_over_contracting": float(errs[conv].max()) if conv.any() else None,
-                          "note": "oracle = reference code restated + substituted fp64 QP solver (ECOS unavailable); on the scenes whose "
-                                  "PAN iteration does not contract within K the oracle's own output moves as much under a "
-                                  "1-ulp change of its input (DESIGN.md section 5)"}
+                          "scenes_well_posed": int(conv.sum()),
+                          "max_over_well_posed": float(errs[conv].max()) if conv.any() else None,
+                          "worst_scenes": [{"scene": int(b), "ctrl_l2": float(errs[b]), "oracle_self_sensitivity": float(moving[b])}
+                                           for b in worst],
+                          "note": "oracle = reference code restated + substituted fp64 QP solver (ECOS unavailable).  well posed = "
+                                  "the oracle's own control output moves <= 1e-4 when every obstacle coordinate of its input "
+                                  "changes by one float32 ulp (second, untimed oracle run per scene); elsewhere the PAN "
+                                  "iteration does not contract within K and the reference algorithm has no answer that is "
+                                  "stable to rounding (DESIGN.md section 5)"}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
