@@ -2,9 +2,13 @@
 1e-4, how the ORACLE itself behaves there -- movement of its own PAN iteration at the last steps and how far its
 output moves when every obstacle coordinate changes by one float32 ulp (the yardstick of DESIGN.md section 5).
 
-    python tests/tools/parity_outliers.py [workload] [scenes] [workers]
+    timeout 300 python tests/tools/parity_outliers.py [workload] [scenes] [workers]
 """
 import os, sys
+# the worker processes re-import this module: one thread each, or 64 workers x (host cores) BLAS/OpenMP threads
+# oversubscribe the box by orders of magnitude (a run without these lines did not finish in 15 minutes)
+for _v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+    os.environ.setdefault(_v, "1")
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -17,7 +21,13 @@ WORKERS = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 cfg = CONFIGS[W]
 
 
+def _one_thread():
+    import torch
+    torch.set_num_threads(1)
+
+
 def job(b):
+    _one_thread()
     sc = make_scene(cfg, b)
     o = make_oracle(cfg)
     s, u, d = o.forward(sc["nom_s"], sc["nom_u"], sc["ref_s"], sc["ref_us"], sc["points"], sc["velocities"])
@@ -26,6 +36,7 @@ def job(b):
 
 
 def job_ulp(b):
+    _one_thread()
     sc = make_scene(cfg, b)
     pts = np.nextafter(sc["points"], np.float32(np.inf))
     o = make_oracle(cfg)
