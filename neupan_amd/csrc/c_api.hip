@@ -299,6 +299,17 @@ static void drop_pending(npa_handle* h);
 extern "C" int npa_destroy(npa_handle* h) {
   if (!h) return NPA_OK;
   drop_pending(h);
+  {
+    // launches of this handle may still be queued on streams it does not own (and a 4-byte counter copy into its
+    // pinned buffer behind the last forward call): let the device finish before anything is freed
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess) {
+      if (cur != h->device) (void)hipSetDevice(h->device);
+      (void)hipDeviceSynchronize();
+      if (cur != h->device) (void)hipSetDevice(cur);
+    }
+    (void)hipGetLastError();
+  }
   for (auto& p : h->ev_dune) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto& p : h->ev_qp) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto& ev : h->sync_ev) hipEventDestroy(ev);
