@@ -229,7 +229,34 @@ def run_dune_train_losses():
     print("dune_train_losses.npz:", out)
 
 
+def run_pathbook():
+    """frontend_pathbook.npz: the host bookkeeping around a path -- `set_initial_path` (average interval, split by
+    gear: initial_path.py:128-158, :289-315) and `_ensure_consistent_angles` (:476-497)"""
+    out, names = {}, []
+    robot = types.SimpleNamespace(kinematics="diff", L=0.0, max_speed=[8.0, 1.0])
+    three_gear = line_path(7, 0.5) + reverse_path(5, 0.3) + line_path(4, 0.7, theta=0.4, x0=-1.2, y0=0.3)
+    for name, path in (("line", line_path(20, 0.4)), ("two_gear", two_gear_path()), ("three_gear", three_gear),
+                       ("corner", corner_path(1.0)), ("arc", arc_path(30, 6.0, 1.0, 0.07)), ("single", line_path(1, 0.4))):
+        ip = InitialPath(10, 0.1, 4.0, robot)
+        ip.set_initial_path(copy.deepcopy(path))
+        names.append(name)
+        out[name + "/path"] = np.hstack(path).T
+        out[name + "/interval"] = np.array(float(ip.interval))
+        out[name + "/curve_len"] = np.array([len(c) for c in ip.curve_list])
+        out[name + "/curves"] = np.vstack([np.hstack(c).T for c in ip.curve_list])
+        ip2 = InitialPath(10, 0.1, 4.0, robot)
+        ip2.initial_path = copy.deepcopy(path)
+        ip2._ensure_consistent_angles()
+        out[name + "/consistent"] = np.hstack(ip2.initial_path).T
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "frontend_pathbook.npz"), **out)
+    print("frontend_pathbook.npz:", len(names), "cases")
+
+
 if __name__ == "__main__":
+    run_pathbook()
+    if "--only-pathbook" in sys.argv:
+        sys.exit(0)
     run_nominal()
     run_scan()
     run_progress()

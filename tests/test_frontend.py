@@ -240,3 +240,20 @@ def test_hip_path_progress_vs_reference_vectors():
         for j, r in enumerate(sel):
             assert pidx[j] == int(r[8]) and bool(arr[j]) == bool(r[10])
             assert abs(md[j] - np.float32(r[9])) <= 1e-6
+
+
+def test_path_bookkeeping_matches_reference():
+    """gear split, average interval (FleetPlanner.set_paths) and heading repair (planner._consistent_angles) against
+    the reference's own InitialPath.set_initial_path / _ensure_consistent_angles (frontend_pathbook.npz)"""
+    from neupan_amd.fleet import FleetPlanner
+    from neupan_amd.planner import _consistent_angles
+    g = np.load(os.path.join(HERE, "golden", "frontend_pathbook.npz"))
+    for name in g["names"]:
+        name = str(name)
+        path = [row.reshape(4, 1).copy() for row in g[name + "/path"]]
+        curves = FleetPlanner._split_by_gear(path)
+        assert [len(c) for c in curves] == list(g[name + "/curve_len"]), name
+        assert np.array_equal(np.vstack(curves), g[name + "/curves"]), name
+        assert FleetPlanner._average_interval(path) == float(g[name + "/interval"]), name
+        _consistent_angles(path)
+        assert np.array_equal(np.hstack(path).T, g[name + "/consistent"]), name
