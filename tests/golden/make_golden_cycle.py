@@ -27,25 +27,46 @@ def line(n, step, y=0.0, gear=1.0, x0=0.0, sgn=1.0):
     return [np.array([[x0 + sgn * i * step], [y], [0.0], [gear]]) for i in range(n)]
 
 
-def build(iter_num, dune_max_num, iter_threshold, collision_threshold=0.1):
-    p = RefNeupan(receding=10, step_time=0.1, ref_speed=4.0, device="cpu", robot_kwargs=dict(ROBOT),
+ACKER = dict(kinematics="acker", max_speed=[8, 1], max_acce=[8, 0.5], length=4.6, width=1.6, wheelbase=3.0)
+OMNI = dict(kinematics="omni", max_speed=[8, 3.2], max_acce=[8, 8], length=1.6, width=2.0)
+
+
+def build(iter_num, dune_max_num, iter_threshold, collision_threshold=0.1, robot=None, ckpt="diff_robot_default"):
+    p = RefNeupan(receding=10, step_time=0.1, ref_speed=4.0, device="cpu", robot_kwargs=dict(robot or ROBOT),
                   ipath_kwargs=dict(waypoints=None, curve_style="line", loop=False),
                   pan_kwargs=dict(iter_num=iter_num, dune_max_num=dune_max_num, nrmp_max_num=10,
-                                  dune_checkpoint=CKPT["diff_robot_default"], iter_threshold=iter_threshold),
+                                  dune_checkpoint=CKPT[ckpt], iter_threshold=iter_threshold),
                   adjust_kwargs=dict(ADJUST), train_kwargs=dict(), collision_threshold=collision_threshold, time_print=False)
     if not REAL:
         p.pan.nrmp_layer.nrmp_layer = OracleLayer(p.pan.nrmp_layer)
     return p
 
 
-def run(name, path, state0, points, cycles, iter_num=2, dune_max_num=100, iter_threshold=0.1, velocities=None):
-    p = build(iter_num, dune_max_num, iter_threshold)
+def step(kin, L, state, action):
+    """the simulated robot: one Euler step of the reference's own motion models (initial_path.py:388-444); for omni the
+    action is (vx, vy) (neupan.py:158-164)"""
+    x, y, th = state[:, 0]
+    a, b = float(action[0, 0]), float(action[1, 0])
+    if kin == "diff":
+        d = [a * np.cos(th), a * np.sin(th), b]
+    elif kin == "acker":
+        d = [a * np.cos(th), a * np.sin(th), a * np.tan(b) / L]
+    else:
+        d = [a, b, 0.0]
+    return state + 0.1 * np.array(d).reshape(3, 1)
+
+
+def run(name, path, state0, points, cycles, iter_num=2, dune_max_num=100, iter_threshold=0.1, velocities=None, robot=None,
+        ckpt="diff_robot_default"):
+    robot = dict(robot or ROBOT)
+    p = build(iter_num, dune_max_num, iter_threshold, robot=robot, ckpt=ckpt)
     p.set_initial_path([q.copy() for q in path])
     state = np.asarray(state0, dtype=np.float64).reshape(3, 1)
     rec = dict(states=[], actions=[], arrive=[], stop=[], min_distance=[], opt_u=[], ref_s=[], point_index=[], curve_index=[])
     for c in range(cycles):
         rec["states"].append(state[:, 0].copy())
-        action, info = p(state.copy(), None if points is None else points.copy(), velocities)
+        pts_c = None if points is None else (points if velocities is None else points + c * 0.1 * velocities)
+        action, info = p(state.copy(), None if pts_c is None else pts_c.copy(), velocities)
         rec["actions"].append(np.asarray(action, dtype=np.float64).reshape(2))
         rec["arrive"].append(bool(info["arrive"])); rec["stop"].append(bool(info["stop"]))
         md = p.min_distance
@@ -53,12 +74,14 @@ def run(name, path, state0, points, cycles, iter_num=2, dune_max_num=100, iter_t
         rec["opt_u"].append(np.asarray(p.cur_vel_array, dtype=np.float64).copy())
         rec["ref_s"].append(info["ref_state_tensor"].numpy().astype(np.float64) if "ref_state_tensor" in info else np.zeros((3, 11)))
         rec["point_index"].append(int(p.ipath.point_index)); rec["curve_index"].append(int(p.ipath.curve_index))
-        v, w = float(action[0, 0]), float(action[1, 0])
-        state = state + 0.1 * np.array([[v * np.cos(state[2, 0])], [v * np.sin(state[2, 0])], [w]])
+        state = step(robot["kinematics"], robot.get("wheelbase", 0.0), state, np.asarray(action, dtype=np.float64))
     out = {k: np.array(v) for k, v in rec.items()}
     out["path"] = np.hstack(path).T
     out["points"] = np.zeros((2, 0)) if points is None else points
     out["meta"] = np.array([iter_num, dune_max_num, iter_threshold], dtype=np.float64)
+    out["velocities"] = np.zeros((2, 0)) if velocities is None else velocities
+    import json
+    out["robot"] = np.array(json.dumps(robot)); out["ckpt"] = np.array(ckpt)
     out["solver"] = np.array("reference" if REAL else "reference code with substituted solver")
     np.savez_compressed(os.path.join(HERE, f"cycle_{name}.npz"), **out)
     print(f"cycle_{name}.npz: {cycles} cycles, arrive {out['arrive'].astype(int).tolist()}, stop {out['stop'].astype(int).tolist()}, "
@@ -80,3 +103,11 @@ if __name__ == "__main__":
     run("stop", line(40, 0.4), [0.0, 0.0, 0.0], close, 3)
     # no obstacle points at all
     run("no_points", line(40, 0.4), [0.0, 0.3, 0.1], None, 3)
+    # car-like robot backing up along a reverse-gear path
+    run("acker_reverse", line(40, 0.4, gear=-1.0, sgn=-1.0), [0.0, 0.1, 0.03], walls[:, 3:203] - np.array([[30.0], [0.0]]), 5,
+        robot=ACKER, ckpt="acker_robot_default")
+    # omnidirectional robot: the action is (vx, vy)
+    run("omni", line(60, 0.4), [0.0, -0.1, 0.0], walls, 5, robot=OMNI)
+    # moving obstacle points (scan_to_point_velocity's output): iter_num 3, no early exit
+    vel = rng.uniform(-1, 1, (2, 200))
+    run("dyna", line(76, 0.4), [0.0, 0.0, 0.0], walls[:, :200], 5, iter_num=3, iter_threshold=0.0, velocities=vel)
