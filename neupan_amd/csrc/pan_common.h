@@ -68,8 +68,9 @@ __host__ __device__ inline size_t npa_state_floats(int T, int M, int E) {
 // flags [B][4] (int: done, iters, warm-start valid)  warm [B][nwarm] (double: x, multipliers)
 // trig [B][T+1][2] (float: cos, sin of the nominal heading of every horizon step, written by whoever writes cur_s)
 // keys [B][T+1][key_stride] (uint: order-preserving distance key of every point of every slice)
-// pan.py:207 builds R from torch.cos / torch.sin of the fp32 heading... the reference's values are those of the
-// fp64 libm on the fp32 angle, rounded to fp32; ONE definition so that every producer of the table agrees bitwise
+// pan.py:207 builds R from torch.cos / torch.sin of the fp32 heading (fp32 libm: within 1 ulp of the correctly rounded
+// value); here: fp64 libm on the fp32 angle, rounded once to fp32.  ONE definition so that every producer of the table
+// (stage_kernel, the QP's write-out, trig_kernel) agrees bitwise
 __device__ inline void npa_trig(float th, float& c, float& s) {
   c = (float)cos((double)th);
   s = (float)sin((double)th);
