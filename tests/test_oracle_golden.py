@@ -104,7 +104,12 @@ PANS = [("diff_n1000_k3", "diff_1k_T10_K10", dict(iter_num=3)),
         ("nopoints_k3", "diff_1k_T10_K10", dict(iter_num=3)),
         ("noobs_m0_k3", "diff_1k_T10_K10", dict(iter_num=3, nrmp_max_num=0)),
         ("default_thr_3calls", "diff_1k_T10_K10", dict(iter_num=6, iter_threshold=0.1, dune_max_num=100)),
-        ("qs_vector_k2", "diff_1k_T10_K10", dict(iter_num=2, adjust=dict(q_s=[1.0, 0.8, 0.3])))]
+        ("qs_vector_k2", "diff_1k_T10_K10", dict(iter_num=2, adjust=dict(q_s=[1.0, 0.8, 0.3]))),
+        # tests/golden/make_golden_more.py
+        ("decimate_n500_k3", "diff_1k_T10_K10", dict(iter_num=3, dune_max_num=100)),
+        ("omni_dyna_n80_k3", "dyna_4k_T10_K10", dict(iter_num=3, dune_max_num=80, robot_kw=OMNI)),
+        ("acker_reverse_n150_k4", "acker_2k_T20_K15", dict(iter_num=4, dune_max_num=150)),
+        ("polygon_dyna_n100_k3", "dyna_4k_T10_K10", dict(iter_num=3, dune_max_num=100, robot_kw=POLY, checkpoint="polygon_robot"))]
 
 
 @pytest.mark.parametrize("case,cfgname,over", PANS)
