@@ -761,10 +761,20 @@ extern "C" hipError_t npa_launch_select(const DevParams& P, const float* wpack, 
   const int approx = key_terms == 0 ? 0 : dbg;
   const size_t shmem = (11 * 32 + 8 * 32 + 8) * sizeof(float) + (NPA_MAX_M + 64) * sizeof(int) +
                        ((size_t)tps * 32 * sizeof(unsigned) + 15) / 16 * 16;
+  // slices of more than ~15 000 points keep more than the default 64 KB of dynamic LDS (4 B per key)
 #define LAUNCH(EE)                                                                                                  \
-  hipLaunchKernelGGL(select_kernel<EE>, dim3(nsl, batch), dim3(64), shmem, stream, P, wpack, n_stride, cur_s, points, \
-                     vel, n_points, flags, gkeys, tps * 32, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count,  \
-                     scene0, t0, approx, e0, stats, trig)
+  do {                                                                                                              \
+    static bool big_lds = false;                                                                                    \
+    if (shmem > 60 * 1024 && !big_lds) {                                                                            \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel<EE>),                         \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
+      if (e_ != hipSuccess) return e_;                                                                              \
+      big_lds = true;                                                                                               \
+    }                                                                                                               \
+    hipLaunchKernelGGL(select_kernel<EE>, dim3(nsl, batch), dim3(64), shmem, stream, P, wpack, n_stride, cur_s,     \
+                       points, vel, n_points, flags, gkeys, tps * 32, mu_sorted, lam_sorted, pts_sorted, dist_sorted, \
+                       count, scene0, t0, approx, e0, stats, trig);                                                 \
+  } while (0)
   switch (P.E) {
     case 3: LAUNCH(3); break;
     case 4: LAUNCH(4); break;

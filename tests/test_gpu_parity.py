@@ -403,3 +403,29 @@ def test_selection_with_many_near_ties_equals_exact_key_selection():
             first = u
         assert np.array_equal(u, first), rep
     assert modes <= {1, 3}
+
+
+@pytest.mark.parametrize("npts", [20000, 32768])
+def test_maximum_slice_sizes(npts):
+    """Slices beyond ~15 000 points keep more than 64 KB of keys in select_kernel's LDS; 32 768 points per scene is the
+    documented maximum (NPA_MAX_POINTS).  The DUNE stage in the default key mode must emit bitwise the rows of the
+    exact-key mode (same process: the mode is read when a handle is created), and a forward call must run."""
+    import os
+    from gpu_helpers import make_gpu_pan
+    from neupan_amd.scenes import make_batch
+    cfg = CONFIGS["diff_1k_T10_K10"]
+    batch = make_batch(cfg, 500, 2, n_points=npts)
+    assert batch["points"].shape[2] == npts
+    pan = make_gpu_pan(cfg, dune_max_num=npts, iter_num=2)
+    os.environ["NPA_DUNE_FP32KEYS"] = "1"
+    try:
+        exact = make_gpu_pan(cfg, dune_max_num=npts, iter_num=2)
+    finally:
+        del os.environ["NPA_DUNE_FP32KEYS"]
+    assert exact.key_mode()["key_terms"] == 0 and pan.key_mode()["key_terms"] in (1, 3)
+    a = pan.dune_stage(batch["nom_s"], batch["points"])
+    b = exact.dune_stage(batch["nom_s"], batch["points"])
+    for k in ("mu", "lam", "pts", "dist", "count"):
+        assert np.array_equal(a[k].cpu().numpy(), b[k].cpu().numpy()), k
+    out = pan.forward_batch(batch["nom_s"], batch["nom_u"], batch["ref_s"], batch["ref_us"], batch["points"])
+    assert np.isfinite(out["opt_u"].cpu().numpy()).all() and (out["iters"].cpu().numpy() == 2).all()
