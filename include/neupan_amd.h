@@ -80,10 +80,16 @@ int npa_create(const npa_config *cfg, const npa_dune_weights *w, npa_handle **ou
 int npa_destroy(npa_handle *h);
 
 /* How this handle computes the distance KEYS that nominate the nrmp_max_num nearest points of a slice (the rows it
- * emits are always re-encoded with the exact fp32 encoder; dune.py:100 argsort is reproduced on those):
- *   key_terms 1 = single fp16 products, 3 = fp16x2 split products, 0 = exact fp32 encoder;
- *   measured_error = max |key - exact| / (1 + |exact|) over a 256 x 256 grid of the training square, measured by
- *   npa_create for THIS checkpoint; margin_e0 = the candidate margin built from it (NPA_KEY_SAFETY x, default 6). */
+ * emits are always re-encoded with the exact fp32 encoder and ranked on the exact result; dune.py:100 argsort is
+ * reproduced on those):
+ *   key_terms 4 = geometric: closed-form distance to the robot polygon, computed inside the selection kernel (no
+ *               encoder pass over all points); measured_error = largest |network distance - geometric distance| [m]
+ *               over the distance bands 0.25 .. 8 m, margin_e0 = the largest candidate margin over those bands
+ *               (1.5 x (error + grid slack), NPA_KEY_SAFETY); both measured by npa_create for THIS checkpoint on nested
+ *               4096 x 4096 grids out to +-128 m; points further out are always candidates;
+ *   key_terms 1 = network keys with single fp16 products, 3 = fp16x2 split products, 0 = exact fp32 encoder:
+ *               measured_error = max |key - exact| / (1 + |exact|) over a 1024 x 1024 grid of the training square
+ *               (|x|, |y| <= 25 m), margin_e0 = 5 x that (NPA_KEY_SAFETY). */
 int npa_key_mode(const npa_handle *h, int *key_terms, float *measured_error, float *margin_e0);
 
 /* Replaces NRMP.update_adjust_parameters_value (nrmp.py:170-217). */
@@ -104,8 +110,8 @@ size_t npa_workspace_qp_info_offset(const npa_handle *h, int batch);
  *         stop_criteria (pan.py:215-243) }.
  * Inputs  nom_s [B][3][T+1], nom_u [B][2][T], ref_s [B][3][T+1], ref_us [B][T],
  *         points [B][2][n_stride] (global frame), velocities same shape or NULL,
- *         n_points [B] int32 (<= n_stride; 0 = no obstacle points for that scene) or NULL
- *         meaning every scene has n_stride points.  Point sets larger than dune_max_num
+ *         n_points [B] int32 (0 = no obstacle points for that scene; values outside [0, n_stride] are clamped
+ *         into it by the kernels) or NULL meaning every scene has n_stride points.  Point sets larger than dune_max_num
  *         are decimated in-kernel exactly like util.downsample_decimation (util:285-305).
  * Outputs out_s [B][3][T+1], out_u [B][2][T], out_d [B][T] (undefined when nrmp_max_num=0),
  *         out_min_distance [B] (DUNE.min_distance, dune.py:97-98; +inf without points),
@@ -187,11 +193,11 @@ int npa_nrmp_backward(npa_handle *h, int batch, const float *nom_s, const float 
                       const float *grad_u, const float *grad_d, float *grad_theta,
                       float *grad_nom_s, double *qp_info, void *stream);
 
-/* Timing hook for bench.py: enqueue HIP events around every DUNE-stage launch of
- * subsequent npa_forward_batch calls (on the launch stream) and read back the average
- * per-launch duration in ms.  enable=0 turns it off. */
+/* Timing hook for bench.py: HIP events around every kernel launch of subsequent forward calls (on the stream each
+ * launch goes to) and the average per-launch durations in ms: dune_kernel (0 when the handle uses geometric keys:
+ * there is no such launch), select_kernel, nrmp_qp_kernel; launches = QP launches timed.  enable=0 turns it off. */
 int npa_profile_enable(npa_handle *h, int enable);
-int npa_profile_read(npa_handle *h, double *dune_ms_avg, double *nrmp_ms_avg, int64_t *launches);
+int npa_profile_read(npa_handle *h, double *dune_ms_avg, double *select_ms_avg, double *nrmp_ms_avg, int64_t *launches);
 
 /* ---- the two steps in front of PAN.forward (handle-free, stream-ordered) --------------------------
  *

@@ -19,19 +19,22 @@ extern "C" hipError_t npa_launch_encode(const DevParams& P, const float* wpack, 
 extern "C" hipError_t npa_launch_trig(const float* cur_s, int batch, int T, float* trig, hipStream_t stream);
 extern "C" hipError_t npa_launch_key_calib(const DevParams& P, const float* wpack, int key_terms, int nside, float half,
                                            unsigned* out, hipStream_t stream);
+extern "C" hipError_t npa_launch_geo_calib(const DevParams& P, const float* wpack, int nside, float half, float inner,
+                                           unsigned* out, int n_cu, hipStream_t stream);
 extern "C" hipError_t npa_launch_select(const DevParams& P, const float* wpack, int batch, int scene0, int t0,
                                         int n_stride, const float* cur_s, const float* points, const float* vel,
                                         const int* n_points, const int* flags, const unsigned* gkeys,
                                         const float* trig, float* mu_sorted, float* lam_sorted, float* pts_sorted,
                                         float* dist_sorted, int* count, int key_terms, float e0, unsigned* stats,
-                                        hipStream_t stream);
+                                        int debug, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);
 extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, const float* cur_s_in,
                                     const float* cur_u_in, const float* ref_s, const float* ref_us, const float* mu_sorted,
                                     const float* lam_sorted, const float* pts_sorted, const float* dist_sorted,
                                     const int* count, float* cur_s_out, float* cur_u_out, float* cur_d_out,
                                     float* out_s, float* out_u, float* out_d, float* out_min_distance,
                                     int* out_iters, float* out_nrmp_points, int* flags, float* state,
-                                    double* qp_info, double* warm, float* trig_out, hipStream_t stream);
+                                    double* qp_info, double* warm, float* trig_out, hipStream_t stream,
+                                    hipEvent_t ev_start, hipEvent_t ev_stop);
 extern "C" size_t npa_qp_shmem_bytes(int T, int M);
 extern "C" hipError_t npa_launch_nominal(int batch, int T, int kin, double dt, double L, const double* state,
                                          const float* vel, const double* ref_speed, const double* path,
@@ -71,8 +74,11 @@ struct npa_handle {
   bool warm_start = false;
   // distance keys (dune_kernel): 1 = single fp16 products, 3 = fp16x2 split products, 0 = the exact fp32 encoder.
   // key_e0: select_kernel's candidate margin e0 (1 + |d|), a multiple of the key error measured at creation
-  int key_terms = 1;
+  int key_terms = 1;                     // 4 = geometric keys computed by select_kernel itself (no dune_kernel launch)
   float key_e0 = 0.f, key_err = 0.f;
+  int sel_debug = 0;                     // NPA_SEL_DEBUG at creation: npa_dune_stage's count[] carries candidate statistics
+  bool geo_valid = false;                // the polygon could be turned into vertices (consecutive CCW edges)
+  float geo_err = 0.f, geo_margin = 0.f; // largest |network - geometric distance| / margin over the bands g in [0.25, 8] m
   // key_auto: both reduced-precision modes are calibrated and the handle switches between them by what the
   // single-product keys cost in select_kernel (tiles it had to re-encode because more candidates fell inside the
   // margin than one tile holds -- walls at constant distance, dense clouds), see key_policy()
@@ -88,14 +94,16 @@ struct npa_handle {
   std::vector<hipEvent_t> sync_ev;
   // profiling (bench.py): HIP events on the launch stream around every stage launch
   bool prof = false;
-  std::vector<EventPair> ev_dune, ev_qp;
-  size_t n_dune = 0, n_qp = 0;
+  std::vector<EventPair> ev_dune, ev_sel, ev_qp;
+  size_t n_dune = 0, n_sel = 0, n_qp = 0;
 };
 
 extern "C" const char* npa_last_error(void) { return g_err.c_str(); }
 extern "C" const char* npa_version(void) { return "neupan_amd 0.1 (gfx950)"; }
 
 static int mdim(const DevParams& P) { return P.M > 0 ? P.M : 1; }
+// per-slice stride of the key buffer inside the workspace: none with geometric keys (select_kernel keeps them in LDS)
+static int kstride(const npa_handle* h) { return h->key_terms == 4 ? 0 : h->P.key_stride; }
 
 extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_handle** out) {
   if (!cfg || !out) return fail(NPA_E_ARG, "npa_create: null argument");
@@ -125,8 +133,40 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
   for (int k = 0; k < 3; ++k) P.q_s[k] = cfg->q_s[k];
   P.p_u = cfg->p_u; P.eta = cfg->eta; P.d_max = cfg->d_max; P.d_min = cfg->d_min;
   for (int e = 0; e < NPA_MAX_E; ++e) { P.G[e][0] = cfg->G[e][0]; P.G[e][1] = cfg->G[e][1]; P.h[e] = cfg->h[e]; }
+  // Vertices of {x : G x <= h} for the geometric distance keys: vertex e = edges e-1 and e, which holds when the rows
+  // are consecutive counter-clockwise edges (util.gen_inequal_from_vertex, util/__init__.py:161-206, produces them
+  // so).  Any other row order fails the check below and the handle keeps network keys.
+  {
+    const int E = P.E;
+    double V[NPA_MAX_E][2];
+    bool ok = true;
+    for (int e = 0; e < E && ok; ++e) {
+      const int p = e == 0 ? E - 1 : e - 1;
+      const double a = P.G[p][0], b = P.G[p][1], c = P.G[e][0], d = P.G[e][1];
+      const double det = a * d - b * c;
+      if (!(det > 0.0)) { ok = false; break; }                 // counter-clockwise turn from edge e-1 to edge e
+      V[e][0] = ((double)P.h[p] * d - b * (double)P.h[e]) / det;
+      V[e][1] = (a * (double)P.h[e] - (double)P.h[p] * c) / det;
+    }
+    for (int e = 0; e < E && ok; ++e) {
+      const int n = e + 1 == E ? 0 : e + 1;
+      const double dx = V[n][0] - V[e][0], dy = V[n][1] - V[e][1], l2 = dx * dx + dy * dy;
+      // edge e must run along row e: G_e parallel to (dy, -dx), and every vertex must satisfy every row
+      const double gn = std::sqrt((double)P.G[e][0] * P.G[e][0] + (double)P.G[e][1] * P.G[e][1]);
+      if (!(l2 > 0.0) || !(gn > 0.0) || std::fabs(P.G[e][0] * dx + P.G[e][1] * dy) > 1e-5 * gn * std::sqrt(l2) ||
+          !(P.G[e][0] * dy - P.G[e][1] * dx > 0.0))
+        ok = false;
+      for (int r = 0; r < E && ok; ++r)
+        if (P.G[r][0] * V[e][0] + P.G[r][1] * V[e][1] - P.h[r] > 1e-5 * (1.0 + std::fabs((double)P.h[r]))) ok = false;
+      P.pvx[e] = (float)V[e][0]; P.pvy[e] = (float)V[e][1]; P.pdx[e] = (float)dx; P.pdy[e] = (float)dy;
+      P.pil[e] = l2 > 0.0 ? (float)(1.0 / l2) : 0.f;
+    }
+    h->geo_valid = ok;
+    P.geo_rcal = 0.f;
+  }
 
   std::vector<float> pack(WP_TOTAL, 0.f);
+  for (int i = 0; i < NPA_GEO_BANDS; ++i) pack[WP_GEO + i] = INFINITY;
   if (need_w) {
     const int E = P.E;
     for (int l = 0; l < 64; ++l) pack[WP_W1 + l] = w->lin_w[0][(l & 31) * 2 + (l >> 5)];   // A[i][k] = W1[i][k]
@@ -234,6 +274,7 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
     if (v >= 1 && v <= 4) h->n_sub = v;
   }
   if (const char* env = getenv("NPA_QP_WARM")) h->warm_start = atoi(env) != 0;
+  h->sel_debug = getenv("NPA_SEL_DEBUG") != nullptr;
   if (const char* env = getenv("NPA_ENC_BLOCKS")) { int v = atoi(env); if (v >= 1 && v <= 8) h->enc_blocks = v; }
   hipError_t e = hipGetDevice(&h->device);
   if (e == hipSuccess) {
@@ -246,46 +287,100 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
   h->own_aux0 = h->aux[0];
   if (e == hipSuccess) e = hipMalloc(&h->wpack, WP_TOTAL * sizeof(float));
   if (e == hipSuccess) e = hipMemcpy(h->wpack, pack.data(), WP_TOTAL * sizeof(float), hipMemcpyHostToDevice);
-  // Key mode and candidate margin.  The reduced-precision key path only nominates candidates (select_kernel
-  // re-encodes them exactly), so its error decides nothing but how many candidates there are -- PROVIDED the
-  // margin covers it.  The error is a property of the checkpoint: measure it here on a 1024 x 1024 grid over the
-  // training square (|x|, |y| <= 25 m) and set e0 = NPA_KEY_SAFETY (default 5) x the largest |key - exact| / (1 + |exact|).
-  // Single fp16 products are used when that margin stays below 5e-2, else the
-  // fp16x2 split products, else the exact encoder.  NPA_DUNE_FP32KEYS=1 / NPA_KEY_TERMS=1|3 force a mode.
+  // Key mode and candidate margin.  Distance KEYS only nominate candidates (select_kernel re-encodes them with the
+  // exact network and ranks on the exact result), so their error decides nothing but how many candidates there are
+  // -- PROVIDED the margin covers it.  The error is a property of the checkpoint and is measured here:
+  //  * geometric keys (mode 4, preferred): |network distance - closed-form distance to the polygon| per distance
+  //    band on three nested 4096 x 4096 grids (half extents 8 / 32 / 128 m, spacing 4 / 16 / 63 mm, each skipping
+  //    the square the finer one covers); margin[band] = NPA_KEY_SAFETY (default 1.5 here: the error is a smooth
+  //    deterministic function, not rounding noise) x (max |f| + max neighbour difference of f), over the band and
+  //    its two neighbours.  Used when the margin stays <= 0.15 m over the bands g in [0.25, 8] m, where the M
+  //    nearest points of a slice normally lie; a checkpoint that fits the geometry worse than that (a quick fit, a
+  //    foreign polygon) keeps network keys;
+  //  * network keys from dune_kernel: single fp16 products (1) when e0 = 5 x the largest |key - exact| / (1 + |exact|)
+  //    on a 1024 x 1024 grid over |x|, |y| <= 25 m stays below 5e-2, else fp16x2 split products (3), else the exact
+  //    encoder (0).
+  // NPA_DUNE_FP32KEYS=1 / NPA_KEY_TERMS=1|3|4 force a mode (tests).
   if (e == hipSuccess && need_w) {
     int forced = -1;
     if (getenv("NPA_DUNE_FP32KEYS")) forced = 0;
-    else if (const char* env = getenv("NPA_KEY_TERMS")) { int v = atoi(env); if (v == 1 || v == 3) forced = v; }
-    double safety = 5.0;
+    else if (const char* env = getenv("NPA_KEY_TERMS")) { int v = atoi(env); if (v == 1 || v == 3 || v == 4) forced = v; }
+    double safety = -1.0;
     if (const char* env = getenv("NPA_KEY_SAFETY")) { double v = atof(env); if (v >= 1.0 && v <= 1e3) safety = v; }
     h->key_terms = 0;
+    bool geo_ok = false;
+    if (h->geo_valid && (forced < 0 || forced == 4)) {
+      unsigned* tab = nullptr;
+      e = hipMalloc(&tab, 2 * NPA_GEO_BANDS * sizeof(unsigned));
+      if (e == hipSuccess) e = hipMemset(tab, 0, 2 * NPA_GEO_BANDS * sizeof(unsigned));
+      const float halves[3] = {8.f, 32.f, 128.f};
+      for (int gI = 0; gI < 3 && e == hipSuccess; ++gI)
+        e = npa_launch_geo_calib(P, h->wpack, 4096, halves[gI], gI == 0 ? 0.f : 0.97f * halves[gI - 1], tab, h->n_cu, nullptr);
+      unsigned bits[2 * NPA_GEO_BANDS];
+      if (e == hipSuccess) e = hipMemcpy(bits, tab, sizeof(bits), hipMemcpyDeviceToHost);
+      if (tab) hipFree(tab);
+      if (e == hipSuccess) {
+        const double sf = safety > 0 ? safety : 1.5;
+        float raw[NPA_GEO_BANDS], mg[NPA_GEO_BANDS];
+        bool seen[NPA_GEO_BANDS];
+        for (int bnd = 0; bnd < NPA_GEO_BANDS; ++bnd) {
+          float f0, f1;
+          memcpy(&f0, &bits[bnd], 4); memcpy(&f1, &bits[NPA_GEO_BANDS + bnd], 4);
+          seen[bnd] = bits[bnd] != 0u || bits[NPA_GEO_BANDS + bnd] != 0u;
+          raw[bnd] = f0 + f1;
+        }
+        float worst_err = 0.f, worst_margin = 0.f;
+        for (int bnd = 0; bnd < NPA_GEO_BANDS; ++bnd) {
+          float m = -1.f;
+          for (int q = std::max(bnd - 1, 0); q <= std::min(bnd + 1, NPA_GEO_BANDS - 1); ++q)
+            if (seen[q]) m = std::max(m, raw[q]);
+          // a band no grid point fell into (beyond the corners of the largest square) stays uncalibrated: +inf
+          mg[bnd] = (m < 0.f || !(m < 1e30f)) ? INFINITY : std::max((float)(sf * m), 1e-4f);
+          if (bnd >= npa_geo_band(0.25f) && bnd <= npa_geo_band(8.0f)) {
+            worst_margin = std::max(worst_margin, mg[bnd]);
+            float f0;
+            memcpy(&f0, &bits[bnd], 4);
+            worst_err = std::max(worst_err, f0);
+          }
+        }
+        h->geo_err = worst_err; h->geo_margin = worst_margin;
+        geo_ok = worst_margin <= 0.15f || forced == 4;
+        if (geo_ok) {
+          e = hipMemcpy(h->wpack + WP_GEO, mg, sizeof(mg), hipMemcpyHostToDevice);
+          P.geo_rcal = halves[2];
+          h->key_terms = 4; h->key_err = worst_err; h->key_e0 = worst_margin;
+        }
+      }
+    }
     unsigned* dmax = nullptr;
-    e = hipMalloc(&dmax, sizeof(unsigned));
     const int modes[2] = {1, 3};
     const float floor_e0[2] = {1e-4f, 2e-5f}, cap_e0[2] = {5e-2f, 1e-3f};
     bool ok[2] = {false, false};
-    for (int m = 0; m < 2 && e == hipSuccess && forced != 0; ++m) {
-      if (forced > 0 && forced != modes[m]) continue;
-      unsigned bits = 0;
-      e = hipMemset(dmax, 0, sizeof(unsigned));
-      if (e == hipSuccess) e = npa_launch_key_calib(P, h->wpack, modes[m], 1024, 25.0f, dmax, nullptr);
-      if (e == hipSuccess) e = hipMemcpy(&bits, dmax, sizeof(unsigned), hipMemcpyDeviceToHost);
-      if (e != hipSuccess) break;
-      float err;
-      memcpy(&err, &bits, sizeof(err));
-      h->err_mode[m] = err;
-      h->e0_mode[m] = std::max((float)(safety * err), floor_e0[m]);
-      ok[m] = h->e0_mode[m] <= cap_e0[m] || forced == modes[m];
+    if (!geo_ok && e == hipSuccess && forced != 0 && forced != 4) {
+      const double sf = safety > 0 ? safety : 5.0;
+      e = hipMalloc(&dmax, sizeof(unsigned));
+      for (int m = 0; m < 2 && e == hipSuccess; ++m) {
+        if (forced > 0 && forced != modes[m]) continue;
+        unsigned bits = 0;
+        e = hipMemset(dmax, 0, sizeof(unsigned));
+        if (e == hipSuccess) e = npa_launch_key_calib(P, h->wpack, modes[m], 1024, 25.0f, dmax, nullptr);
+        if (e == hipSuccess) e = hipMemcpy(&bits, dmax, sizeof(unsigned), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) break;
+        float err;
+        memcpy(&err, &bits, sizeof(err));
+        h->err_mode[m] = err;
+        h->e0_mode[m] = std::max((float)(sf * err), floor_e0[m]);
+        ok[m] = h->e0_mode[m] <= cap_e0[m] || forced == modes[m];
+      }
+      if (dmax) hipFree(dmax);
+      const int pick = ok[0] ? 0 : (ok[1] ? 1 : -1);
+      if (pick >= 0) { h->key_terms = modes[pick]; h->key_err = h->err_mode[pick]; h->key_e0 = h->e0_mode[pick]; }
+      h->key_auto = forced < 0 && ok[0] && ok[1];
     }
-    if (dmax) hipFree(dmax);
-    const int pick = ok[0] ? 0 : (ok[1] ? 1 : -1);
-    if (pick >= 0) { h->key_terms = modes[pick]; h->key_err = h->err_mode[pick]; h->key_e0 = h->e0_mode[pick]; }
-    h->key_auto = forced < 0 && ok[0] && ok[1] && getenv("NPA_KEY_NOAUTO") == nullptr;
     if (e == hipSuccess) e = hipMalloc(&h->sel_stats_dev, sizeof(unsigned));
     if (e == hipSuccess) e = hipMemset(h->sel_stats_dev, 0, sizeof(unsigned));
     if (e == hipSuccess) e = hipHostMalloc(&h->sel_stats_host, sizeof(unsigned), hipHostMallocDefault);
     if (e == hipSuccess) *h->sel_stats_host = 0;
-    if (const char* env = getenv("NPA_SEL_E0")) h->key_e0 = (float)atof(env);
   }
   if (e != hipSuccess) {
     npa_destroy(h);                                      // releases whatever was created so far
@@ -311,6 +406,7 @@ extern "C" int npa_destroy(npa_handle* h) {
     (void)hipGetLastError();
   }
   for (auto& p : h->ev_dune) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+  for (auto& p : h->ev_sel) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto& p : h->ev_qp) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto& ev : h->sync_ev) hipEventDestroy(ev);
   if (h->own_aux0) hipStreamDestroy(h->own_aux0);
@@ -340,11 +436,11 @@ extern "C" int npa_set_adjust(npa_handle* h, const float q_s[3], float p_u, floa
 
 extern "C" size_t npa_workspace_bytes(const npa_handle* h, int batch) {
   if (!h || batch < 1) return 0;
-  return npa_scratch_layout(batch, h->P.T, mdim(h->P), h->P.E, h->P.key_stride).total * sizeof(float);
+  return npa_scratch_layout(batch, h->P.T, mdim(h->P), h->P.E, kstride(h)).total * sizeof(float);
 }
 extern "C" size_t npa_workspace_qp_info_offset(const npa_handle* h, int batch) {
   if (!h || batch < 1) return 0;
-  return npa_scratch_layout(batch, h->P.T, mdim(h->P), h->P.E, h->P.key_stride).qp_info * sizeof(float);
+  return npa_scratch_layout(batch, h->P.T, mdim(h->P), h->P.E, kstride(h)).qp_info * sizeof(float);
 }
 extern "C" size_t npa_state_bytes(const npa_handle* h, int batch) {
   if (!h || batch < 1) return 0;
@@ -365,11 +461,12 @@ static EventPair* next_event(npa_handle* h, std::vector<EventPair>& pool, size_t
 extern "C" int npa_profile_enable(npa_handle* h, int enable) {
   if (!h) return fail(NPA_E_ARG, "null handle");
   h->prof = enable != 0;
-  h->n_dune = h->n_qp = 0;
+  h->n_dune = h->n_sel = h->n_qp = 0;
   return NPA_OK;
 }
 
-extern "C" int npa_profile_read(npa_handle* h, double* dune_ms_avg, double* nrmp_ms_avg, int64_t* launches) {
+extern "C" int npa_profile_read(npa_handle* h, double* dune_ms_avg, double* select_ms_avg, double* nrmp_ms_avg,
+                                int64_t* launches) {
   if (!h) return fail(NPA_E_ARG, "null handle");
   auto avg = [](std::vector<EventPair>& pool, size_t used, double* out) -> hipError_t {
     double tot = 0;
@@ -385,9 +482,10 @@ extern "C" int npa_profile_read(npa_handle* h, double* dune_ms_avg, double* nrmp
     return hipSuccess;
   };
   HIP_TRY(avg(h->ev_dune, h->n_dune, dune_ms_avg));
+  HIP_TRY(avg(h->ev_sel, h->n_sel, select_ms_avg));
   HIP_TRY(avg(h->ev_qp, h->n_qp, nrmp_ms_avg));
-  if (launches) *launches = (int64_t)h->n_dune;
-  h->n_dune = h->n_qp = 0;
+  if (launches) *launches = (int64_t)h->n_qp;
+  h->n_dune = h->n_sel = h->n_qp = 0;
   return NPA_OK;
 }
 
@@ -402,9 +500,10 @@ extern "C" int npa_dune_stage(npa_handle* h, int batch, int n_stride, const floa
     int nmax = n_stride < h->P.dune_max_num ? n_stride : h->P.dune_max_num;
     if (nmax > h->P.key_stride) return fail(NPA_E_UNSUPPORTED, "more than 32768 points per scene after decimation");
   }
-  // key scratch (+ one work counter) owned by the handle (the stage entry point is a
-  // test/profiling hook, the production path carves both from the caller's workspace)
-  const size_t key_bytes = (size_t)batch * (h->P.T + 1) * h->P.key_stride * sizeof(unsigned);
+  // key scratch owned by the handle (the stage entry point is a test / profiling hook, the production path carves
+  // it from the caller's workspace); none with geometric keys
+  const bool geo = h->key_terms == 4;
+  const size_t key_bytes = geo ? 0 : (size_t)batch * (h->P.T + 1) * h->P.key_stride * sizeof(unsigned);
   const size_t trig_bytes = ((size_t)batch * (h->P.T + 1) * 2 * sizeof(float) + 63) / 64 * 64;
   const size_t need = key_bytes + trig_bytes + 64;
   if (need > h->stage_cand_bytes) {
@@ -416,12 +515,13 @@ extern "C" int npa_dune_stage(npa_handle* h, int batch, int n_stride, const floa
   }
   float* trig = reinterpret_cast<float*>(reinterpret_cast<char*>(h->stage_cand) + key_bytes);
   HIP_TRY(npa_launch_trig(nom_s, batch, h->P.T, trig, (hipStream_t)stream));
-  HIP_TRY(npa_launch_encode(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr,
-                            (unsigned*)h->stage_cand, trig, h->n_cu, h->enc_blocks, h->key_terms, (hipStream_t)stream,
-                            nullptr, nullptr));
+  if (!geo)
+    HIP_TRY(npa_launch_encode(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr,
+                              (unsigned*)h->stage_cand, trig, h->n_cu, h->enc_blocks, h->key_terms, (hipStream_t)stream,
+                              nullptr, nullptr));
   HIP_TRY(npa_launch_select(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr,
                             (const unsigned*)h->stage_cand, trig, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count,
-                            h->key_terms, h->key_e0, h->sel_stats_dev, (hipStream_t)stream));
+                            h->key_terms, h->key_e0, h->sel_stats_dev, h->sel_debug, (hipStream_t)stream, nullptr, nullptr));
   return NPA_OK;
 }
 
@@ -435,7 +535,7 @@ extern "C" int npa_nrmp_stage(npa_handle* h, int batch, const float* nom_s, cons
     return fail(NPA_E_ARG, "npa_nrmp_stage: obstacle arrays required when nrmp_max_num > 0");
   HIP_TRY(npa_launch_qp(h->P, batch, 0, nom_s, nom_u, ref_s, ref_us, mu_sorted, lam_sorted, pts_sorted, nullptr, count,
                         out_s, out_u, out_d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                        qp_info, nullptr, nullptr, (hipStream_t)stream));
+                        qp_info, nullptr, nullptr, (hipStream_t)stream, nullptr, nullptr));
   return NPA_OK;
 }
 
@@ -570,7 +670,7 @@ extern "C" int npa_forward_begin(npa_handle* h, int batch, int n_stride, const f
   const int T = P.T;
   const bool helper = (qp_on_helper_stream & NPA_FWD_HELPER) != 0;
   const bool reset_state = (qp_on_helper_stream & NPA_FWD_RESET_STATE) != 0;
-  const ScratchLayout L = npa_scratch_layout(batch, T, mdim(P), P.E, P.key_stride);
+  const ScratchLayout L = npa_scratch_layout(batch, T, mdim(P), P.E, kstride(h));
   float* ws = (float*)workspace;
   pc->batch = batch; pc->n_stride = n_stride; pc->ref_s = ref_s; pc->ref_us = ref_us; pc->points = points;
   pc->velocities = velocities; pc->n_points = n_points; pc->out_s = out_s; pc->out_u = out_u; pc->out_d = out_d;
@@ -580,7 +680,8 @@ extern "C" int npa_forward_begin(npa_handle* h, int batch, int n_stride, const f
   if (pc->dune) key_policy(h, batch, n_stride);
   // sub-batches [lo_i, hi_i): DUNE(i,k) on `stream` in (k, i) order, QP(i,k) on aux[i]
   // (when the caller interleaves several batches the batches themselves are the pipeline stages)
-  pc->nsub = (h->n_sub > 1 && pc->dune && batch >= 16 * h->n_sub && !helper) ? h->n_sub : 1;
+  const bool geo = h->key_terms == 4;
+  pc->nsub = (h->n_sub > 1 && pc->dune && batch >= 16 * h->n_sub && !helper && !geo) ? h->n_sub : 1;
   pc->qp_aux = pc->dune && (pc->nsub > 1 || (helper && h->aux[0]));
   const size_t need_ev = (size_t)2 * pc->nsub * P.K + 2;
   while (h->sync_ev.size() < need_ev) {
@@ -627,7 +728,8 @@ extern "C" int npa_forward_iter(npa_handle* h, int k) {
   const DevParams& P = h->P;
   if (k < 0 || k >= P.K) return fail(NPA_E_ARG, "npa_forward_iter: iteration index out of range");
   const int T = P.T, batch = pc->batch, nsub = pc->nsub;
-  const ScratchLayout L = npa_scratch_layout(batch, T, mdim(P), P.E, P.key_stride);
+  const bool geo = h->key_terms == 4;
+  const ScratchLayout L = npa_scratch_layout(batch, T, mdim(P), P.E, kstride(h));
   float* ws = pc->ws;
   float *cur_s = ws + L.cur_s, *cur_u = ws + L.cur_u, *cur_d = ws + L.cur_d;
   float *mu = ws + L.mu, *lam = ws + L.lam, *pts = ws + L.pts, *dist = ws + L.dist;
@@ -644,30 +746,33 @@ extern "C" int npa_forward_iter(npa_handle* h, int k) {
     const int s0 = lo(i), nb = lo(i + 1) - lo(i);
     hipStream_t qs = pc->qp_aux ? h->aux[i] : stream;
     if (pc->dune) {
-      if (pc->qp_aux && k > 0) HIP_TRY(hipStreamWaitEvent(stream, ev_q(i, k - 1), 0));
-      if (pc->staged_on_aux && k == 0) HIP_TRY(hipStreamWaitEvent(stream, h->sync_ev[0], 0));
-      EventPair* ev = next_event(h, h->ev_dune, h->n_dune);
       const int t0 = k == 0 ? 0 : 1;
-      // the events ride on the dispatch (no marker packets between back-to-back encode launches): the
-      // completion event is the profiling stop event when profiling, else the hand-over event
-      hipEvent_t done = ev ? ev->b : (pc->qp_aux ? ev_d(i, k) : nullptr);
-      HIP_TRY(npa_launch_encode(P, h->wpack, nb, s0, t0, pc->n_stride, cur_s, pc->points, pc->velocities,
-                                pc->n_points, flags, gkeys, ws + L.trig, h->n_cu, h->enc_blocks, h->key_terms, stream,
-                                ev ? ev->a : nullptr, done));
-      if (pc->qp_aux) HIP_TRY(hipStreamWaitEvent(qs, done, 0));
-      // selection + QP follow the encode on the helper stream (when there is one): the next
-      // encode launch on `stream` -- another sub-batch or another batch in flight -- overlaps them
+      if (!geo) {
+        if (pc->qp_aux && k > 0) HIP_TRY(hipStreamWaitEvent(stream, ev_q(i, k - 1), 0));
+        if (pc->staged_on_aux && k == 0) HIP_TRY(hipStreamWaitEvent(stream, h->sync_ev[0], 0));
+        EventPair* ev = next_event(h, h->ev_dune, h->n_dune);
+        // the events ride on the dispatch (no marker packets between back-to-back encode launches): the
+        // completion event is the profiling stop event when profiling, else the hand-over event
+        hipEvent_t done = ev ? ev->b : (pc->qp_aux ? ev_d(i, k) : nullptr);
+        HIP_TRY(npa_launch_encode(P, h->wpack, nb, s0, t0, pc->n_stride, cur_s, pc->points, pc->velocities,
+                                  pc->n_points, flags, gkeys, ws + L.trig, h->n_cu, h->enc_blocks, h->key_terms, stream,
+                                  ev ? ev->a : nullptr, done));
+        if (pc->qp_aux) HIP_TRY(hipStreamWaitEvent(qs, done, 0));
+      }
+      // selection + QP follow on `qs`.  Network keys: behind the encode launch, on the helper stream when there is
+      // one (the next encode launch on `stream` -- another sub-batch or another batch in flight -- overlaps them).
+      // Geometric keys: select_kernel computes its keys itself, the whole chain of this forward call lives on `qs`.
+      EventPair* evs = next_event(h, h->ev_sel, h->n_sel);
       HIP_TRY(npa_launch_select(P, h->wpack, nb, s0, t0, pc->n_stride, cur_s, pc->points, pc->velocities,
                                 pc->n_points, flags, gkeys, ws + L.trig, mu, lam, pts, dist, count, h->key_terms, h->key_e0,
-                                h->sel_stats_dev, qs));
+                                h->sel_stats_dev, h->sel_debug, qs, evs ? evs->a : nullptr, evs ? evs->b : nullptr));
     }
     EventPair* ev = next_event(h, h->ev_qp, h->n_qp);
-    if (ev) HIP_TRY(hipEventRecord(ev->a, qs));
     HIP_TRY(npa_launch_qp(P, nb, s0, cur_s, cur_u, pc->ref_s, pc->ref_us, mu, lam, pts, dist, count, cur_s, cur_u,
                           cur_d, pc->out_s, pc->out_u, pc->out_d, pc->out_md, pc->out_iters, pc->out_np, flags,
-                          pc->state, qp_info, h->warm_start ? warm : nullptr, pc->dune ? ws + L.trig : nullptr, qs));
-    if (ev) HIP_TRY(hipEventRecord(ev->b, qs));
-    if (pc->qp_aux) HIP_TRY(hipEventRecord(ev_q(i, k), qs));
+                          pc->state, qp_info, h->warm_start ? warm : nullptr, pc->dune ? ws + L.trig : nullptr, qs,
+                          ev ? ev->a : nullptr, ev ? ev->b : nullptr));
+    if (pc->qp_aux && (!geo || k == P.K - 1)) HIP_TRY(hipEventRecord(ev_q(i, k), qs));
     if (h->key_auto && pc->dune && k == P.K - 1 && i == nsub - 1)      // behind the hand-over event: nobody waits for it
       HIP_TRY(hipMemcpyAsync(h->sel_stats_host, h->sel_stats_dev, sizeof(unsigned), hipMemcpyDeviceToHost, qs));
   }

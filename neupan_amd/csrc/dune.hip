@@ -477,6 +477,7 @@ void dune_kernel(
       const int bl = (int)((unsigned)sl / (unsigned)nsl), b = bl + scene0;
       t = sl - bl * nsl + t0;
       n_raw = n_points ? n_points[b] : n_stride;
+      n_raw = n_raw < 0 ? 0 : (n_raw > n_stride ? n_stride : n_raw);      // the documented contract, enforced
       n_use = n_raw < P.dune_max_num ? n_raw : P.dune_max_num;
       skip = (flags && flags[b * 4 + 0]) || n_use <= 0;     // converged scene (pan.py:144-145) / no points
       if (!skip) {
@@ -498,10 +499,33 @@ void dune_kernel(
   }
 }
 
-// ---- launch 2: the M nearest of a slice, one wave per slice -----------------------------------------
-// LDS per slice stays < 9 KB at 1000 points so that all (T+1) slices of a CU's scenes are resident.
+// ---- geometric distance of a robot-frame point to the robot polygon (0 inside) ---------------------------
+// min over the edges of the point-segment distance: ~12 VALU instructions per edge.  Only ever used as a KEY.
 template <int E>
-__global__ __launch_bounds__(64, 4) void select_kernel(
+__device__ __forceinline__ float geo_dist(const DevParams& P, float x, float y) {
+  float best = 3.0e38f;
+  bool inside = true;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const float rx = x - P.pvx[e], ry = y - P.pvy[e];
+    inside = inside && (fmaf(P.pdy[e], rx, -(P.pdx[e] * ry)) <= 0.f);     // G_e . p - h_e with G_e = (dy, -dx)
+    float t = fmaf(rx, P.pdx[e], ry * P.pdy[e]) * P.pil[e];
+    t = fminf(fmaxf(t, 0.f), 1.f);
+    const float qx = fmaf(-t, P.pdx[e], rx), qy = fmaf(-t, P.pdy[e], ry);
+    best = fminf(best, fmaf(qx, qx, qy * qy));
+  }
+  return inside ? 0.f : __builtin_sqrtf(best);
+}
+
+// ---- launch 2: the M nearest of a slice, one wave per slice -----------------------------------------
+// GEO = true: the slice's distance keys are computed HERE from the robot polygon (no dune_kernel launch, no key
+// buffer): key = closed-form distance g of the point, candidates = every point that the measured bound
+// |network distance - g| <= margin[band(g)] cannot exclude from the M nearest (below).  GEO = false: keys read from
+// gkeys (dune_kernel: reduced-precision or exact network distances).
+// LDS per slice stays < 9 KB at 1000 points so that all (T+1) slices of a CU's scenes are resident.
+#define SEL_CAP 64                               // candidates the final exact ranking holds (two 32-point tiles)
+template <int E, bool GEO>
+__global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(3, 3))) void select_kernel(
     DevParams P, const float* __restrict__ wpack, int n_stride, const float* __restrict__ cur_s,
     const float* __restrict__ points, const float* __restrict__ vel, const int* __restrict__ n_points,
     const int* __restrict__ flags, const unsigned* __restrict__ gkeys, int key_stride,
@@ -512,14 +536,20 @@ __global__ __launch_bounds__(64, 4) void select_kernel(
   float* vec = smem;                       // [11][32]
   float* w6 = vec + 11 * 32;               // [8][32]
   float* b6 = w6 + 8 * 32;                 // [8]
-  int* sel = reinterpret_cast<int*>(b6 + 8);            // [NPA_MAX_M = 32]: the candidates of this slice
-  int* lst = sel + NPA_MAX_M;                           // [64]: short list of the first extraction
-  unsigned* dkey = reinterpret_cast<unsigned*>(lst + 64);          // [n_use] keys; later the candidate list + their exact keys
+  float* etab = b6 + 8;                    // [NPA_GEO_BANDS] margin per distance band (GEO)
+  int* sel = reinterpret_cast<int*>(etab + NPA_GEO_BANDS);   // [SEL_CAP]: the candidates of this slice
+  unsigned* skey = reinterpret_cast<unsigned*>(sel + SEL_CAP);   // [NPA_MAX_M] keys of the msel extracted entries
+  int* lst = reinterpret_cast<int*>(skey + NPA_MAX_M);        // [64]: short list of the first extraction
+  constexpr int ROW_W = E + 5;                                // mu[E], lam[2], point[2], distance
+  float* rows = reinterpret_cast<float*>(lst + 64);           // [SEL_CAP][ROW_W]: exact rows of the final candidates
+  unsigned* rkey = reinterpret_cast<unsigned*>(rows + SEL_CAP * (NPA_MAX_E + 5));   // [SEL_CAP][2]: (index, exact key)
+  unsigned* dkey = rkey + 2 * SEL_CAP;                        // [n_use] keys; later the candidate list + their exact keys
   const int t = blockIdx.x + t0, b = blockIdx.y + scene0, lane = threadIdx.x;
   const int j = lane & 31, hf = lane >> 5;
   const int T = P.T, M = P.M;
   if (flags && flags[b * 4 + 0]) return;
-  const int n_raw = n_points ? n_points[b] : n_stride;
+  int n_raw = n_points ? n_points[b] : n_stride;
+  n_raw = n_raw < 0 ? 0 : (n_raw > n_stride ? n_stride : n_raw);      // the documented contract, enforced
   const int n_use = n_raw < P.dune_max_num ? n_raw : P.dune_max_num;
   const size_t orow = (size_t)b * (T + 1) + t;
   if (n_use <= 0) {
@@ -527,28 +557,45 @@ __global__ __launch_bounds__(64, 4) void select_kernel(
     return;
   }
   for (int i = lane; i < 11 * 32 + 8 * 32 + 8; i += 64) smem[i] = wpack[WP_VEC + i];
-  const unsigned* gk = gkeys + orow * key_stride;
-  for (int n = lane; n < n_use; n += 64) dkey[n] = gk[n];
-  WaveWeights W;
-  load_weights(wpack, lane, W);
+  if constexpr (GEO)
+    for (int i = lane; i < NPA_GEO_BANDS; i += 64) etab[i] = wpack[WP_GEO + i];
   SliceFrame F;
   load_frame<E>(P, cur_s, trig, b, t, F);
   const float* px_row = points + (size_t)b * 2 * n_stride;
   const float* py_row = px_row + n_stride;
   const float* vx_row = vel ? vel + (size_t)b * 2 * n_stride : nullptr;
   const float* vy_row = vel ? vx_row + n_stride : nullptr;
+  if constexpr (GEO) {
+    for (int n = lane; n < n_use; n += 64) {
+      const int src = src_index(n, n_raw, n_use);
+      float gx = px_row[src], gy = py_row[src];                 // the point flow of point_features
+      if (vx_row) {
+        gx = __fadd_rn(gx, __fmul_rn(F.tstep, __fmul_rn(vx_row[src], P.dt32)));
+        gy = __fadd_rn(gy, __fmul_rn(F.tstep, __fmul_rn(vy_row[src], P.dt32)));
+      }
+      const float dx = __fsub_rn(gx, F.tx), dy = __fsub_rn(gy, F.ty);
+      const float p0x = fmaf(F.c, dx, __fmul_rn(F.s, dy)), p0y = fmaf(F.c, dy, -__fmul_rn(F.s, dx));
+      const bool calibrated = fmaxf(fabsf(p0x), fabsf(p0y)) <= P.geo_rcal;     // false for NaN / inf too
+      dkey[n] = calibrated ? __float_as_uint(geo_dist<E>(P, p0x, p0y)) : NPA_GEO_KEY_FAR;
+    }
+  } else {
+    const unsigned* gk = gkeys + orow * key_stride;
+    for (int n = lane; n < n_use; n += 64) dkey[n] = gk[n];
+  }
+  WaveWeights W;
+  load_weights(wpack, lane, W);
   WSYNC();
 
   const int msel = n_use < M ? n_use : M;
   unsigned last_key = 0;
-  auto extract = [&]() {                      // the msel smallest (key, index) pairs -> sel[0..msel)
+  auto extract = [&]() {                      // the msel smallest (key, index) pairs -> sel[0..msel), skey[0..msel)
     for (int m = 0; m < msel; ++m) {
       unsigned long long best = ~0ull;
       for (int n = lane; n < n_use; n += 64) best = umin64(best, ((unsigned long long)dkey[n] << 32) | (unsigned)n);
       best = wave_min_u64(best);
       const int idx = (int)(best & 0xFFFFFFFFu);
       last_key = (unsigned)(best >> 32);
-      if (lane == 0) { sel[m] = idx; dkey[idx] = 0xFFFFFFFFu; }
+      if (lane == 0) { sel[m] = idx; skey[m] = last_key; dkey[idx] = 0xFFFFFFFFu; }
       WSYNC();
     }
   };
@@ -579,108 +626,152 @@ __global__ __launch_bounds__(64, 4) void select_kernel(
     const unsigned long long v = lane < L ? (((unsigned long long)dkey[idx] << 32) | (unsigned)idx) : ~0ull;
     int rk = 0;
     for (int i = 0; i < L; ++i) rk += readlane_u64(v, i) < v ? 1 : 0;
-    if (lane < L && rk < msel) { sel[rk] = idx; dkey[idx] = 0xFFFFFFFFu; }
+    if (lane < L && rk < msel) { sel[rk] = idx; skey[rk] = (unsigned)(v >> 32); dkey[idx] = 0xFFFFFFFFu; }
     const unsigned long long lastb = __ballot(lane < L && rk == msel - 1);
     last_key = (unsigned)(readlane_u64(v, (int)__builtin_ctzll(lastb)) >> 32);
     WSYNC();
     return true;
   };
   if (!extract_short()) extract();
-  // Reduced-precision keys decide only WHO is a candidate: besides the msel smallest, every point whose key lies
-  // within 2e of the msel-th, e = e0 (1 + |d|) with e0 = a multiple of the key error MEASURED for this checkpoint
-  // when the handle was created (key_calib_kernel).  If |key - exact| <= e then the exact msel nearest are among
-  // the candidates; they are re-encoded exactly below and ranked on the exact (distance, index) key.
+  // The keys decide only WHO is a candidate; the candidates are re-encoded exactly below and ranked on the exact
+  // (distance, index) key, so the emitted rows are those of an exact-key selection PROVIDED no true member of the
+  // msel nearest is left out:
+  //  * network keys (GEO = false, approx_keys): |key - exact| <= e = e0 (1 + |d|), e0 a multiple of the key error
+  //    measured for this checkpoint (key_calib_kernel): every point with key <= key_M + 2e is a candidate;
+  //  * geometric keys: exact in [g - m(g), g + m(g)], m = margin[band(g)] measured for this checkpoint
+  //    (geo_calib_kernel).  U = max over the msel smallest-g points of g + m(g) bounds the msel-th smallest EXACT
+  //    distance from above (those msel points all lie below it), so a point with g - m(g) > U cannot be among the
+  //    msel nearest.  Points outside the calibrated square (key FAR) are always candidates.
   int ncand = msel, fellback = 0;
-  if (approx_keys && msel == M && n_use > M && last_key < 0xFFFFFFFEu) {
-    const float dM = __uint_as_float((last_key & 0x80000000u) ? (last_key & 0x7FFFFFFFu) : ~last_key);
-    const unsigned thr = ordered_key(dM + 2.0f * e0 * (1.0f + fabsf(dM)));
+  bool widen = false;
+  unsigned thr = 0;
+  float U = 0.f;
+  if constexpr (GEO) {
+    widen = n_use > msel;
+    float hi = -1.f;
+    if (lane < msel) {
+      const unsigned k = skey[lane];
+      const float g = __uint_as_float(k);
+      hi = (k == NPA_GEO_KEY_FAR) ? __builtin_inff() : g + etab[npa_geo_band(g)];
+    }
+    for (int i = 0; i < msel; ++i) U = fmaxf(U, __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hi), i)));
+  } else {
+    widen = approx_keys && msel == M && n_use > M && last_key < 0xFFFFFFFEu;
+    if (widen) {
+      const float dM = __uint_as_float((last_key & 0x80000000u) ? (last_key & 0x7FFFFFFFu) : ~last_key);
+      thr = ordered_key(dM + 2.0f * e0 * (1.0f + fabsf(dM)));
+    }
+  }
+  bool overflow = false, all = false;
+  int total = 0, extra = 0;
+  if (widen) {
     // compact the indices of the points inside the window IN PLACE over the keys already scanned (slot <= index)
-    int extra = 0;                                              // points besides the msel extracted ones
     for (int n0 = 0; n0 < n_use; n0 += 64) {
       const int n = n0 + lane;
-      const bool hit = n < n_use && dkey[n] <= thr;            // extracted entries are 0xFFFFFFFF
+      bool hit = false;
+      if (n < n_use) {
+        const unsigned k = dkey[n];                             // extracted entries are 0xFFFFFFFF
+        if constexpr (GEO) {
+          const float g = __uint_as_float(k);
+          hit = k != 0xFFFFFFFFu && (k == NPA_GEO_KEY_FAR || g - etab[npa_geo_band(g)] <= U);
+        } else {
+          hit = k <= thr;
+        }
+      }
       const unsigned long long bal = __ballot(hit);
       const int pos = extra + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
-      if (hit) dkey[pos] = (unsigned)n;
+      if (hit) dkey[pos] = (unsigned)n;                         // points besides the msel extracted ones
       extra += __popcll(bal);
     }
     WSYNC();
-    if (msel + extra <= NPA_MAX_M) {                            // the usual case: everything fits one tile
+    if (msel + extra <= SEL_CAP) {                              // the usual case: everything fits the final ranking
       if (lane < extra) sel[msel + lane] = (int)dkey[lane];
       ncand = msel + extra;
       WSYNC();
     } else {
-      // more candidates than one tile (many points within 2e of the M-th nearest: a wall at constant distance,
-      // a cluster of exact zeros inside the robot): exact keys for the candidates -- stored behind the list -- or,
-      // when the list takes more than half the slice, for the whole slice; then the msel smallest again
+      // more candidates than the final ranking holds (many points within the margin of the M-th nearest: a wall at
+      // constant distance, a cluster of exact zeros inside the robot): exact keys for the candidates -- stored behind
+      // the list -- or, when the list takes more than half the slice, for the whole slice; then the msel smallest again
+      overflow = true;
       fellback = 1;
-      const bool all = 2 * extra + msel > n_use;
-      const int total = all ? n_use : msel + extra;
-      unsigned* ckey = dkey + extra;                            // [total] exact keys of the candidates (compact form)
-      auto cand_index = [&](int q) { return all ? q : (q < msel ? sel[q] : (int)dkey[q - msel]); };
-      for (int q0 = 0; q0 < total; q0 += 32) {
-        const int q = q0 + j, qc = q < total ? q : total - 1;
-        const int idx = cand_index(qc);
-        float mu_[E], gx_, gy_, lx_, ly_, d_;
-        point_features<E, 0>(P, F, W, nullptr, vec, w6, b6, px_row, py_row, vx_row, vy_row,
-                             src_index(idx, n_raw, n_use), lane, mu_, gx_, gy_, lx_, ly_, d_);
-        if (hf == 0 && q < total) {
-          if (all) dkey[idx] = ordered_key(d_);
-          else ckey[q] = ordered_key(d_);
+      all = 2 * extra + msel > n_use;
+      total = all ? n_use : msel + extra;
+    }
+  }
+  unsigned* ckey = dkey + extra;                                // [total] exact keys of the candidates (compact form)
+  auto cand_index = [&](int q) { return all ? q : (q < msel ? sel[q] : (int)dkey[q - msel]); };
+  // Exact re-encoding.  Phase 0 (overflow only): exact KEYS of the long candidate list, then the msel smallest of
+  // them become the candidates.  Phase 1: the final candidates (<= SEL_CAP, two tiles at most) with their ROWS
+  // parked in LDS; they are ranked on the exact (distance, index) key and the msel nearest are emitted as sorted
+  // rows.  ONE call site of the encoder for both (its 65 weight registers + 16 accumulators leave no room for a
+  // second inlined copy inside 128 VGPRs).
+#pragma unroll 1
+  for (int phase = overflow ? 0 : 1;; phase = 1) {
+    const int cnt = phase == 0 ? total : ncand;
+#pragma unroll 1
+    for (int q0 = 0; q0 < cnt; q0 += 32) {
+      const int q = q0 + j, qc = q < cnt ? q : cnt - 1;
+      const int idx = phase == 0 ? cand_index(qc) : sel[qc];
+      float mu[E], gx, gy, lx, ly, dist;
+      point_features<E, 0>(P, F, W, nullptr, vec, w6, b6, px_row, py_row, vx_row, vy_row,
+                           src_index(idx, n_raw, n_use), lane, mu, gx, gy, lx, ly, dist);
+      if (hf == 0 && q < cnt) {
+        const unsigned k = ordered_key(dist);
+        if (phase == 0) {
+          if (all) dkey[idx] = k;
+          else ckey[q] = k;
+        } else {
+          float* r = rows + q * ROW_W;
+#pragma unroll
+          for (int e = 0; e < E; ++e) r[e] = mu[e];
+          r[E] = lx; r[E + 1] = ly; r[E + 2] = gx; r[E + 3] = gy; r[E + 4] = dist;
+          rkey[2 * q] = (unsigned)idx; rkey[2 * q + 1] = k;
         }
       }
-      WSYNC();
-      if (stats && lane == 0) atomicAdd(stats, (unsigned)((total + 31) / 32));
-      if (all) {
-        extract();
-      } else {
-        // the msel smallest exact (key, index) pairs among the candidates; lane m keeps the m-th winner
-        int mywin = 0;
-        for (int m2 = 0; m2 < msel; ++m2) {
-          unsigned long long best = ~0ull;
-          int bq = -1;
-          for (int q = lane; q < total; q += 64) {
-            const unsigned long long v = ((unsigned long long)ckey[q] << 32) | (unsigned)cand_index(q);
-            if (v < best) { best = v; bq = q; }
-          }
-          const unsigned long long win = wave_min_u64(best);
-          if (best == win && bq >= 0) ckey[bq] = 0xFFFFFFFFu;   // (key, index) pairs are distinct: one lane retires it
-          if (lane == m2) mywin = (int)(win & 0xFFFFFFFFu);
-          WSYNC();
+    }
+    WSYNC();
+    if (phase == 1) break;
+    if (stats && lane == 0) atomicAdd(stats, (unsigned)((total + 31) / 32));
+    if (all) {
+      extract();
+    } else {
+      // the msel smallest exact (key, index) pairs among the candidates; lane m keeps the m-th winner
+      int mywin = 0;
+      for (int m2 = 0; m2 < msel; ++m2) {
+        unsigned long long best = ~0ull;
+        int bq = -1;
+        for (int q = lane; q < total; q += 64) {
+          const unsigned long long v = ((unsigned long long)ckey[q] << 32) | (unsigned)cand_index(q);
+          if (v < best) { best = v; bq = q; }
         }
-        if (lane < msel) sel[lane] = mywin;                     // sel[] was read through cand_index until here
+        const unsigned long long win = wave_min_u64(best);
+        if (best == win && bq >= 0) ckey[bq] = 0xFFFFFFFFu;     // (key, index) pairs are distinct: one lane retires it
+        if (lane == m2) mywin = (int)(win & 0xFFFFFFFFu);
         WSYNC();
       }
-      ncand = msel;
+      if (lane < msel) sel[lane] = mywin;                       // sel[] was read through cand_index until here
+      WSYNC();
     }
+    ncand = msel;
   }
-  // re-encode the candidates exactly and emit the msel nearest as sorted rows; rows >= msel replicate row 0
-  const int cj = j < ncand ? j : 0;
-  float mu[E], gx, gy, lx, ly, dist;
-  point_features<E, 0>(P, F, W, nullptr, vec, w6, b6, px_row, py_row, vx_row, vy_row,
-                           src_index(sel[cj], n_raw, n_use), lane, mu, gx, gy, lx, ly, dist);
-  const unsigned long long kx = (j < ncand) ? (((unsigned long long)ordered_key(dist) << 32) | (unsigned)sel[cj]) : ~0ull;
+  // lane q speaks for candidate q: rank on the exact (distance, index) key, emit; rows >= msel replicate row 0
+  const bool mine = lane < ncand;
+  const unsigned long long kx = mine ? (((unsigned long long)rkey[2 * lane + 1] << 32) | rkey[2 * lane]) : ~0ull;
   int rank = 0;
   for (int i = 0; i < ncand; ++i) rank += readlane_u64(kx, i) < kx ? 1 : 0;
-  if (hf == 0 && j < ncand && rank < msel) {
-    size_t o = orow * M + rank;
+  if (mine && rank < msel) {
+    const float* r = rows + lane * ROW_W;
+    auto put = [&](int q) {
+      const size_t o = orow * M + q;
 #pragma unroll
-    for (int e = 0; e < E; ++e) mu_sorted[o * E + e] = mu[e];
-    lam_sorted[o * 2 + 0] = lx; lam_sorted[o * 2 + 1] = ly;
-    pts_sorted[o * 2 + 0] = gx; pts_sorted[o * 2 + 1] = gy;
-    dist_sorted[o] = dist;
-  }
-  // rows >= msel replicate the nearest row (padding rule of nrmp.py:258-259): the lane holding it
-  // (rank 0) writes the copies
-  if (hf == 0 && j < ncand && rank == 0) {
-    for (int q = msel; q < M; ++q) {
-      size_t o = orow * M + q;
-#pragma unroll
-      for (int e = 0; e < E; ++e) mu_sorted[o * E + e] = mu[e];
-      lam_sorted[o * 2 + 0] = lx; lam_sorted[o * 2 + 1] = ly;
-      pts_sorted[o * 2 + 0] = gx; pts_sorted[o * 2 + 1] = gy;
-      dist_sorted[o] = dist;
-    }
+      for (int e = 0; e < E; ++e) mu_sorted[o * E + e] = r[e];
+      lam_sorted[o * 2 + 0] = r[E]; lam_sorted[o * 2 + 1] = r[E + 1];
+      pts_sorted[o * 2 + 0] = r[E + 2]; pts_sorted[o * 2 + 1] = r[E + 3];
+      dist_sorted[o] = r[E + 4];
+    };
+    put(rank);
+    if (rank == 0)                          // the nearest row also fills rows >= msel: the padding rule of nrmp.py:258-259
+      for (int q = msel; q < M; ++q) put(q);
   }
   if (lane == 0) count[orow] = approx_keys == 2 ? (msel | (ncand << 8) | (fellback << 16)) : msel;
 }
@@ -753,28 +844,108 @@ extern "C" hipError_t npa_launch_select(const DevParams& P, const float* wpack, 
                                         const int* n_points, const int* flags, const unsigned* gkeys,
                                         const float* trig, float* mu_sorted, float* lam_sorted, float* pts_sorted,
                                         float* dist_sorted, int* count, int key_terms, float e0, unsigned* stats,
-                                        hipStream_t stream) {
-  // key_terms != 0: the keys are reduced-precision ones, candidates within the margin e0 (1 + |d|) are re-ranked
+                                        int debug, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  // ev_start / ev_stop (may be null) ride on the dispatch (hipExtLaunchKernelGGL): no marker packets on the stream
+  // debug != 0: count[] also carries the number of candidates and the overflow flag (tests/tools/geo_check.py)
+  // key_terms: 0 = exact network keys in gkeys, 1 / 3 = reduced-precision network keys in gkeys (candidates within
+  // the margin e0 (1 + |d|) are re-ranked), 4 = geometric keys computed by select_kernel itself (gkeys unused)
   const int nsl = P.T + 1 - t0;
   const int tps = tiles_per_slice(P, n_stride);
-  static const int dbg = getenv("NPA_SEL_DEBUG") ? 2 : (getenv("NPA_SEL_NOMARGIN") ? 0 : 1);
+  const int dbg = debug ? 2 : 1;
+  const bool geo = key_terms == 4;
   const int approx = key_terms == 0 ? 0 : dbg;
-  const size_t shmem = (11 * 32 + 8 * 32 + 8) * sizeof(float) + (NPA_MAX_M + 64) * sizeof(int) +
-                       ((size_t)tps * 32 * sizeof(unsigned) + 15) / 16 * 16;
+  const size_t shmem = (11 * 32 + 8 * 32 + 8 + NPA_GEO_BANDS) * sizeof(float) + (SEL_CAP + NPA_MAX_M + 64) * sizeof(int) +
+                       SEL_CAP * (NPA_MAX_E + 5 + 2) * sizeof(float) + ((size_t)tps * 32 * sizeof(unsigned) + 15) / 16 * 16;
   // slices of more than ~15 000 points keep more than the default 64 KB of dynamic LDS (4 B per key)
-#define LAUNCH(EE)                                                                                                  \
+#define LAUNCH1(EE, GG)                                                                                             \
   do {                                                                                                              \
     static bool big_lds = false;                                                                                    \
     if (shmem > 60 * 1024 && !big_lds) {                                                                            \
-      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel<EE>),                         \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel<EE, GG>),                     \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
       if (e_ != hipSuccess) return e_;                                                                              \
       big_lds = true;                                                                                               \
     }                                                                                                               \
-    hipLaunchKernelGGL(select_kernel<EE>, dim3(nsl, batch), dim3(64), shmem, stream, P, wpack, n_stride, cur_s,     \
-                       points, vel, n_points, flags, gkeys, tps * 32, mu_sorted, lam_sorted, pts_sorted, dist_sorted, \
-                       count, scene0, t0, approx, e0, stats, trig);                                                 \
+    hipExtLaunchKernelGGL((select_kernel<EE, GG>), dim3(nsl, batch), dim3(64), shmem, stream, ev_start, ev_stop, 0, P,    \
+                          wpack, n_stride, cur_s, points, vel, n_points, flags, gkeys, tps * 32, mu_sorted, lam_sorted, \
+                          pts_sorted, dist_sorted, count, scene0, t0, approx, e0, stats, trig);                      \
   } while (0)
+#define LAUNCH(EE)                                                                                                  \
+  do {                                                                                                              \
+    if (geo) LAUNCH1(EE, true);                                                                                     \
+    else LAUNCH1(EE, false);                                                                                        \
+  } while (0)
+  switch (P.E) {
+    case 3: LAUNCH(3); break;
+    case 4: LAUNCH(4); break;
+    case 5: LAUNCH(5); break;
+    case 6: LAUNCH(6); break;
+    case 7: LAUNCH(7); break;
+    case 8: LAUNCH(8); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef LAUNCH
+#undef LAUNCH1
+  return hipGetLastError();
+}
+
+// ---- geometric-key calibration (npa_create) ----------------------------------------------------------
+// f(p) = network distance - geometric distance is a smooth function of the robot-frame position and a property of
+// the checkpoint.  Per distance band (npa_geo_band) this records, over a square grid of spacing d, max |f| and the
+// largest difference of f between grid neighbours in x and y (how much f can exceed its grid maximum between grid
+// points).  The
+// host runs it on nested grids (fine next to the robot, coarser outwards; a grid skips the inner square a finer one
+// covers) and builds margin[band] = safety x (max |f| + max |delta f|), taken over the band and its two neighbours.
+template <int E>
+__global__ __launch_bounds__(256) void geo_calib_kernel(DevParams P, const float* __restrict__ wpack, float half, int nside,
+                                                        float inner, unsigned* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* vec = smem;
+  float* w6 = vec + 11 * 32;
+  float* b6 = w6 + 8 * 32;
+  unsigned* tab = reinterpret_cast<unsigned*>(b6 + 8);          // [2][NPA_GEO_BANDS]
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hf = lane >> 5;
+  for (int i = tid; i < 11 * 32 + 8 * 32 + 8; i += blockDim.x) smem[i] = wpack[WP_VEC + i];
+  for (int i = tid; i < 2 * NPA_GEO_BANDS; i += blockDim.x) tab[i] = 0u;
+  __syncthreads();
+  WaveWeights W;
+  load_weights(wpack, lane, W);
+  // 8 x 4 points per tile so that a lane's x- and y-neighbours (lanes j + 1, j + 8) sit in the same tile; nside % 8 == 0
+  const float step = 2.0f * half / (float)(nside - 1);
+  const int tiles_x = nside >> 3, tiles_y = nside >> 2;
+  const long long tiles = (long long)tiles_x * tiles_y;
+  const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (tid >> 6), nwave = (long long)gridDim.x * (blockDim.x >> 6);
+  for (long long tile = wave; tile < tiles; tile += nwave) {
+    const int ix = (int)(tile % tiles_x) * 8 + (j & 7), iy = (int)(tile / tiles_x) * 4 + (j >> 3);
+    const float p0x = -half + step * (float)ix, p0y = -half + step * (float)iy;
+    float me[E];
+    encode_tile<E>(W, vec, w6, b6, p0x, p0y, lane, me);
+    float de = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) de = fmaf(me[e], __fsub_rn(fmaf(P.G[e][0], p0x, __fmul_rn(P.G[e][1], p0y)), P.h[e]), de);
+    const float g = geo_dist<E>(P, p0x, p0y);
+    float f = de - g;
+    if (!(f == f)) f = 3.0e38f;                                 // NaN anywhere disqualifies the band
+    const float fx = __shfl_down(f, 1, 64), fy = __shfl_down(f, 8, 64);
+    if (hf == 0 && fmaxf(fabsf(p0x), fabsf(p0y)) >= inner) {
+      const int band = npa_geo_band(g);
+      atomicMax(&tab[band], __float_as_uint(fabsf(f)));
+      float df = 0.f;
+      if ((j & 7) < 7) df = fabsf(fx - f);
+      if (j < 24) df = fmaxf(df, fabsf(fy - f));
+      atomicMax(&tab[NPA_GEO_BANDS + band], __float_as_uint(df));
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * NPA_GEO_BANDS; i += blockDim.x)
+    if (tab[i]) atomicMax(&out[i], tab[i]);
+}
+
+extern "C" hipError_t npa_launch_geo_calib(const DevParams& P, const float* wpack, int nside, float half, float inner,
+                                           unsigned* out, int n_cu, hipStream_t stream) {
+  const size_t shmem = (11 * 32 + 8 * 32 + 8 + 2 * NPA_GEO_BANDS) * sizeof(float);
+  const int blocks = n_cu * 4;
+#define LAUNCH(EE) hipLaunchKernelGGL((geo_calib_kernel<EE>), dim3(blocks), dim3(256), shmem, stream, P, wpack, half, nside, inner, out)
   switch (P.E) {
     case 3: LAUNCH(3); break;
     case 4: LAUNCH(4); break;

@@ -29,6 +29,7 @@
 // wave reductions are DPP (quad_perm / row_mirror) + 4 readlanes, and every division in a
 // serial loop is replaced by a reciprocal computed once per iteration.
 #include "pan_common.h"
+#include <hip/hip_ext.h>
 #include <cstdlib>
 
 #define QP_THREADS 64          // lanes cooperating on one scene (one wavefront)
@@ -1013,7 +1014,7 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
                                     float* cur_d_out, float* out_s, float* out_u, float* out_d,
                                     float* out_min_distance, int* out_iters, float* out_nrmp_points, int* flags,
                                     float* state, double* qp_info, double* warm, float* trig_out,
-                                    hipStream_t stream) {
+                                    hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
   static const bool force_generic = getenv("NPA_QP_GENERIC") != nullptr;
   static const bool low_prio = getenv("NPA_QP_LOWPRIO") != nullptr;
   const bool fast = qp_fast_path(P.T, P.M) && !force_generic;
@@ -1037,11 +1038,11 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
     attr_set = true;
   }
 #define QP_LAUNCH(TTV, MMV)                                                                                      \
-  hipLaunchKernelGGL((nrmp_qp_kernel<TTV, MMV>), dim3(nblocks), dim3(QP_THREADS * wpg), shmem, stream, P, cur_s_in, cur_u_in, \
-                     ref_s, ref_us, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count, cur_s_out, cur_u_out, \
-                     cur_d_out, out_s, out_u, out_d, out_min_distance, out_iters, out_nrmp_points, flags, state, \
-                     qp_info, warm, scene0, batch, wave_doubles, low_prio ? -wpg : wpg,                         \
-                     QpBackward{nullptr, nullptr, nullptr, nullptr, nullptr}, trig_out)
+  hipExtLaunchKernelGGL((nrmp_qp_kernel<TTV, MMV>), dim3(nblocks), dim3(QP_THREADS * wpg), shmem, stream, ev_start, ev_stop, 0, \
+                        P, cur_s_in, cur_u_in, ref_s, ref_us, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count,  \
+                        cur_s_out, cur_u_out, cur_d_out, out_s, out_u, out_d, out_min_distance, out_iters,            \
+                        out_nrmp_points, flags, state, qp_info, warm, scene0, batch, wave_doubles,                   \
+                        low_prio ? -wpg : wpg, QpBackward{nullptr, nullptr, nullptr, nullptr, nullptr}, trig_out)
   if (P.T == 10 && P.M == 10 && !force_generic) QP_LAUNCH(10, 10);
   else if (P.T == 20 && P.M == 10 && !force_generic) QP_LAUNCH(20, 10);
   else QP_LAUNCH(0, 0);

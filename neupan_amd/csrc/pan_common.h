@@ -20,7 +20,27 @@ struct DevParams {
   float q_s[3], p_u, eta, d_max, d_min;
   float G[NPA_MAX_E][2];
   float h[NPA_MAX_E];
+  // robot polygon as vertices (fp64 intersection of consecutive edges, rounded once): edge e runs V[e] -> V[e] + D[e];
+  // used by the GEOMETRIC distance keys (select_kernel<E, true>), never by the rows that are emitted
+  float pvx[NPA_MAX_E], pvy[NPA_MAX_E], pdx[NPA_MAX_E], pdy[NPA_MAX_E], pil[NPA_MAX_E];   // pil = 1 / |D|^2
+  float geo_rcal;             // half extent of the square (robot frame) over which the geometric key's error was measured
 };
+
+// ---- geometric distance keys ------------------------------------------------------------------------
+// The DUNE network approximates the distance from a point to the robot polygon; the closed-form distance is ~12
+// VALU instructions per edge, so select_kernel<E, true> uses IT to nominate the candidates (the kept rows are still
+// re-encoded with the exact network).  What the margin must cover is |network distance - geometric distance|, a
+// smooth function of the robot-frame position and a property of the checkpoint: npa_create measures its maximum
+// per DISTANCE BAND on nested grids (geo_calib_kernel) and stores margin[band] in the weight pack (WP_GEO).
+// band(g): 8 bands per octave of g + 0.25 m (32 mm wide next to the robot, ~12 % of g far away).
+#define NPA_GEO_BANDS 88                          // g + 0.25 in [2^-2, 2^9)
+#define NPA_GEO_KEY_FAR 0x7F800000u               // key of a point outside the calibrated square: always a candidate
+__host__ __device__ inline int npa_geo_band(float g) {
+  union { float f; unsigned u; } v;
+  v.f = g + 0.25f;
+  const int b = (int)(v.u >> 20) - (int)(0x3E800000u >> 20);
+  return b < 0 ? 0 : (b >= NPA_GEO_BANDS ? NPA_GEO_BANDS - 1 : b);
+}
 
 // ---- packed DUNE weights (device buffer, floats) -----------------------------------------
 // MFMA A-operand fragments of v_mfma_f32_32x32x2_f32: lane l holds A[i = l&31][k = l>>5].
@@ -50,7 +70,8 @@ struct DevParams {
 #define WP_KSC (WP_KVEC + 5 * 32)                 // [8]      LayerNorm eps x3 (scaled), tanh output scale x3
 #define WP_KW1 (WP_KSC + 8)                       // [64]     centred Linear(2,32) A-fragment (read per lane)
 #define WP_KEY_LDS_FLOATS (WP_BF_FLOATS + 5 * 32 + 8)
-#define WP_TOTAL (WP_KW1 + 64)
+#define WP_GEO (WP_KW1 + 64)                      // [NPA_GEO_BANDS] margin of the geometric key per distance band (+inf = uncalibrated)
+#define WP_TOTAL (WP_GEO + NPA_GEO_BANDS)
 // order of the per-feature vectors
 enum { V_B1 = 0, V_G1, V_BE1, V_B2, V_B3, V_G2, V_BE2, V_B4, V_B5, V_G3, V_BE3 };
 

@@ -26,8 +26,8 @@ def gather_controls(opt_u: torch.Tensor, dist=None, world: int = 1, equal_shards
     Equal shard sizes use one all_gather_into_tensor (pass equal_shards=True when the caller knows
     that every rank holds the same number of scenes: it saves the size exchange); ragged shards
     are padded to the largest shard and trimmed."""
-    if dist is None or world == 1:
-        return opt_u
+    if dist is None or not dist.is_initialized():
+        return opt_u                     # no process group: the single-process case (a group of ONE rank does gather)
     if equal_shards and dist.get_backend() != "gloo":
         send = opt_u.contiguous()
         out = torch.empty((world * send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)

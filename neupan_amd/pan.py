@@ -331,14 +331,30 @@ class PAN(torch.nn.Module):
         self.last_out = out
         return out
 
-    def forward_batch(self, nom_s, nom_u, ref_s, ref_us, points=None, velocities=None, n_points=None):
-        """Plan B independent scenes.  Shapes: nom_s (B,3,T+1) nom_u (B,2,T) ref_s (B,3,T+1)
+    def forward_batch(self, nom_s, nom_u, ref_s, ref_us, points=None, velocities=None, n_points=None, reset_state=False):
+        """Plan B independent scenes (reset_state: forget the stop criterion's previous iterate first, inside the staging launch).  Shapes: nom_s (B,3,T+1) nom_u (B,2,T) ref_s (B,3,T+1)
         ref_us (B,T) points (B,2,N)|None velocities (B,2,N)|None n_points (B,) int32|None.
         Returns dict(opt_s, opt_u, opt_d|None, min_distance (B,), iters (B,), nrmp_points (B,2,M)|None)."""
-        self.forward_begin(nom_s, nom_u, ref_s, ref_us, points, velocities, n_points)
+        self.forward_begin(nom_s, nom_u, ref_s, ref_us, points, velocities, n_points, reset_state=reset_state)
         for k in range(self.iter_num):
             self.forward_iter(k)
         return self.forward_end()
+
+    def forward_batch_trace(self, nom_s, nom_u, ref_s, ref_us, points=None, velocities=None, n_points=None):
+        """forward_batch that also returns the controls after every PAN iteration: out["trace_u"] (B, K, 2, T), the
+        working nominal copied out of the workspace behind each iteration's QP (parity tooling: how a deviation from
+        the oracle grows with the iteration count)."""
+        self.forward_begin(nom_s, nom_u, ref_s, ref_us, points, velocities, n_points)
+        B, T = self._B, self.T
+        wsf = self._ws.view(torch.float32)
+        off_u = (B * 3 * (T + 1) + 3) // 4 * 4                  # cur_u follows cur_s (pan_common.h: npa_scratch_layout)
+        us = []
+        for k in range(self.iter_num):
+            self.forward_iter(k)
+            us.append(wsf[off_u:off_u + B * 2 * T].clone().reshape(B, 2, T))
+        out = self.forward_end()
+        out["trace_u"] = torch.stack(us, dim=1)
+        return out
 
     # ------------------------------------------------------------------ reference signature
     def forward(self, nom_s, nom_u, ref_s, ref_us, obs_points=None, point_velocities=None):
@@ -483,9 +499,9 @@ class PAN(torch.nn.Module):
         check(self._lib.npa_profile_enable(self._h, 1 if enable else 0), "npa_profile_enable")
 
     def profile_read(self):
-        a, b, n = C.c_double(), C.c_double(), C.c_int64()
-        check(self._lib.npa_profile_read(self._h, C.byref(a), C.byref(b), C.byref(n)), "npa_profile_read")
-        return dict(dune_ms=a.value, nrmp_ms=b.value, launches=n.value)
+        a, s_, b, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+        check(self._lib.npa_profile_read(self._h, C.byref(a), C.byref(s_), C.byref(b), C.byref(n)), "npa_profile_read")
+        return dict(dune_ms=a.value, select_ms=s_.value, nrmp_ms=b.value, launches=n.value)
 
 
 class _PanGrad(torch.autograd.Function):

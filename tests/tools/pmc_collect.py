@@ -1,0 +1,114 @@
+"""PMC evidence for bench.py's roofline object, per kernel, tracked: writes profiles/r02_pmc.json.
+
+    python tests/tools/pmc_collect.py [workload]            # on the GPU box
+
+Separate rocprofv3 passes (--kernel-trace + ONE --pmc group each; FETCH_SIZE and WRITE_SIZE cannot share a pass, see
+/opt/skills/guides/MI355X_MICROARCH.md "rocprofv3 PMC slots") of `bench.py --inflight 1 --no-cpu --no-latency`, i.e. every
+kernel alone on the chip, 256 scenes per launch.  Per kernel: average of every counter over its dispatches, the average
+duration from the kernel trace of the same pass, and derived figures:
+  valu_issue_frac  = SQ_ACTIVE_INST_VALU [quad-cycles] / (GRBM_GUI_ACTIVE per XCD [cycles] x 1024 SIMDs / 4)
+  fp64_flops       = 64 lanes x (ADD_F64 + MUL_F64 + 2 FMA_F64) wave-instructions (an upper bound: lanes may be masked off)
+  hbm_bytes        = FETCH_SIZE [KiB] x 1024 (x2 only where the kernel streams 16 B/lane -- none of ours do: the reads are
+                     4-B/lane gathers, counted at face value, see the guide's HBM section) + WRITE_SIZE [KiB] x 1024
+`source_hash` ties the file to the kernel sources it was measured on (bench.py ignores it otherwise)."""
+import collections, csv, json, os, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+GROUPS = [
+    ["SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64",
+     "SQ_INSTS_MFMA", "SQ_INSTS_SALU", "SQ_INSTS_LDS"],
+    ["SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAVES",
+     "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"],
+    ["SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_ACTIVE_INST_LDS",
+     "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"],
+    ["FETCH_SIZE"],
+    ["WRITE_SIZE"],
+]
+KERNELS = ("dune_kernel", "select_kernel", "nrmp_qp_kernel", "stage_kernel")
+
+
+def short(name):
+    n = name.replace("void ", "")
+    for k in KERNELS:
+        if n.startswith(k):
+            return k
+    return None
+
+
+def run_pass(counters, workload):
+    d = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "-o", "p", "--",
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu", "--no-latency",
+           "--inflight", "1", "--workload", workload]
+    r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    agg, n = collections.defaultdict(lambda: collections.defaultdict(float)), collections.Counter()
+    dur, nd = collections.defaultdict(float), collections.Counter()
+    full = {}
+    for root, _, files in os.walk(d):
+        for f in files:
+            if f.endswith("counter_collection.csv"):
+                for row in csv.DictReader(open(os.path.join(root, f))):
+                    k = short(row["Kernel_Name"])
+                    if k is None:
+                        continue
+                    full[k] = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                    agg[k][row["Counter_Name"]] += float(row["Counter_Value"]); n[(k, row["Counter_Name"])] += 1
+            if f.endswith("kernel_trace.csv"):
+                for row in csv.DictReader(open(os.path.join(root, f))):
+                    k = short(row["Kernel_Name"])
+                    if k is None:
+                        continue
+                    dur[k] += (float(row["End_Timestamp"]) - float(row["Start_Timestamp"])) * 1e-6; nd[k] += 1
+    out = {k: {c: v / n[(k, c)] for c, v in cs.items()} for k, cs in agg.items()}
+    return out, {k: dur[k] / nd[k] for k in dur}, full, (r.returncode, r.stdout[-400:])
+
+
+def main():
+    from bench import source_hash, BATCH
+    workload = sys.argv[1] if len(sys.argv) > 1 else "diff_1k_T10_K10"
+    kern = collections.defaultdict(dict)
+    durs = collections.defaultdict(list)
+    names, log = {}, []
+    for g in GROUPS:
+        vals, dur, full, (rc, tail) = run_pass(g, workload)
+        log.append({"counters": g, "rc": rc, "kernels_seen": sorted(vals)})
+        if rc != 0 or not vals:          # an unknown counter kills the pass: retry one by one
+            for c in g:
+                v1, d1, f1, (rc1, _) = run_pass([c], workload)
+                log.append({"counters": [c], "rc": rc1, "kernels_seen": sorted(v1)})
+                for k in v1:
+                    kern[k].update(v1[k]); durs[k].append(d1.get(k, 0.0)); names.update(f1)
+            continue
+        names.update(full)
+        for k in vals:
+            kern[k].update(vals[k]); durs[k].append(dur.get(k, 0.0))
+    res = {"source_hash": source_hash(), "workload": workload, "scenes_per_launch": BATCH,
+           "command": "rocprofv3 --kernel-trace --pmc <group> -- python bench.py --steps 4 --warmup 1 --no-cpu --no-latency --inflight 1",
+           "passes": log, "kernels": {}}
+    for k, c in kern.items():
+        ms = sum(durs[k]) / max(len(durs[k]), 1)
+        e = {"kernel": names.get(k, k), "avg_ms_alone": ms, "counters": c}
+        gui = c.get("GRBM_GUI_ACTIVE")
+        if gui and ms > 0:
+            per_xcd = gui / max(1, round(gui / (ms * 1e-3 * 2.3e9)))      # the CSV may hold the sum over the 8 XCDs
+            e["gui_active_cycles_per_xcd"] = per_xcd
+            if "SQ_ACTIVE_INST_VALU" in c:
+                e["valu_issue_frac"] = c["SQ_ACTIVE_INST_VALU"] / (per_xcd * 1024 / 4)
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+                e["mfma_busy_frac"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (per_xcd * 1024)
+        if "SQ_INSTS_VALU" in c:
+            e["valu_insts_per_launch"] = c["SQ_INSTS_VALU"]
+        e["fp64_flops_per_launch"] = 64.0 * (c.get("SQ_INSTS_VALU_ADD_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0) +
+                                             2 * c.get("SQ_INSTS_VALU_FMA_F64", 0))
+        f, w = c.get("FETCH_SIZE", 0.0) * 1024, c.get("WRITE_SIZE", 0.0) * 1024
+        e["fetch_bytes_raw"], e["write_bytes"], e["hbm_bytes_per_launch"] = f, w, f + w
+        res["kernels"][k] = e
+    os.makedirs(os.path.join(ROOT, "gpurun_out", "r02"), exist_ok=True)
+    json.dump(res, open(os.path.join(ROOT, "gpurun_out", "r02", f"pmc_{workload}.json"), "w"), indent=1)
+    print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "counters"} for k, v in res["kernels"].items()}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
