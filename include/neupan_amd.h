@@ -126,20 +126,12 @@ int npa_forward_batch(npa_handle *h, int batch, int n_stride,
                       void *workspace, size_t workspace_bytes, void *state, size_t state_bytes,
                       void *stream);
 
-/* npa_forward_batch == npa_forward_begin + iter_num x npa_forward_iter(k) + npa_forward_end.
- * The split lets a host interleave the PAN iterations of several independent batches (one handle
- * each) on ONE stream: the DUNE launches of all batches stay ordered on `stream`, each batch's QP
- * chain runs on that handle's helper stream (qp_on_helper_stream != 0) and overlaps the other
- * batches' DUNE launches.  Same arguments as npa_forward_batch; buffers must stay valid until
- * the work enqueued by npa_forward_end has completed.
- * `qp_on_helper_stream` is a flag word: NPA_FWD_HELPER (1) as above; with it the staging copies
- * also go to the helper stream (behind the previous forward's last QP on this handle), so a new
- * forward can be begun before the previous one was joined.  NPA_FWD_RESET_STATE (2): zero the stop
- * criterion's state buffer first (a fresh planner).
- * npa_forward_end joins on `stream`; npa_forward_end_on(h, join_stream) makes `join_stream` wait for
- * the results instead (NULL: no join -- the caller synchronises some other way), which keeps
- * `stream` free for the other batches' DUNE launches. */
-#define NPA_FWD_HELPER 1
+/* npa_forward_batch == npa_forward_begin + iter_num x npa_forward_iter(k) + npa_forward_end, all enqueued on `stream`.
+ * The split lets a caller look at the working nominal between PAN iterations (it sits at the head of the workspace:
+ * cur_s [B][3][T+1], then cur_u [B][2][T] at the next 16-byte boundary).  Same arguments as npa_forward_batch; buffers
+ * must stay valid until the enqueued work has completed.  Independent batches overlap by running on different
+ * streams, one handle each.
+ * flags: NPA_FWD_RESET_STATE zeroes the stop criterion's state buffer first (a fresh planner), inside the staging launch. */
 #define NPA_FWD_RESET_STATE 2
 int npa_forward_begin(npa_handle *h, int batch, int n_stride,
                       const float *nom_s, const float *nom_u, const float *ref_s, const float *ref_us,
@@ -147,14 +139,9 @@ int npa_forward_begin(npa_handle *h, int batch, int n_stride,
                       float *out_s, float *out_u, float *out_d, float *out_min_distance,
                       int32_t *out_iters, float *out_nrmp_points,
                       void *workspace, size_t workspace_bytes, void *state, size_t state_bytes,
-                      void *stream, int qp_on_helper_stream);
+                      void *stream, int flags);
 int npa_forward_iter(npa_handle *h, int k);
 int npa_forward_end(npa_handle *h);
-int npa_forward_end_on(npa_handle *h, void *join_stream);
-/* Use `stream` (caller-owned) as this handle's helper stream instead of its own; NULL restores it.
- * Several handles may share one helper stream: their select+QP chains then run one after the other,
- * which bounds how many QP launches co-execute with the DUNE launches (forward_interleaved's `lanes`). */
-int npa_set_helper_stream(npa_handle *h, void *stream);
 
 /* Stage entry points (used by the parity tests and for profiling one stage alone).
  * npa_dune_stage  = generate_point_flow + DUNE.forward + the top-M gather:
@@ -171,6 +158,17 @@ int npa_nrmp_stage(npa_handle *h, int batch, const float *nom_s, const float *no
                    const float *ref_s, const float *ref_us, const float *mu_sorted,
                    const float *lam_sorted, const float *pts_sorted, const int32_t *count,
                    float *out_s, float *out_u, float *out_d, double *qp_info, void *stream);
+
+/* npa_nrmp_params = the parameter build of npa_nrmp_stage alone, for parity tests: what generate_state_parameter_value
+ * (robot.py:239-316: A_t, B_t, C_t of the linearised model) and generate_coefficient_parameter_value (nrmp.py:220-261:
+ * fa, fb of the hinge rows, slice t+1 of the sorted DUNE output, padding rule nrmp.py:258-259) hand to the solver, in
+ * fp32 exactly as the kernel built them (they never leave LDS otherwise):
+ *   out_abc [B][T][11]: A[0][2] A[1][2] B[0][0] B[0][1] B[1][0] B[1][1] B[2][0] B[2][1] C[0] C[1] C[2]
+ *                       (A's other entries are those of the identity);
+ *   out_f   [B][T][M][3]: fa[.,0], fa[.,1], fb (NULL allowed when nrmp_max_num == 0). */
+int npa_nrmp_params(npa_handle *h, int batch, const float *nom_s, const float *nom_u, const float *mu_sorted,
+                    const float *lam_sorted, const float *pts_sorted, const int32_t *count, float *out_abc,
+                    float *out_f, void *stream);
 
 /* npa_nrmp_backward = npa_nrmp_stage + the gradient of a scalar loss L(opt_s, opt_u, opt_d) w.r.t. the
  * adjust parameters.  Replaces what cvxpylayers provides in the reference (the adjust parameters are

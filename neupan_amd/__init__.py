@@ -6,7 +6,7 @@ from .robot import Robot  # noqa: F401
 from .scenes import CONFIGS, SceneConfig, make_batch, make_scene  # noqa: F401
 
 
-_LAZY = {"PAN": ("pan", "PAN"), "forward_interleaved": ("pan", "forward_interleaved"), "PanPipeline": ("pan", "PanPipeline"),
+_LAZY = {"PAN": ("pan", "PAN"), "forward_interleaved": ("pan", "forward_interleaved"),
          "FleetPlanner": ("fleet", "FleetPlanner"), "NominalBatch": ("frontend", "NominalBatch"),
          "scan_to_point_batch": ("frontend", "scan_to_point_batch"),
          "scan_to_point_velocity_batch": ("frontend", "scan_to_point_velocity_batch"),

@@ -47,10 +47,9 @@ SYMBOLS = {
     "npa_forward_begin": (_I, [_P, _I, _I] + [_P] * 13 + [_P, _SZ, _P, _SZ, _P, _I]),
     "npa_forward_iter": (_I, [_P, _I]),
     "npa_forward_end": (_I, [_P]),
-    "npa_forward_end_on": (_I, [_P, _P]),
-    "npa_set_helper_stream": (_I, [_P, _P]),
     "npa_dune_stage": (_I, [_P, _I, _I] + [_P] * 9 + [_P]),
     "npa_nrmp_stage": (_I, [_P, _I] + [_P] * 12 + [_P]),
+    "npa_nrmp_params": (_I, [_P, _I] + [_P] * 8 + [_P]),
     "npa_nrmp_backward": (_I, [_P, _I] + [_P] * 17 + [_P]),
     "npa_nominal_ref_states": (_I, [_I, _I, _I, C.c_double, C.c_double] + [_P] * 12 + [_P]),
     "npa_path_progress": (_I, [_I, _P, _P, _P, _P, _P, C.c_double, _I, C.c_double, _I, _P, _P, _P]),

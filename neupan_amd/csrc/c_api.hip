@@ -33,7 +33,7 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
                                     const int* count, float* cur_s_out, float* cur_u_out, float* cur_d_out,
                                     float* out_s, float* out_u, float* out_d, float* out_min_distance,
                                     int* out_iters, float* out_nrmp_points, int* flags, float* state,
-                                    double* qp_info, double* warm, float* trig_out, hipStream_t stream,
+                                    double* qp_info, float* trig_out, float* dbg_abc, float* dbg_f, hipStream_t stream,
                                     hipEvent_t ev_start, hipEvent_t ev_stop);
 extern "C" size_t npa_qp_shmem_bytes(int T, int M);
 extern "C" hipError_t npa_launch_nominal(int batch, int T, int kin, double dt, double L, const double* state,
@@ -60,18 +60,8 @@ struct npa_handle {
   float* wpack = nullptr;     // device
   int device = 0;
   int n_cu = 256;
-  float* stage_cand = nullptr;   // distance-key scratch of npa_dune_stage (grown on demand)
+  float* stage_cand = nullptr;   // scratch of npa_dune_stage (keys, trig table), grown on demand
   size_t stage_cand_bytes = 0;
-  // sub-batch pipelining: DUNE launches stay in order on the caller's stream, each
-  // sub-batch's QP chain runs on its own helper stream so it overlaps the other
-  // sub-batches' DUNE launches (the QP is latency bound and occupies one wave per scene)
-  int n_sub = 1;              // sub-batches of one forward (NPA_PIPELINE); >1 rarely pays, see DESIGN.md
-  int enc_blocks = 5;         // encode workgroups per CU (persistent grid = n_cu * enc_blocks; the
-                              // launcher caps it at 4 for the fp32-key variant, 117 VGPRs); 4-wave workgroups only
-  // IPM warm start across the PAN iterations of one forward call (NPA_QP_WARM=1): fewer iterations
-  // on average (12.6 -> 8.5) but a longer tail, and the iterates land at slightly different points of
-  // the QP's flat directions (control L2 vs oracle up to 1e-3 on some scenes) -> off by default
-  bool warm_start = false;
   // distance keys (dune_kernel): 1 = single fp16 products, 3 = fp16x2 split products, 0 = the exact fp32 encoder.
   // key_e0: select_kernel's candidate margin e0 (1 + |d|), a multiple of the key error measured at creation
   int key_terms = 1;                     // 4 = geometric keys computed by select_kernel itself (no dune_kernel launch)
@@ -89,9 +79,6 @@ struct npa_handle {
   unsigned stats_mark = 0;
   unsigned long long tiles_window = 0;
   int calls_window = 0, hold = 0;
-  hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
-  hipStream_t own_aux0 = nullptr;        // the helper stream created with the handle (aux[0] may be replaced)
-  std::vector<hipEvent_t> sync_ev;
   // profiling (bench.py): HIP events on the launch stream around every stage launch
   bool prof = false;
   std::vector<EventPair> ev_dune, ev_sel, ev_qp;
@@ -269,22 +256,13 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
             kh[((((size_t)L * 2 + 1) * 2 + s2) * 64 + l) * 8 + q] = h2;
           }
   }
-  if (const char* env = getenv("NPA_PIPELINE")) {
-    int v = atoi(env);
-    if (v >= 1 && v <= 4) h->n_sub = v;
-  }
-  if (const char* env = getenv("NPA_QP_WARM")) h->warm_start = atoi(env) != 0;
   h->sel_debug = getenv("NPA_SEL_DEBUG") != nullptr;
-  if (const char* env = getenv("NPA_ENC_BLOCKS")) { int v = atoi(env); if (v >= 1 && v <= 8) h->enc_blocks = v; }
   hipError_t e = hipGetDevice(&h->device);
   if (e == hipSuccess) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0)
       h->n_cu = prop.multiProcessorCount;
   }
-  for (int i = 0; i < (h->n_sub > 1 ? h->n_sub : 1) && e == hipSuccess; ++i)
-    e = hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking);
-  h->own_aux0 = h->aux[0];
   if (e == hipSuccess) e = hipMalloc(&h->wpack, WP_TOTAL * sizeof(float));
   if (e == hipSuccess) e = hipMemcpy(h->wpack, pack.data(), WP_TOTAL * sizeof(float), hipMemcpyHostToDevice);
   // Key mode and candidate margin.  Distance KEYS only nominate candidates (select_kernel re-encodes them with the
@@ -408,9 +386,6 @@ extern "C" int npa_destroy(npa_handle* h) {
   for (auto& p : h->ev_dune) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto& p : h->ev_sel) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto& p : h->ev_qp) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
-  for (auto& ev : h->sync_ev) hipEventDestroy(ev);
-  if (h->own_aux0) hipStreamDestroy(h->own_aux0);
-  for (int i = 1; i < 4; ++i) if (h->aux[i]) hipStreamDestroy(h->aux[i]);
   if (h->wpack) hipFree(h->wpack);
   if (h->sel_stats_dev) hipFree(h->sel_stats_dev);
   if (h->sel_stats_host) hipHostFree(h->sel_stats_host);
@@ -517,7 +492,7 @@ extern "C" int npa_dune_stage(npa_handle* h, int batch, int n_stride, const floa
   HIP_TRY(npa_launch_trig(nom_s, batch, h->P.T, trig, (hipStream_t)stream));
   if (!geo)
     HIP_TRY(npa_launch_encode(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr,
-                              (unsigned*)h->stage_cand, trig, h->n_cu, h->enc_blocks, h->key_terms, (hipStream_t)stream,
+                              (unsigned*)h->stage_cand, trig, h->n_cu, 5, h->key_terms, (hipStream_t)stream,
                               nullptr, nullptr));
   HIP_TRY(npa_launch_select(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr,
                             (const unsigned*)h->stage_cand, trig, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count,
@@ -535,7 +510,20 @@ extern "C" int npa_nrmp_stage(npa_handle* h, int batch, const float* nom_s, cons
     return fail(NPA_E_ARG, "npa_nrmp_stage: obstacle arrays required when nrmp_max_num > 0");
   HIP_TRY(npa_launch_qp(h->P, batch, 0, nom_s, nom_u, ref_s, ref_us, mu_sorted, lam_sorted, pts_sorted, nullptr, count,
                         out_s, out_u, out_d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                        qp_info, nullptr, nullptr, (hipStream_t)stream, nullptr, nullptr));
+                        qp_info, nullptr, nullptr, nullptr, (hipStream_t)stream, nullptr, nullptr));
+  return NPA_OK;
+}
+
+extern "C" int npa_nrmp_params(npa_handle* h, int batch, const float* nom_s, const float* nom_u, const float* mu_sorted,
+                               const float* lam_sorted, const float* pts_sorted, const int32_t* count, float* out_abc,
+                               float* out_f, void* stream) {
+  if (!h || batch < 1 || !nom_s || !nom_u || !out_abc) return fail(NPA_E_ARG, "npa_nrmp_params: bad argument");
+  if (h->P.M > 0 && (!mu_sorted || !lam_sorted || !pts_sorted || !count || !out_f))
+    return fail(NPA_E_ARG, "npa_nrmp_params: obstacle arrays required when nrmp_max_num > 0");
+  // (the reference trajectory only enters the cost: the nominal arrays stand in for it, the kernel returns before the solve)
+  HIP_TRY(npa_launch_qp(h->P, batch, 0, nom_s, nom_u, nom_s, nom_u, mu_sorted, lam_sorted, pts_sorted, nullptr, count,
+                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                        nullptr, nullptr, out_abc, h->P.M > 0 ? out_f : nullptr, (hipStream_t)stream, nullptr, nullptr));
   return NPA_OK;
 }
 
@@ -583,13 +571,14 @@ __global__ void stage_kernel(float* __restrict__ cur_s, const float* __restrict_
 }
 
 // ---- forward = begin + K x iter + end ------------------------------------------------------------
-// The split exists so that a host can interleave the PAN iterations of several independent
-// batches (one handle each) on ONE stream: DUNE launches of all batches stay ordered there, each
-// batch's QP chain runs on that handle's helper stream(s) and overlaps the other batches' DUNE
-// launches (neupan_amd.pan.forward_interleaved).  npa_forward_batch is the single-batch form.
+// One forward call is a chain of launches on ONE stream: staging, then per PAN iteration the selection (preceded by
+// the key launch when the handle uses network keys) and the QP.  Independent batches overlap by running on different
+// streams (one handle each; neupan_amd.pan.forward_interleaved, bench.py): every kernel here is latency bound, and
+// the waves of one batch fill the SIMDs the others leave idle.  The split into begin / iter / end exists for the
+// callers that look at the working nominal between iterations (PAN.forward_batch_trace, the gradient chain).
 struct PendingCall {
   bool active = false;
-  int batch = 0, n_stride = 0, nsub = 1;
+  int batch = 0, n_stride = 0;
   const float *ref_s = nullptr, *ref_us = nullptr, *points = nullptr, *velocities = nullptr;
   const int32_t* n_points = nullptr;
   float *out_s = nullptr, *out_u = nullptr, *out_d = nullptr, *out_md = nullptr, *out_np = nullptr;
@@ -597,7 +586,7 @@ struct PendingCall {
   float* ws = nullptr;
   float* state = nullptr;
   hipStream_t stream = nullptr;
-  bool dune = false, qp_aux = false, staged_on_aux = false;
+  bool dune = false;
 };
 static std::mutex g_pending_mu;
 static std::vector<std::pair<npa_handle*, PendingCall>> g_pending;
@@ -608,22 +597,11 @@ static PendingCall* pending_of(npa_handle* h, bool create) {
   return &g_pending.back().second;
 }
 
-extern "C" int npa_set_helper_stream(npa_handle* h, void* stream) {
-  if (!h) return fail(NPA_E_ARG, "npa_set_helper_stream: null handle");
-  {
-    std::lock_guard<std::mutex> lock(g_pending_mu);
-    PendingCall* pc = pending_of(h, false);
-    if (pc && pc->active) return fail(NPA_E_ARG, "npa_set_helper_stream: a forward is in progress on this handle");
-  }
-  h->aux[0] = stream ? (hipStream_t)stream : h->own_aux0;
-  return NPA_OK;
-}
-
-// Single fp16 products make the key launch ~25 % cheaper but put more points inside select_kernel's margin; when
-// they do not fit the final tile the slice re-encodes them exactly, ~3 key-tile units per tile.  Every 8 forward
-// calls compare the two: if the re-encoded tiles cost more than the saving, use the split products for the next
-// 256 calls, then try again.  (The outputs are bitwise the same in either mode; only the time differs.)  The
-// counter is read from a pinned copy that trails the device by a call or two -- good enough for a policy.
+// Network keys only.  Single fp16 products make the key launch ~25 % cheaper but put more points inside
+// select_kernel's margin; when they do not fit the final ranking the slice re-encodes them exactly, ~3 key-tile units
+// per tile.  Every 8 forward calls compare the two: if the re-encoded tiles cost more than the saving, use the split
+// products for the next 256 calls, then try again.  (The outputs are bitwise the same in either mode; only the time
+// differs.)  The counter is read from a pinned copy that trails the device by a call or two -- good enough for a policy.
 static void key_policy(npa_handle* h, int batch, int n_stride) {
   if (!h->key_auto) return;
   const DevParams& P = h->P;
@@ -634,9 +612,6 @@ static void key_policy(npa_handle* h, int batch, int n_stride) {
     h->stats_mark = now; h->tiles_window = 0; h->calls_window = 0;
   } else if (h->calls_window >= 8) {
     const unsigned redone = now - h->stats_mark;
-    static const bool dbg = getenv("NPA_KEY_DEBUG") != nullptr;
-    if (dbg) fprintf(stderr, "[npa key policy] re-encoded tiles %u vs key tiles %llu (ratio %.4f)\n", redone, h->tiles_window,
-                     (double)redone / (double)std::max<unsigned long long>(h->tiles_window, 1));
     if ((unsigned long long)redone * 12ull > h->tiles_window) {
       h->key_terms = 3; h->key_err = h->err_mode[1]; h->key_e0 = h->e0_mode[1]; h->hold = 256;
       return;
@@ -653,7 +628,7 @@ extern "C" int npa_forward_begin(npa_handle* h, int batch, int n_stride, const f
                                  const float* velocities, const int32_t* n_points, float* out_s, float* out_u,
                                  float* out_d, float* out_min_distance, int32_t* out_iters, float* out_nrmp_points,
                                  void* workspace, size_t workspace_bytes, void* state, size_t state_bytes,
-                                 void* stream_, int qp_on_helper_stream) {
+                                 void* stream_, int flags) {
   if (!h || batch < 1 || !nom_s || !nom_u || !ref_s || !ref_us || !out_s || !out_u || !workspace || !state)
     return fail(NPA_E_ARG, "npa_forward_begin: null argument");
   const DevParams& P = h->P;
@@ -668,8 +643,7 @@ extern "C" int npa_forward_begin(npa_handle* h, int batch, int n_stride, const f
   if (pc->active) return fail(NPA_E_ARG, "npa_forward_begin: previous forward on this handle not ended");
   hipStream_t stream = (hipStream_t)stream_;
   const int T = P.T;
-  const bool helper = (qp_on_helper_stream & NPA_FWD_HELPER) != 0;
-  const bool reset_state = (qp_on_helper_stream & NPA_FWD_RESET_STATE) != 0;
+  const bool reset_state = (flags & NPA_FWD_RESET_STATE) != 0;
   const ScratchLayout L = npa_scratch_layout(batch, T, mdim(P), P.E, kstride(h));
   float* ws = (float*)workspace;
   pc->batch = batch; pc->n_stride = n_stride; pc->ref_s = ref_s; pc->ref_us = ref_us; pc->points = points;
@@ -678,43 +652,17 @@ extern "C" int npa_forward_begin(npa_handle* h, int batch, int n_stride, const f
   pc->state = (float*)state; pc->stream = stream;
   pc->dune = P.M > 0 && points != nullptr;
   if (pc->dune) key_policy(h, batch, n_stride);
-  // sub-batches [lo_i, hi_i): DUNE(i,k) on `stream` in (k, i) order, QP(i,k) on aux[i]
-  // (when the caller interleaves several batches the batches themselves are the pipeline stages)
-  const bool geo = h->key_terms == 4;
-  pc->nsub = (h->n_sub > 1 && pc->dune && batch >= 16 * h->n_sub && !helper && !geo) ? h->n_sub : 1;
-  pc->qp_aux = pc->dune && (pc->nsub > 1 || (helper && h->aux[0]));
-  const size_t need_ev = (size_t)2 * pc->nsub * P.K + 2;
-  while (h->sync_ev.size() < need_ev) {
-    hipEvent_t ev;
-    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    h->sync_ev.push_back(ev);
-  }
-  // staging.  With a helper stream it goes THERE: behind the last QP of the previous forward on this
-  // handle (which still owns the scratch), so the caller need not have joined that forward on `stream`.
-  pc->staged_on_aux = pc->qp_aux && pc->nsub == 1 && helper;
-  hipStream_t st = pc->staged_on_aux ? h->aux[0] : stream;
-  if (pc->staged_on_aux) {
-    HIP_TRY(hipEventRecord(h->sync_ev[1], stream));                 // the caller's inputs are ready
-    HIP_TRY(hipStreamWaitEvent(st, h->sync_ev[1], 0));
-  }
   {
-    // one launch instead of two copies and up to three memsets (each costs tens of microseconds
-    // of stream time between the forward calls)
+    // one launch instead of two copies and up to three memsets (each costs tens of microseconds of stream time)
     const size_t ns = (size_t)batch * 3 * (T + 1), nu2 = (size_t)batch * 2 * T;
     const size_t nflag = (size_t)batch * 4, ncount = (size_t)batch * (T + 1);
     const size_t nstate = reset_state ? npa_state_bytes(h, batch) / 4 : 0;
     const size_t work = std::max(std::max(ns, nu2), std::max(std::max(nflag, ncount), nstate));
     const int threads = 256;
     const int blocks = (int)std::min<size_t>((work + threads - 1) / threads, 512);
-    hipLaunchKernelGGL(stage_kernel, dim3(blocks), dim3(threads), 0, st, ws + L.cur_s, nom_s, ns, ws + L.cur_u, nom_u, nu2,
+    hipLaunchKernelGGL(stage_kernel, dim3(blocks), dim3(threads), 0, stream, ws + L.cur_s, nom_s, ns, ws + L.cur_u, nom_u, nu2,
                        (int*)(ws + L.flags), nflag, (int*)(ws + L.count), ncount, (int*)state, nstate, ws + L.trig, T);
     HIP_TRY(hipGetLastError());
-  }
-  if (pc->staged_on_aux) {
-    HIP_TRY(hipEventRecord(h->sync_ev[0], st));                     // staged: the first DUNE launch waits for it
-  } else if (pc->qp_aux) {
-    HIP_TRY(hipEventRecord(h->sync_ev[0], stream));                 // inputs staged
-    for (int i = 0; i < pc->nsub; ++i) HIP_TRY(hipStreamWaitEvent(h->aux[i], h->sync_ev[0], 0));
   }
   pc->active = true;
   return NPA_OK;
@@ -727,7 +675,7 @@ extern "C" int npa_forward_iter(npa_handle* h, int k) {
   if (!pc || !pc->active) return fail(NPA_E_ARG, "npa_forward_iter: no forward in progress on this handle");
   const DevParams& P = h->P;
   if (k < 0 || k >= P.K) return fail(NPA_E_ARG, "npa_forward_iter: iteration index out of range");
-  const int T = P.T, batch = pc->batch, nsub = pc->nsub;
+  const int T = P.T, batch = pc->batch;
   const bool geo = h->key_terms == 4;
   const ScratchLayout L = npa_scratch_layout(batch, T, mdim(P), P.E, kstride(h));
   float* ws = pc->ws;
@@ -735,75 +683,41 @@ extern "C" int npa_forward_iter(npa_handle* h, int k) {
   float *mu = ws + L.mu, *lam = ws + L.lam, *pts = ws + L.pts, *dist = ws + L.dist;
   int* count = (int*)(ws + L.count);
   int* flags = (int*)(ws + L.flags);
-  double* warm = (double*)(ws + L.warm);
   double* qp_info = (double*)(ws + L.qp_info);
   unsigned* gkeys = (unsigned*)(ws + L.keys);
   hipStream_t stream = pc->stream;
-  auto lo = [&](int i) { return (int)((long long)batch * i / nsub); };
-  auto ev_d = [&](int i, int kk) { return h->sync_ev[2 + (size_t)2 * (kk * nsub + i)]; };
-  auto ev_q = [&](int i, int kk) { return h->sync_ev[2 + (size_t)2 * (kk * nsub + i) + 1]; };
-  for (int i = 0; i < nsub; ++i) {
-    const int s0 = lo(i), nb = lo(i + 1) - lo(i);
-    hipStream_t qs = pc->qp_aux ? h->aux[i] : stream;
-    if (pc->dune) {
-      const int t0 = k == 0 ? 0 : 1;
-      if (!geo) {
-        if (pc->qp_aux && k > 0) HIP_TRY(hipStreamWaitEvent(stream, ev_q(i, k - 1), 0));
-        if (pc->staged_on_aux && k == 0) HIP_TRY(hipStreamWaitEvent(stream, h->sync_ev[0], 0));
-        EventPair* ev = next_event(h, h->ev_dune, h->n_dune);
-        // the events ride on the dispatch (no marker packets between back-to-back encode launches): the
-        // completion event is the profiling stop event when profiling, else the hand-over event
-        hipEvent_t done = ev ? ev->b : (pc->qp_aux ? ev_d(i, k) : nullptr);
-        HIP_TRY(npa_launch_encode(P, h->wpack, nb, s0, t0, pc->n_stride, cur_s, pc->points, pc->velocities,
-                                  pc->n_points, flags, gkeys, ws + L.trig, h->n_cu, h->enc_blocks, h->key_terms, stream,
-                                  ev ? ev->a : nullptr, done));
-        if (pc->qp_aux) HIP_TRY(hipStreamWaitEvent(qs, done, 0));
-      }
-      // selection + QP follow on `qs`.  Network keys: behind the encode launch, on the helper stream when there is
-      // one (the next encode launch on `stream` -- another sub-batch or another batch in flight -- overlaps them).
-      // Geometric keys: select_kernel computes its keys itself, the whole chain of this forward call lives on `qs`.
-      EventPair* evs = next_event(h, h->ev_sel, h->n_sel);
-      HIP_TRY(npa_launch_select(P, h->wpack, nb, s0, t0, pc->n_stride, cur_s, pc->points, pc->velocities,
-                                pc->n_points, flags, gkeys, ws + L.trig, mu, lam, pts, dist, count, h->key_terms, h->key_e0,
-                                h->sel_stats_dev, h->sel_debug, qs, evs ? evs->a : nullptr, evs ? evs->b : nullptr));
+  if (pc->dune) {
+    // slice 0 does not depend on the iterate (s(0) is pinned, robot.py:234): after the first iteration of a forward
+    // call only slices 1..T are redone
+    const int t0 = k == 0 ? 0 : 1;
+    if (!geo) {
+      EventPair* ev = next_event(h, h->ev_dune, h->n_dune);
+      HIP_TRY(npa_launch_encode(P, h->wpack, batch, 0, t0, pc->n_stride, cur_s, pc->points, pc->velocities,
+                                pc->n_points, flags, gkeys, ws + L.trig, h->n_cu, 5, h->key_terms, stream,
+                                ev ? ev->a : nullptr, ev ? ev->b : nullptr));
     }
-    EventPair* ev = next_event(h, h->ev_qp, h->n_qp);
-    HIP_TRY(npa_launch_qp(P, nb, s0, cur_s, cur_u, pc->ref_s, pc->ref_us, mu, lam, pts, dist, count, cur_s, cur_u,
-                          cur_d, pc->out_s, pc->out_u, pc->out_d, pc->out_md, pc->out_iters, pc->out_np, flags,
-                          pc->state, qp_info, h->warm_start ? warm : nullptr, pc->dune ? ws + L.trig : nullptr, qs,
-                          ev ? ev->a : nullptr, ev ? ev->b : nullptr));
-    if (pc->qp_aux && (!geo || k == P.K - 1)) HIP_TRY(hipEventRecord(ev_q(i, k), qs));
-    if (h->key_auto && pc->dune && k == P.K - 1 && i == nsub - 1)      // behind the hand-over event: nobody waits for it
-      HIP_TRY(hipMemcpyAsync(h->sel_stats_host, h->sel_stats_dev, sizeof(unsigned), hipMemcpyDeviceToHost, qs));
+    EventPair* evs = next_event(h, h->ev_sel, h->n_sel);
+    HIP_TRY(npa_launch_select(P, h->wpack, batch, 0, t0, pc->n_stride, cur_s, pc->points, pc->velocities,
+                              pc->n_points, flags, gkeys, ws + L.trig, mu, lam, pts, dist, count, h->key_terms, h->key_e0,
+                              h->sel_stats_dev, h->sel_debug, stream, evs ? evs->a : nullptr, evs ? evs->b : nullptr));
   }
-  return NPA_OK;
-}
-
-static int forward_end_impl(npa_handle* h, bool join, hipStream_t join_stream) {
-  if (!h) return fail(NPA_E_ARG, "npa_forward_end: null handle");
-  std::lock_guard<std::mutex> lock(g_pending_mu);
-  PendingCall* pc = pending_of(h, false);
-  if (!pc || !pc->active) return fail(NPA_E_ARG, "npa_forward_end: no forward in progress on this handle");
-  const int nsub = pc->nsub, K = h->P.K;
-  if (pc->qp_aux && join)                                               // join the helper streams
-    for (int i = 0; i < nsub; ++i)
-      HIP_TRY(hipStreamWaitEvent(join_stream, h->sync_ev[2 + (size_t)2 * ((K - 1) * nsub + i) + 1], 0));
-  pc->active = false;
+  EventPair* ev = next_event(h, h->ev_qp, h->n_qp);
+  HIP_TRY(npa_launch_qp(P, batch, 0, cur_s, cur_u, pc->ref_s, pc->ref_us, mu, lam, pts, dist, count, cur_s, cur_u,
+                        cur_d, pc->out_s, pc->out_u, pc->out_d, pc->out_md, pc->out_iters, pc->out_np, flags,
+                        pc->state, qp_info, pc->dune ? ws + L.trig : nullptr, nullptr, nullptr, stream,
+                        ev ? ev->a : nullptr, ev ? ev->b : nullptr));
+  if (h->key_auto && pc->dune && k == P.K - 1)
+    HIP_TRY(hipMemcpyAsync(h->sel_stats_host, h->sel_stats_dev, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
   return NPA_OK;
 }
 
 extern "C" int npa_forward_end(npa_handle* h) {
-  hipStream_t s = nullptr;
-  {
-    std::lock_guard<std::mutex> lock(g_pending_mu);
-    PendingCall* pc = h ? pending_of(h, false) : nullptr;
-    if (pc) s = pc->stream;
-  }
-  return forward_end_impl(h, true, s);
-}
-
-extern "C" int npa_forward_end_on(npa_handle* h, void* join_stream) {
-  return forward_end_impl(h, join_stream != nullptr, (hipStream_t)join_stream);
+  if (!h) return fail(NPA_E_ARG, "npa_forward_end: null handle");
+  std::lock_guard<std::mutex> lock(g_pending_mu);
+  PendingCall* pc = pending_of(h, false);
+  if (!pc || !pc->active) return fail(NPA_E_ARG, "npa_forward_end: no forward in progress on this handle");
+  pc->active = false;
+  return NPA_OK;
 }
 
 extern "C" int npa_forward_batch(npa_handle* h, int batch, int n_stride, const float* nom_s, const float* nom_u,

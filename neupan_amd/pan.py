@@ -256,12 +256,9 @@ class PAN(torch.nn.Module):
         return t
 
     # ------------------------------------------------------------------ batched entry
-    def forward_begin(self, nom_s, nom_u, ref_s, ref_us, points=None, velocities=None, n_points=None,
-                      qp_on_helper_stream=False, reset_state=False):
-        """Stage one batch (see forward_batch for shapes) and start a forward: follow with
-        forward_iter(k) for k in range(iter_num) and forward_end().  With qp_on_helper_stream the QP
-        chain of this batch runs on the handle's helper stream so that another planner's DUNE
-        launches, enqueued on the same (current) stream, overlap it -- see forward_interleaved."""
+    def forward_begin(self, nom_s, nom_u, ref_s, ref_us, points=None, velocities=None, n_points=None, reset_state=False):
+        """Stage one batch (see forward_batch for shapes) and start a forward on the current stream: follow with
+        forward_iter(k) for k in range(iter_num) and forward_end()."""
         T, M = self.T, self.nrmp_max_num
         nom_s = self._dev(nom_s)
         B = nom_s.shape[0]
@@ -301,32 +298,21 @@ class PAN(torch.nn.Module):
                 self._h, B, max(n_stride, 1), _ptr(nom_s), _ptr(nom_u), _ptr(ref_s), _ptr(ref_us), _ptr(points),
                 _ptr(velocities), _ptr(n_points), _ptr(out_s), _ptr(out_u), _ptr(out_d), _ptr(out_md), _ptr(out_it),
                 _ptr(out_np), _ptr(ws), ws.numel(), _ptr(state), state.numel(), C.c_void_p(stream),
-                (1 if qp_on_helper_stream else 0) | (2 if reset_state else 0)), "npa_forward_begin")
+                2 if reset_state else 0), "npa_forward_begin")
         # keep inputs alive until the stream has consumed them
         self._last = dict(points=points, velocities=velocities, n_points=n_points, min_distance=out_md,
                           nrmp_points=out_np, used_points=use_pts, hold=(nom_s, nom_u, ref_s, ref_us))
         self._pending = dict(opt_s=out_s, opt_u=out_u, opt_d=out_d, min_distance=out_md, iters=out_it, nrmp_points=out_np)
 
-    def set_helper_stream(self, stream=None):
-        """Run this planner's select+QP chain on `stream` (a torch.cuda.Stream; None = the handle's own)."""
-        self._helper = stream                      # keep it alive
-        check(self._lib.npa_set_helper_stream(self._h, None if stream is None else C.c_void_p(stream.cuda_stream)),
-              "npa_set_helper_stream")
-
     def forward_iter(self, k):
-        """Enqueue PAN iteration k (DUNE launch + QP launch) of the forward started by forward_begin."""
-        with torch.cuda.device(self.device):       # the launches must see the device of the handle's streams
+        """Enqueue PAN iteration k (selection + QP launches) of the forward started by forward_begin."""
+        with torch.cuda.device(self.device):       # the launches must see the device of the handle
             check(self._lib.npa_forward_iter(self._h, int(k)), "npa_forward_iter")
 
-    def forward_end(self, join_stream=None):
-        """Join the helper streams; returns the output dict (device tensors, valid in stream order).
-        join_stream: a torch.cuda.Stream that waits for the results INSTEAD of the stream the forward
-        was begun on (PanPipeline: that stream stays free for the other batches' DUNE launches)."""
+    def forward_end(self):
+        """Close the forward; returns the output dict (device tensors, valid in stream order)."""
         with torch.cuda.device(self.device):
-            if join_stream is None:
-                check(self._lib.npa_forward_end(self._h), "npa_forward_end")
-            else:
-                check(self._lib.npa_forward_end_on(self._h, C.c_void_p(join_stream.cuda_stream)), "npa_forward_end_on")
+            check(self._lib.npa_forward_end(self._h), "npa_forward_end")
         out, self._pending = self._pending, None
         self.last_out = out
         return out
@@ -439,6 +425,30 @@ class PAN(torch.nn.Module):
                                            _ptr(info), C.c_void_p(stream)), "npa_nrmp_stage")
         torch.cuda.synchronize(dev)
         return dict(opt_s=out_s, opt_u=out_u, opt_d=out_d, info=info)
+
+    def nrmp_params(self, nom_s, nom_u, stage=None):
+        """The parameters the NRMP kernel builds before it solves (npa_nrmp_params): dict(A (B,T,3,3), B (B,T,3,2),
+        C (B,T,3,1), fa (B,T,M,2), fb (B,T,M,1)) in the reference's shapes (robot.py:239-316, nrmp.py:220-261)."""
+        T, M = self.T, self.nrmp_max_num
+        nom_s = self._dev(nom_s)
+        B = nom_s.shape[0]
+        nom_u = self._dev(nom_u, (B, 2, T))
+        dev = self.device
+        abc = torch.zeros((B, T, 11), dtype=torch.float32, device=dev)
+        f = torch.zeros((B, T, max(M, 1), 3), dtype=torch.float32, device=dev)
+        g = (lambda k: _ptr(stage[k])) if stage is not None else (lambda k: None)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            check(self._lib.npa_nrmp_params(self._h, B, _ptr(nom_s), _ptr(nom_u), g("mu"), g("lam"), g("pts"), g("count"),
+                                            _ptr(abc), _ptr(f), C.c_void_p(stream)), "npa_nrmp_params")
+        torch.cuda.synchronize(dev)
+        a = abc.cpu().numpy()
+        A = np.tile(np.eye(3, dtype=np.float32), (B, T, 1, 1))
+        A[:, :, 0, 2], A[:, :, 1, 2] = a[:, :, 0], a[:, :, 1]
+        Bm = a[:, :, 2:8].reshape(B, T, 3, 2)
+        Cm = a[:, :, 8:11].reshape(B, T, 3, 1)
+        fn = f.cpu().numpy()
+        return dict(A=A, B=Bm, C=Cm, fa=fn[..., 0:2], fb=fn[..., 2:3])
 
     def nrmp_backward(self, nom_s, nom_u, ref_s, ref_us, stage, grad_s, grad_u, grad_d=None):
         """One NRMP solve plus dL/d(q_s[3], p_u, eta, d_max, d_min) per scene for upstream gradients
@@ -567,136 +577,27 @@ class _PanGrad(torch.autograd.Function):
 _STREAMS = {}
 
 
-def forward_interleaved(planners, inputs, mode=None, reset_state=False, lanes=None, coalesce=1):
-    """Plan several independent batches concurrently: `planners[i]` (one PAN per batch in flight,
-    same configuration) plans `inputs[i]` (the positional arguments of forward_batch).
-    mode "events" (default): the DUNE launches of all batches are enqueued round-robin on the current
-      stream and each batch's select+QP on its planner's helper stream (one event per hand-over), so
-      DUNE launches never run beside each other.
-    mode "streams": every planner's whole chain (DUNE -> select -> QP, K times) goes to a stream of its
-      own and the hardware queues interleave the chains -- measured slower (94-113 k vs 122 k plans/s):
-      concurrent DUNE launches split the CUs and stretch each other.
-    lanes: number of helper streams shared by the planners' select+QP chains (planner j uses lane j % lanes);
-      default: one per planner.  Fewer lanes than planners bound how many QP launches co-execute with the
-      DUNE launches.
-    coalesce: run this many consecutive batches as one forward call (see the code comment).
-    reset_state: clear every planner's stop-criterion memory first (fresh planners), inside the staging launch.
-    Returns the list of output dicts (valid on the current stream)."""
-    import os
-    if coalesce and coalesce > 1:
-        # run `coalesce` consecutive batches as ONE forward call of the first planner of each group (larger
-        # launches amortise the per-launch gaps: 256 -> 512 scenes per launch gives +14 % plans/s) and hand
-        # the outputs back per batch.  The grouped batches must agree in every shape.
-        groups = [list(range(i, min(i + coalesce, len(inputs)))) for i in range(0, len(inputs), coalesce)]
-        cat = lambda ts: None if ts[0] is None else torch.cat([planners[0]._dev(t) for t in ts], dim=0)
-        merged = [[cat([inputs[j][a] if a < len(inputs[j]) else None for j in g]) for a in range(max(len(inputs[j]) for j in g))]
-                  for g in groups]
-        outs_m = forward_interleaved([planners[g[0]] for g in groups], merged, mode, reset_state, lanes, 1)
-        outs = []
-        for g, om in zip(groups, outs_m):
-            sizes = [planners[0]._dev(inputs[j][0]).shape[0] for j in g]
-            off = 0
-            for sz in sizes:
-                outs.append({k: (v[off:off + sz] if isinstance(v, torch.Tensor) else v) for k, v in om.items()})
-                off += sz
-        return outs
+def forward_interleaved(planners, inputs, reset_state=False):
+    """Plan several independent batches concurrently: `planners[i]` (one PAN per batch in flight, same configuration)
+    plans `inputs[i]` (the positional arguments of forward_batch) on a stream of its own; the results are joined on the
+    current stream.  Every kernel of the path is latency bound, so the chains of different batches fill each other's
+    idle SIMDs.  reset_state: clear every planner's stop-criterion memory first (fresh planners), inside the staging
+    launch.  Returns the list of output dicts (valid on the current stream)."""
     assert len(planners) == len(inputs) and len(planners) >= 1
-    mode = mode or os.environ.get("NPA_INTERLEAVE", "events")
-    K = planners[0].iter_num
-    for p in planners:
-        assert p.iter_num == K
-    if mode == "events" or len(planners) == 1:
-        if lanes:                                    # planner j's QP chain on helper lane j % lanes
-            key = ("lanes", planners[0].device.index, int(lanes))
-            if key not in _STREAMS:
-                _STREAMS[key] = [torch.cuda.Stream(device=planners[0].device) for _ in range(int(lanes))]
-            for j, p in enumerate(planners):
-                want = _STREAMS[key][j % int(lanes)]
-                if getattr(p, "_helper", None) is not want:
-                    p.set_helper_stream(want)
-        for p, a in zip(planners, inputs):
-            p.forward_begin(*a, qp_on_helper_stream=len(planners) > 1, reset_state=reset_state)
-        for k in range(K):
-            for p in planners:
-                p.forward_iter(k)
-        return [p.forward_end() for p in planners]
     dev = planners[0].device
     cur = torch.cuda.current_stream(dev)
     key = (dev.index, len(planners))
     if key not in _STREAMS:
         _STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in planners]
     streams = _STREAMS[key]
+    outs = []
     for st, p, a in zip(streams, planners, inputs):
         st.wait_stream(cur)                      # inputs were produced on the current stream
         with torch.cuda.stream(st):
-            p.forward_begin(*a, qp_on_helper_stream=False, reset_state=reset_state)
-    for k in range(K):
-        for st, p in zip(streams, planners):
-            with torch.cuda.stream(st):
-                p.forward_iter(k)
-    outs = []
-    for st, p in zip(streams, planners):
-        with torch.cuda.stream(st):
-            outs.append(p.forward_end())
+            outs.append(p.forward_batch(*a, reset_state=reset_state))
+    for st, o in zip(streams, outs):
         cur.wait_stream(st)
-        for t in outs[-1].values():              # allocated on `st`, consumed on the current stream
+        for t in o.values():                     # allocated on `st`, consumed on the current stream
             if isinstance(t, torch.Tensor):
                 t.record_stream(cur)
     return outs
-
-
-class PanPipeline:
-    """Continuous form of forward_interleaved: a queue of batches flows through `planners` (one per
-    batch in flight) with the planners' PAN iterations staggered, so that the forward calls do not end
-    together.  The DUNE launches of every batch go to the current stream; a finished batch is joined on
-    a separate output stream (npa_forward_end_on) and its planner starts the next batch at once -- its
-    staging runs on the helper stream behind its last QP -- so the DUNE stream never drains between
-    forward calls.  `run` returns the output dicts in submission order, valid on the current stream.
-    Measured on one MI355X (256 scenes per batch): 120 k plans/s with 3 planners, FALLING to 104 k with 5,
-    where lockstep groups (forward_interleaved) reach 122 k -- the cause was not found; bench.py keeps the
-    groups."""
-
-    def __init__(self, planners):
-        assert len(planners) >= 1
-        self.planners = list(planners)
-        self.K = planners[0].iter_num
-        assert all(p.iter_num == self.K for p in planners)
-        self.device = planners[0].device
-        self.out_stream = torch.cuda.Stream(device=self.device)
-
-    def run(self, inputs, reset_state=True):
-        n, K = len(self.planners), self.K
-        if n == 1:
-            outs = []
-            for a in inputs:
-                if reset_state:
-                    self.planners[0].reset_stop_state()
-                outs.append(self.planners[0].forward_batch(*a))
-            return outs
-        cur = torch.cuda.current_stream(self.device)
-        pending = list(enumerate(inputs))[::-1]
-        outs = [None] * len(inputs)
-        active = [None] * n                                  # [input index, next iteration]
-        start = [(j * K) // n for j in range(n)]             # stagger of the first forwards
-        tick = 0
-        while pending or any(a is not None for a in active):
-            for j, p in enumerate(self.planners):
-                if active[j] is None:
-                    if not pending or tick < start[j]:
-                        continue
-                    idx, a = pending.pop()
-                    p.forward_begin(*a, qp_on_helper_stream=True, reset_state=reset_state)
-                    active[j] = [idx, 0]
-                idx, k = active[j]
-                p.forward_iter(k)
-                if k + 1 == K:
-                    outs[idx] = p.forward_end(join_stream=self.out_stream)
-                    for t in outs[idx].values():
-                        if isinstance(t, torch.Tensor):
-                            t.record_stream(self.out_stream)
-                    active[j] = None
-                else:
-                    active[j][1] = k + 1
-            tick += 1
-        cur.wait_stream(self.out_stream)
-        return outs

@@ -77,7 +77,7 @@ def condense(pb: NrmpProblem):
 WARM_DELTA = 0.1        # QP_WARM_DELTA in nrmp_qp.hip
 
 
-def solve_condensed(pb: NrmpProblem, tol=1e-12, max_iter=40, trace=None, warm=None):
+def solve_condensed(pb: NrmpProblem, tol=1e-14, max_iter=40, trace=None, warm=None):
     """warm = (x, lc, lf) of a previous, similar solve: the kernel's warm start across the PAN
     iterations of one forward call (multipliers and slacks floored at WARM_DELTA)."""
     H, g, F, f, C, c, Phi, cv = condense(pb)

@@ -45,7 +45,9 @@ from .nrmp_qp import NrmpProblem, solve_nrmp_qp
 
 
 def backward_ipm(pb: NrmpProblem, gs, gu, gd, tol=1e-12):
-    """gs (3,T+1), gu (2,T), gd (1,T)|None: upstream gradients.  Returns dict q_s (3,), p_u, eta,
+    """(tol: the implicit gradient is taken at the interior-point iterate; at 1e-12 the barrier Newton matrix is still
+    well enough conditioned for it -- the forward solves stop at 1e-14, oracle/nrmp_qp.py.)
+    gs (3,T+1), gu (2,T), gd (1,T)|None: upstream gradients.  Returns dict q_s (3,), p_u, eta,
     d_max, d_min."""
     H, g, F, f, C, c, Phi, cv = condense(pb)
     T, nu = pb.T, 2 * pb.T

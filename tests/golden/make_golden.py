@@ -30,6 +30,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, HERE)
 
 from ref_stub_loader import import_reference, real_solver_stack_available  # noqa: E402
@@ -156,39 +157,7 @@ def pan_case(name, cfg, scene_idx, n_points, calls=1, **over):
     return pan
 
 
-def highs_solve(P, q, A, b, G, h):
-    """Solve min 1/2 z'Pz+q'z, Az=b, Gz<=h with HiGHS (scipy's bundled highspy core)."""
-    from scipy.optimize._highspy import _core as hc
-    from scipy.sparse import csc_matrix, tril
-    n = P.shape[0]
-    rows = np.vstack([A, G])
-    lo = np.concatenate([b, np.full(G.shape[0], -hc.kHighsInf)])
-    hi = np.concatenate([b, h])
-    H = hc._Highs()
-    H.setOptionValue("output_flag", False)
-    for opt, val in (("primal_feasibility_tolerance", 1e-10), ("dual_feasibility_tolerance", 1e-10)):
-        H.setOptionValue(opt, val)
-    lp = hc.HighsLp()
-    lp.num_col_, lp.num_row_ = n, rows.shape[0]
-    lp.col_cost_ = q
-    lp.col_lower_ = np.full(n, -hc.kHighsInf); lp.col_upper_ = np.full(n, hc.kHighsInf)
-    lp.row_lower_, lp.row_upper_ = lo, hi
-    Am = csc_matrix(rows)
-    lp.a_matrix_.format_ = hc.MatrixFormat.kColwise
-    lp.a_matrix_.num_col_, lp.a_matrix_.num_row_ = n, rows.shape[0]
-    lp.a_matrix_.start_, lp.a_matrix_.index_, lp.a_matrix_.value_ = Am.indptr, Am.indices, Am.data
-    hess = hc.HighsHessian()
-    Pl = csc_matrix(tril(csc_matrix(P)))
-    hess.dim_ = n
-    hess.format_ = hc.HessianFormat.kTriangular
-    hess.start_, hess.index_, hess.value_ = Pl.indptr, Pl.indices, Pl.data
-    model = hc.HighsModel()
-    model.lp_ = lp
-    model.hessian_ = hess
-    H.passModel(model)
-    H.run()
-    status = H.modelStatusToString(H.getModelStatus())
-    return np.array(H.getSolution().col_value), status
+from qp_highs import highs_solve  # noqa: E402  (tests/qp_highs.py)
 
 
 def qp_cases(problems):

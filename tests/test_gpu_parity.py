@@ -241,8 +241,8 @@ def test_dune_stage_full_size_deterministic_and_selects_nearest():
 
 
 def test_interleaved_batches_equal_sequential():
-    """forward_interleaved (several batches in flight, QP on helper streams) must give bitwise the
-    results of planning each batch on its own."""
+    """forward_interleaved (several batches in flight, one stream each) must give bitwise the results of planning
+    each batch on its own."""
     from gpu_helpers import make_gpu_pan
     from neupan_amd.pan import forward_interleaved
     cfg = CONFIGS["diff_1k_T10_K10"]
@@ -284,27 +284,6 @@ def test_other_baseline_configs_full_size(cfgname, scenes):
     assert checked >= 2
 
 
-def test_pipeline_schedule_equals_sequential():
-    """PanPipeline (staggered forward calls, staging on the helper stream, joins on an output stream) must
-    give bitwise the results of planning each batch on its own, including when a planner is reused."""
-    from gpu_helpers import make_gpu_pan
-    from neupan_amd.pan import PanPipeline
-    cfg = CONFIGS["diff_1k_T10_K10"]
-    B = 32
-    inputs = []
-    for j in range(7):
-        b = make_batch(cfg, 900 + j * B, B, 300)
-        inputs.append([b[k] for k in ("nom_s", "nom_u", "ref_s", "ref_us", "points")])
-    pipe = PanPipeline([make_gpu_pan(cfg, dune_max_num=300, iter_num=4) for _ in range(3)])
-    outs = pipe.run(inputs)
-    ref = make_gpu_pan(cfg, dune_max_num=300, iter_num=4)
-    for j in range(7):
-        ref.reset_stop_state()
-        o = ref.forward_batch(*inputs[j])
-        assert np.array_equal(o["opt_u"].cpu().numpy(), outs[j]["opt_u"].cpu().numpy()), j
-        assert np.array_equal(o["opt_s"].cpu().numpy(), outs[j]["opt_s"].cpu().numpy()), j
-
-
 def test_eight_edge_robot_parity():
     """BASELINE.json configs[4]: 8-vertex hull (E = 8 instantiations of the kernels).  The weights are
     the quick fit of tests/golden/make_poly8_checkpoint.py: parity is 'same weights, HIP vs oracle'."""
@@ -320,28 +299,6 @@ def test_eight_edge_robot_parity():
         errs.append(l2(u.cpu().numpy(), uo))
         assert pan.E == 8
     assert np.median(errs) <= 1e-5 and max(errs) <= 1e-4, errs
-
-
-def test_coalesced_batches_equal_sequential():
-    """forward_interleaved(coalesce=2): pairs of batches run as one forward call; every batch's result must be
-    bitwise what it is when planned alone (scenes are independent)."""
-    from gpu_helpers import make_gpu_pan
-    from neupan_amd.pan import forward_interleaved
-    cfg = CONFIGS["diff_1k_T10_K10"]
-    B = 40
-    inputs = []
-    for j in range(5):
-        b = make_batch(cfg, 1500 + j * B, B, 350)
-        inputs.append([b[k] for k in ("nom_s", "nom_u", "ref_s", "ref_us", "points")])
-    pans = [make_gpu_pan(cfg, dune_max_num=350, iter_num=3) for _ in range(5)]
-    outs = forward_interleaved(pans, inputs, coalesce=2, reset_state=True)
-    assert len(outs) == 5
-    ref = make_gpu_pan(cfg, dune_max_num=350, iter_num=3)
-    for j in range(5):
-        ref.reset_stop_state()
-        o = ref.forward_batch(*inputs[j])
-        assert np.array_equal(o["opt_u"].cpu().numpy(), outs[j]["opt_u"].cpu().numpy()), j
-        assert np.array_equal(o["min_distance"].cpu().numpy(), outs[j]["min_distance"].cpu().numpy()), j
 
 
 def _with_env(env, fn):
