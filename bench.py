@@ -26,6 +26,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# One HIP stream per batch in flight; every stream should own a hardware queue, or two batches serialise behind each
+# other.  The runtime's default is 4 queues; 32 covers the 16 batches in flight plus torch's own streams (sweep in
+# with fewer queues than streams the throughput falls to what that many concurrent chains give).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -53,15 +58,15 @@ def main():
     global BATCH
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--cpu-scenes", type=int, default=0,
                     help="scenes of the first batch planned by the CPU oracle + its ensemble (rank 0, N=1); 0 = 256 on a host "
                          "with >= 64 cores, else 96")
     ap.add_argument("--cpu-cores", type=int, default=0, help="worker processes of the CPU baseline (0 = all host cores)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-scene latency measurement")
-    ap.add_argument("--inflight", type=int, default=8, help="independent batches (steps) kept in flight, one stream each")
+    ap.add_argument("--inflight", type=int, default=16, help="independent batches (steps) kept in flight, one stream each")
     ap.add_argument("--workload", default=WORKLOAD,
                     choices=sorted(k for k in __import__("neupan_amd.scenes", fromlist=["CONFIGS"]).CONFIGS),
                     help="scene configuration (default: the one BASELINE.json's metric is quoted on)")
@@ -219,6 +224,7 @@ def main():
                                     f"T={T}, K={K} (iter_threshold=0), M={cfg.nrmp_max_num}, fp32 DUNE (MFMA) + fp64 QP",
                    "scenes_per_gpu": BATCH, "points": N, "T": T, "K": K, "M": cfg.nrmp_max_num,
                    "batches_in_flight": nfl, "schedule": "one HIP stream per batch in flight",
+                   "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                    "parallelism": f"scene-shard x{world}, RCCL all-gather of controls"
                                   + (" (process group initialised)" if dist is not None else "")},
         "roofline": roof,
@@ -246,7 +252,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from parity_tools import judge, run_ensemble
+        from parity_tools import gpu_last_qp_certificates, judge, run_ensemble
         host = os.cpu_count() or 1
         n_sc = args.cpu_scenes if args.cpu_scenes > 0 else (BATCH if host >= 64 else min(96, BATCH))
         n_sc = min(n_sc, BATCH)
@@ -268,6 +274,12 @@ def main():
                        "spread of the final controls <= 1e-4.  A: HIP <= 1e-4 on every well-posed scene; B: HIP inside the ensemble "
                        "spread elsewhere; C: HIP <= 1e-5 at every iteration before the ensemble itself first disagrees by > 1e-5 "
                        "(tests/parity_tools.py, DESIGN.md section 5)")
+        # the kernel's own last QP, per scene: rebuilt on the host from the parameters the kernel built, fp64 solution certified
+        batch0 = make_batch(cfg, rank * nfl * BATCH, BATCH)
+        rep["gpu_last_qp"] = dict(gpu_last_qp_certificates(pans[0], cfg, batch0),
+                                  note="KKT certificate (NNLS stationarity, complementarity, feasibility) of the kernel's fp64 "
+                                       "solution of its last QP and objective gap to the oracle's solve of the same problem, "
+                                       "all scenes of the batch; stat_oracle = the same certificate on the oracle's solutions")
         line["parity"] = rep
     if rank == 0:
         print(json.dumps(line), flush=True)

@@ -149,7 +149,9 @@ int npa_forward_end(npa_handle *h);
  *   dist_sorted [B][T+1][M], count [B][T+1] (= min(N,M); rows >= count replicate row 0).
  * npa_nrmp_stage  = generate_state_parameter_value + generate_coefficient_parameter_value
  *   + the QP solve, from those arrays; writes s,u,d plus qp_info [B][16] doubles
- *   (best iteration, final merit, mu, status, iterations run; rest reserved for profiling builds). */
+ *   (best iteration, final merit, mu, status, iterations run; rest reserved for profiling builds), and, when x64 is
+ *   not NULL, the fp64 solution before the cast to fp32 (nrmp.py:145-148): x64 [B][3T] = u_0x, u_0y, ..., u_(T-1)y,
+ *   d_0..d_(T-1) -- what an optimality certificate should be computed on. */
 int npa_dune_stage(npa_handle *h, int batch, int n_stride, const float *nom_s,
                    const float *points, const float *velocities, const int32_t *n_points,
                    float *mu_sorted, float *lam_sorted, float *pts_sorted, float *dist_sorted,
@@ -157,7 +159,7 @@ int npa_dune_stage(npa_handle *h, int batch, int n_stride, const float *nom_s,
 int npa_nrmp_stage(npa_handle *h, int batch, const float *nom_s, const float *nom_u,
                    const float *ref_s, const float *ref_us, const float *mu_sorted,
                    const float *lam_sorted, const float *pts_sorted, const int32_t *count,
-                   float *out_s, float *out_u, float *out_d, double *qp_info, void *stream);
+                   float *out_s, float *out_u, float *out_d, double *qp_info, double *x64, void *stream);
 
 /* npa_nrmp_params = the parameter build of npa_nrmp_stage alone, for parity tests: what generate_state_parameter_value
  * (robot.py:239-316: A_t, B_t, C_t of the linearised model) and generate_coefficient_parameter_value (nrmp.py:220-261:

@@ -48,7 +48,7 @@ SYMBOLS = {
     "npa_forward_iter": (_I, [_P, _I]),
     "npa_forward_end": (_I, [_P]),
     "npa_dune_stage": (_I, [_P, _I, _I] + [_P] * 9 + [_P]),
-    "npa_nrmp_stage": (_I, [_P, _I] + [_P] * 12 + [_P]),
+    "npa_nrmp_stage": (_I, [_P, _I] + [_P] * 13 + [_P]),
     "npa_nrmp_params": (_I, [_P, _I] + [_P] * 8 + [_P]),
     "npa_nrmp_backward": (_I, [_P, _I] + [_P] * 17 + [_P]),
     "npa_nominal_ref_states": (_I, [_I, _I, _I, C.c_double, C.c_double] + [_P] * 12 + [_P]),

@@ -33,8 +33,8 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
                                     const int* count, float* cur_s_out, float* cur_u_out, float* cur_d_out,
                                     float* out_s, float* out_u, float* out_d, float* out_min_distance,
                                     int* out_iters, float* out_nrmp_points, int* flags, float* state,
-                                    double* qp_info, float* trig_out, float* dbg_abc, float* dbg_f, hipStream_t stream,
-                                    hipEvent_t ev_start, hipEvent_t ev_stop);
+                                    double* qp_info, float* trig_out, float* dbg_abc, float* dbg_f, double* dbg_x,
+                                    hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);
 extern "C" size_t npa_qp_shmem_bytes(int T, int M);
 extern "C" hipError_t npa_launch_nominal(int batch, int T, int kin, double dt, double L, const double* state,
                                          const float* vel, const double* ref_speed, const double* path,
@@ -503,14 +503,14 @@ extern "C" int npa_dune_stage(npa_handle* h, int batch, int n_stride, const floa
 extern "C" int npa_nrmp_stage(npa_handle* h, int batch, const float* nom_s, const float* nom_u, const float* ref_s,
                               const float* ref_us, const float* mu_sorted, const float* lam_sorted,
                               const float* pts_sorted, const int32_t* count, float* out_s, float* out_u,
-                              float* out_d, double* qp_info, void* stream) {
+                              float* out_d, double* qp_info, double* x64, void* stream) {
   if (!h || batch < 1 || !nom_s || !nom_u || !ref_s || !ref_us || !out_s || !out_u)
     return fail(NPA_E_ARG, "npa_nrmp_stage: bad argument");
   if (h->P.M > 0 && (!mu_sorted || !lam_sorted || !pts_sorted || !count || !out_d))
     return fail(NPA_E_ARG, "npa_nrmp_stage: obstacle arrays required when nrmp_max_num > 0");
   HIP_TRY(npa_launch_qp(h->P, batch, 0, nom_s, nom_u, ref_s, ref_us, mu_sorted, lam_sorted, pts_sorted, nullptr, count,
                         out_s, out_u, out_d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                        qp_info, nullptr, nullptr, nullptr, (hipStream_t)stream, nullptr, nullptr));
+                        qp_info, nullptr, nullptr, nullptr, x64, (hipStream_t)stream, nullptr, nullptr));
   return NPA_OK;
 }
 
@@ -523,7 +523,7 @@ extern "C" int npa_nrmp_params(npa_handle* h, int batch, const float* nom_s, con
   // (the reference trajectory only enters the cost: the nominal arrays stand in for it, the kernel returns before the solve)
   HIP_TRY(npa_launch_qp(h->P, batch, 0, nom_s, nom_u, nom_s, nom_u, mu_sorted, lam_sorted, pts_sorted, nullptr, count,
                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                        nullptr, nullptr, out_abc, h->P.M > 0 ? out_f : nullptr, (hipStream_t)stream, nullptr, nullptr));
+                        nullptr, nullptr, out_abc, h->P.M > 0 ? out_f : nullptr, nullptr, (hipStream_t)stream, nullptr, nullptr));
   return NPA_OK;
 }
 
@@ -704,7 +704,7 @@ extern "C" int npa_forward_iter(npa_handle* h, int k) {
   EventPair* ev = next_event(h, h->ev_qp, h->n_qp);
   HIP_TRY(npa_launch_qp(P, batch, 0, cur_s, cur_u, pc->ref_s, pc->ref_us, mu, lam, pts, dist, count, cur_s, cur_u,
                         cur_d, pc->out_s, pc->out_u, pc->out_d, pc->out_md, pc->out_iters, pc->out_np, flags,
-                        pc->state, qp_info, pc->dune ? ws + L.trig : nullptr, nullptr, nullptr, stream,
+                        pc->state, qp_info, pc->dune ? ws + L.trig : nullptr, nullptr, nullptr, nullptr, stream,
                         ev ? ev->a : nullptr, ev ? ev->b : nullptr));
   if (h->key_auto && pc->dune && k == P.K - 1)
     HIP_TRY(hipMemcpyAsync(h->sel_stats_host, h->sel_stats_dev, sizeof(unsigned), hipMemcpyDeviceToHost, stream));

@@ -113,6 +113,7 @@ struct QpBackward {
   // reference holds them -- and returns before the solve
   float* dbg_abc;
   float* dbg_f;
+  double* dbg_x;            // [B][2T + T]: the fp64 solution (u_0x, u_0y, ..., then d) before the cast to fp32, or null
 };
 
 template <int TT, int MM, bool BWD = false>
@@ -849,6 +850,8 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
   }
   LSYNC();
 
+  if (bw.dbg_x)
+    for (int a = lane; a < nu + T; a += QP_THREADS) bw.dbg_x[(size_t)b * (nu + T) + a] = (a < nu || obs) ? xbest[a] : 0.0;
   // ---- write the solution (fp64 -> fp32, nrmp.py:145-148) ------------------------------------
   float* so = cur_s_out + (size_t)b * 3 * (T + 1);
   float* uo = cur_u_out + (size_t)b * 2 * T;
@@ -990,6 +993,7 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
                                     float* cur_d_out, float* out_s, float* out_u, float* out_d,
                                     float* out_min_distance, int* out_iters, float* out_nrmp_points, int* flags,
                                     float* state, double* qp_info, float* trig_out, float* dbg_abc, float* dbg_f,
+                                    double* dbg_x,
                                     hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
   static const bool force_generic = getenv("NPA_QP_GENERIC") != nullptr;     // tests: the generic (LDS) instantiation for every (T, M)
   const bool low_prio = false;
@@ -1015,7 +1019,7 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
                         P, cur_s_in, cur_u_in, ref_s, ref_us, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count,  \
                         cur_s_out, cur_u_out, cur_d_out, out_s, out_u, out_d, out_min_distance, out_iters,            \
                         out_nrmp_points, flags, state, qp_info, scene0, batch, wave_doubles,                         \
-                        low_prio ? -wpg : wpg, QpBackward{nullptr, nullptr, nullptr, nullptr, nullptr, dbg_abc, dbg_f}, trig_out)
+                        low_prio ? -wpg : wpg, QpBackward{nullptr, nullptr, nullptr, nullptr, nullptr, dbg_abc, dbg_f, dbg_x}, trig_out)
   if (P.T == 10 && P.M == 10 && !force_generic) QP_LAUNCH(10, 10);
   else if (P.T == 20 && P.M == 10 && !force_generic) QP_LAUNCH(20, 10);
   else QP_LAUNCH(0, 0);
@@ -1040,6 +1044,6 @@ extern "C" hipError_t npa_launch_qp_backward(const DevParams& P, int batch, cons
                      ref_us, mu_sorted, lam_sorted, pts_sorted, (const float*)nullptr, count, out_s, out_u, out_d,
                      (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int*)nullptr, (float*)nullptr,
                      (int*)nullptr, (float*)nullptr, qp_info, 0, batch,
-                     (int)(wave_bytes / sizeof(double)), 1, QpBackward{grad_s, grad_u, grad_d, grad_theta, grad_nom_s, nullptr, nullptr}, (float*)nullptr);
+                     (int)(wave_bytes / sizeof(double)), 1, QpBackward{grad_s, grad_u, grad_d, grad_theta, grad_nom_s, nullptr, nullptr, nullptr}, (float*)nullptr);
   return hipGetLastError();
 }

@@ -94,7 +94,7 @@ class DuneTrain:
                 f"valid_freq: {valid_freq}, save_freq: {save_freq}, lr: {lr}, lr_decay: {lr_decay}, decay_freq: {decay_freq}, "
                 f"robot_G: {self.G.cpu()}, robot_h: {self.h.cpu()}")
         with open(log, "a") as f:
-            print(head + "\\n", file=f)
+            print(head + "\n", file=f)
         with open(os.path.join(self.checkpoint_path, "train_dict.pkl"), "wb") as f:
             pickle.dump(dict(data_size=data_size, data_range=list(data_range), batch_size=batch_size, epoch=epoch,
                              valid_freq=valid_freq, save_freq=save_freq, lr=lr, lr_decay=lr_decay, decay_freq=decay_freq), f)
@@ -112,12 +112,12 @@ class DuneTrain:
                 self.model.eval()
                 vml, vdl, val, vbl = self._epoch(valid, batch_size, True)
                 with open(log, "a") as f:
-                    print(f"Epoch {i}/{epoch} learning rate {self.optimizer.param_groups[0]['lr']} \\n"
-                          "---------------------------------\\nLosses:\\n"
-                          f"  Mu Loss:          {ml:.2e}   | Validate Mu Loss:            {vml:.2e}\\n"
-                          f"  Distance Loss:    {dl:.2e}   | Validate Distance Loss:      {vdl:.2e}\\n"
-                          f"  Fa Loss:          {al:.2e}   | Validate Fa Loss:            {val:.2e}\\n"
-                          f"  Fb Loss:          {bl:.2e}   | Validate Fb Loss:            {vbl:.2e}\\n", file=f)
+                    print(f"Epoch {i}/{epoch} learning rate {self.optimizer.param_groups[0]['lr']} \n"
+                          "---------------------------------\nLosses:\n"
+                          f"  Mu Loss:          {ml:.2e}   | Validate Mu Loss:            {vml:.2e}\n"
+                          f"  Distance Loss:    {dl:.2e}   | Validate Distance Loss:      {vdl:.2e}\n"
+                          f"  Fa Loss:          {al:.2e}   | Validate Fa Loss:            {val:.2e}\n"
+                          f"  Fb Loss:          {bl:.2e}   | Validate Fb Loss:            {vbl:.2e}\n", file=f)
             if i % save_freq == 0:
                 full = os.path.join(self.checkpoint_path, f"model_{i}.pth")
                 torch.save({k: v.detach().cpu() for k, v in self.model.state_dict().items()}, full)

@@ -112,7 +112,9 @@ class FleetPlanner:
         warm = opt_u.detach()
         self.cur_vel = warm if self.cur_vel is None else torch.where(done[:, None, None], self.cur_vel, warm)
         # 5. stop test and action
-        md = out["min_distance"]
+        md = self.pan.current_min_distance()          # keeps the last value over cycles without points (dune.py:97-98)
+        if md is None:
+            md = out["min_distance"]
         stop = md < self.collision_threshold
         act = opt_u[:, :, 0]
         if self.robot.kinematics == "omni":

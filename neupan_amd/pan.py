@@ -113,7 +113,8 @@ class _DuneFacade:
         pan = self._pan
         name = kw.pop("model_name", getattr(pan.robot, "name", None) or "robot")
         kw.pop("direct_train", None)
-        path = os.path.join(sys.path[0] or os.getcwd(), "model", name)
+        # dune_train.py:66-69 writes to <script dir>/model/<name>; `save_dir` (ours) overrides the root
+        path = os.path.join(kw.pop("save_dir", None) or sys.path[0] or os.getcwd(), "model", name)
         tr = DuneTrain(None, np.asarray(pan.robot.G, dtype=np.float32), np.asarray(pan.robot.h, dtype=np.float32), path,
                        device=pan.device)
         self.full_model_name = tr.start(**kw)
@@ -175,6 +176,19 @@ class PAN(torch.nn.Module):
         self._fill_adjust(cfg)
 
         wts = None
+        self._untrained = False
+        train_kwargs = dict(train_kwargs or {})
+        if not self.no_obs and dune_checkpoint in (None, "None") and train_kwargs.get("direct_train", False):
+            # the reference's training workflow (example/dune_train/*.yaml: no checkpoint, train.direct_train: true;
+            # dune.py:152-156 constructs the planner and then trains): no obstacle stage exists until train_dune() has
+            # produced a checkpoint and a planner is constructed with it -- forward raises until then
+            self._untrained = True
+            self.dune_layer = _DuneFacade(None, self)
+            self._h = C.c_void_p()
+            self._B = 0
+            self._ws = self._state = self._last = None
+            self.printed = False
+            return
         if not self.no_obs:
             path = _resolve_checkpoint(dune_checkpoint)
             sd = torch.load(path, map_location="cpu")                    # dune.py:142
@@ -259,6 +273,9 @@ class PAN(torch.nn.Module):
     def forward_begin(self, nom_s, nom_u, ref_s, ref_us, points=None, velocities=None, n_points=None, reset_state=False):
         """Stage one batch (see forward_batch for shapes) and start a forward on the current stream: follow with
         forward_iter(k) for k in range(iter_num) and forward_end()."""
+        if self._untrained:
+            raise NeupanAmdError("this planner was constructed without a DUNE checkpoint (train.direct_train): call "
+                                 "dune_layer.train_dune(...) and construct a planner with dune_checkpoint=<the file it returns>")
         T, M = self.T, self.nrmp_max_num
         nom_s = self._dev(nom_s)
         B = nom_s.shape[0]
@@ -300,8 +317,13 @@ class PAN(torch.nn.Module):
                 _ptr(out_np), _ptr(ws), ws.numel(), _ptr(state), state.numel(), C.c_void_p(stream),
                 2 if reset_state else 0), "npa_forward_begin")
         # keep inputs alive until the stream has consumed them
+        # DUNE.min_distance keeps its last value over calls without points (dune.py:97-98 runs only with points;
+        # pan.py:246-252 reads the attribute): remember the last distances that came from points
+        prev = self._last["md_keep"] if self._last is not None and self._last.get("md_keep") is not None and \
+            self._last["md_keep"].shape[0] == B else None
         self._last = dict(points=points, velocities=velocities, n_points=n_points, min_distance=out_md,
-                          nrmp_points=out_np, used_points=use_pts, hold=(nom_s, nom_u, ref_s, ref_us))
+                          nrmp_points=out_np, used_points=use_pts, hold=(nom_s, nom_u, ref_s, ref_us), md_prev=prev,
+                          md_keep=None)
         self._pending = dict(opt_s=out_s, opt_u=out_u, opt_d=out_d, min_distance=out_md, iters=out_it, nrmp_points=out_np)
 
     def forward_iter(self, k):
@@ -356,11 +378,26 @@ class PAN(torch.nn.Module):
         return out["opt_s"][0], out["opt_u"][0], d
 
     # ------------------------------------------------------------------ attributes of the reference class
+    def current_min_distance(self):
+        """(B,) tensor: DUNE.min_distance per scene with the reference's persistence -- a scene without points in the
+        last call keeps the value of its last call WITH points (dune.py:97-98), +inf if there never was one."""
+        if self.no_obs or self._last is None:
+            return None
+        L = self._last
+        if L["md_keep"] is None:
+            md, prev = L["min_distance"], L["md_prev"]
+            if not L["used_points"]:
+                md = prev if prev is not None else torch.full_like(md, inf)
+            elif prev is not None:
+                md = torch.where(torch.isinf(md), prev, md)          # scenes with n_points == 0 this call
+            L["md_keep"] = md
+        return L["md_keep"]
+
     @property
     def min_distance(self):
-        if self.no_obs or self._last is None or not self._last["used_points"]:
+        md = self.current_min_distance()
+        if md is None:
             return inf
-        md = self._last["min_distance"]
         return md[0] if md.shape[0] == 1 else md
 
     @property
@@ -417,14 +454,15 @@ class PAN(torch.nn.Module):
         out_u = torch.empty((B, 2, T), dtype=torch.float32, device=dev)
         out_d = torch.empty((B, 1, T), dtype=torch.float32, device=dev)
         info = torch.zeros((B, 16), dtype=torch.float64, device=dev)
+        x64 = torch.zeros((B, 3 * T), dtype=torch.float64, device=dev)
         g = (lambda k: _ptr(stage[k])) if stage is not None else (lambda k: None)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             check(self._lib.npa_nrmp_stage(self._h, B, _ptr(nom_s), _ptr(nom_u), _ptr(ref_s), _ptr(ref_us), g("mu"),
                                            g("lam"), g("pts"), g("count"), _ptr(out_s), _ptr(out_u), _ptr(out_d),
-                                           _ptr(info), C.c_void_p(stream)), "npa_nrmp_stage")
+                                           _ptr(info), _ptr(x64), C.c_void_p(stream)), "npa_nrmp_stage")
         torch.cuda.synchronize(dev)
-        return dict(opt_s=out_s, opt_u=out_u, opt_d=out_d, info=info)
+        return dict(opt_s=out_s, opt_u=out_u, opt_d=out_d, info=info, x64=x64)
 
     def nrmp_params(self, nom_s, nom_u, stage=None):
         """The parameters the NRMP kernel builds before it solves (npa_nrmp_params): dict(A (B,T,3,3), B (B,T,3,2),

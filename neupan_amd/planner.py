@@ -160,12 +160,14 @@ class neupan(torch.nn.Module):
 
     def set_initial_path(self, path):
         """neupan.py:296-303 / initial_path.py:128-142: path = list of (4,1) x, y, theta, gear."""
+        self._generated = False
         self._install(path)
 
     def _path_from(self, waypoints):
         path = generate_curve(self.curve_style, waypoints, self.interval, self.min_radius)
         if self.curve_style == "line":
             _consistent_angles(path)
+        self._generated = True
         self._install(path)
         self.fleet.intervals = [self.interval]             # a generated path keeps the configured interval
         self.fleet._upload()
@@ -202,6 +204,11 @@ class neupan(torch.nn.Module):
         self.cur_vel_array = np.zeros_like(self.cur_vel_array)
         if self.initial_path_ is not None:
             self._install(self.initial_path_)
+            if getattr(self, "_generated", False):
+                # only set_initial_path averages the interval (initial_path.py:138); a path generated from waypoints keeps
+                # the configured one across reset(), as the reference's InitialPath does
+                self.fleet.intervals = [self.interval]
+                self.fleet._upload()
 
     def train_dune(self):
         self.pan.dune_layer.train_dune(self.dune_train_kwargs)

@@ -57,7 +57,8 @@ def step(kin, L, state, action):
 
 
 def run(name, path, state0, points, cycles, iter_num=2, dune_max_num=100, iter_threshold=0.1, velocities=None, robot=None,
-        ckpt="diff_robot_default"):
+        ckpt="diff_robot_default", points_until=None):
+    """points_until: the cloud is delivered only in the first `points_until` cycles, None afterwards."""
     robot = dict(robot or ROBOT)
     p = build(iter_num, dune_max_num, iter_threshold, robot=robot, ckpt=ckpt)
     p.set_initial_path([q.copy() for q in path])
@@ -66,6 +67,8 @@ def run(name, path, state0, points, cycles, iter_num=2, dune_max_num=100, iter_t
     for c in range(cycles):
         rec["states"].append(state[:, 0].copy())
         pts_c = None if points is None else (points if velocities is None else points + c * 0.1 * velocities)
+        if points_until is not None and c >= points_until:
+            pts_c = None
         action, info = p(state.copy(), None if pts_c is None else pts_c.copy(), velocities)
         rec["actions"].append(np.asarray(action, dtype=np.float64).reshape(2))
         rec["arrive"].append(bool(info["arrive"])); rec["stop"].append(bool(info["stop"]))
@@ -78,7 +81,7 @@ def run(name, path, state0, points, cycles, iter_num=2, dune_max_num=100, iter_t
     out = {k: np.array(v) for k, v in rec.items()}
     out["path"] = np.hstack(path).T
     out["points"] = np.zeros((2, 0)) if points is None else points
-    out["meta"] = np.array([iter_num, dune_max_num, iter_threshold], dtype=np.float64)
+    out["meta"] = np.array([iter_num, dune_max_num, iter_threshold, cycles if points_until is None else points_until], dtype=np.float64)
     out["velocities"] = np.zeros((2, 0)) if velocities is None else velocities
     import json
     out["robot"] = np.array(json.dumps(robot)); out["ckpt"] = np.array(ckpt)
@@ -101,6 +104,8 @@ if __name__ == "__main__":
     # an obstacle inside the collision threshold: stop flag
     close = np.concatenate([np.array([[0.83], [0.0]]), walls[:, 3:60]], axis=1)
     run("stop", line(40, 0.4), [0.0, 0.0, 0.0], close, 3)
+    # ... and then the cloud disappears: DUNE.min_distance keeps its last value (dune.py:97-98), the robot stays stopped
+    run("stop_then_empty", line(40, 0.4), [0.0, 0.0, 0.0], close, 4, points_until=2)
     # no obstacle points at all
     run("no_points", line(40, 0.4), [0.0, 0.3, 0.1], None, 3)
     # car-like robot backing up along a reverse-gear path

@@ -54,3 +54,32 @@ def test_two_rank_gather_is_in_scene_order(total):
         assert p.exitcode == 0
     for r in range(2):
         assert got[r] == [float(i) for i in range(total)]
+
+
+@pytest.mark.gpu
+def test_rccl_all_gather_branch_on_one_gpu():
+    """The production branch of gather_controls -- one flat all_gather_into_tensor over RCCL (backend "nccl") -- on the
+    GPU at hand: a process group of ONE rank still goes through the collective (bench.py does the same when it is
+    launched under torch.distributed.run with one process).  Ragged shards take the padded branch."""
+    import torch.distributed as dist
+    from neupan_amd.dist import gather_controls
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        assert dist.get_backend() == "nccl"
+        u = torch.arange(256 * 2 * 10, dtype=torch.float32, device=dev).reshape(256, 2, 10)
+        calls = []
+        orig = dist.all_gather_into_tensor
+        dist.all_gather_into_tensor = lambda out, inp, *a, **k: (calls.append(tuple(inp.shape)), orig(out, inp, *a, **k))[1]
+        try:
+            g = gather_controls(u, dist, 1, equal_shards=True)
+            g2 = gather_controls(u, dist, 1, equal_shards=False)
+        finally:
+            dist.all_gather_into_tensor = orig
+        torch.cuda.synchronize()
+        assert len(calls) == 2 and calls[0] == (256, 2, 10)
+        assert g.data_ptr() != u.data_ptr() and torch.equal(g, u) and torch.equal(g2, u)
+    finally:
+        dist.destroy_process_group()

@@ -55,3 +55,30 @@ def test_short_training_run_on_hip_labels():
     from gpu_helpers import make_gpu_pan
     pan = make_gpu_pan(CONFIGS["corridor_diff_small"], checkpoint=full, iter_num=1)
     assert pan.E == 4
+
+
+@pytest.mark.gpu
+def test_training_workflow_without_checkpoint(tmp_path):
+    """The reference's training workflow (example/dune_train/dune_train_diff.yaml: robot + train sections only, no
+    dune_checkpoint, train.direct_train: true; dune.py:152-156 builds the planner, then trains): init_from_yaml must
+    construct a planner, train_dune() must run and return a checkpoint in the reference's format, planning before that
+    must raise (the reference blocks on input()), and a planner built with the new checkpoint must plan."""
+    from neupan_amd._lib import NeupanAmdError
+    from neupan_amd.planner import neupan
+    y = tmp_path / "dune_train_diff.yaml"
+    y.write_text("robot:\n  kinematics: 'diff'\n  length: 1.6\n  width: 2.0\n\ntrain:\n  direct_train: true\n  data_size: 4000\n"
+                 "  data_range: [-25, -25, 25, 25]\n  batch_size: 256\n  epoch: 6\n  valid_freq: 3\n  save_freq: 6\n  lr: 5e-3\n"
+                 f"  lr_decay: 0.5\n  decay_freq: 1500\n  save_dir: '{tmp_path}'\n")
+    planner = neupan.init_from_yaml(str(y))
+    with pytest.raises(NeupanAmdError):
+        planner.pan.forward_batch(np.zeros((1, 3, 11), np.float32), np.zeros((1, 2, 10), np.float32), np.zeros((1, 3, 11), np.float32),
+                                  np.zeros((1, 10), np.float32), np.ones((1, 2, 5), np.float32))
+    planner.train_dune()
+    full = planner.pan.dune_layer.full_model_name
+    assert full.endswith("model_6.pth") and os.path.exists(full)
+    log = open(os.path.join(os.path.dirname(full), "results.txt")).read()
+    assert "Validate Mu Loss" in log and "\\n" not in log and log.count("\n") > 10          # real newlines in the log
+    from gpu_helpers import make_gpu_pan
+    from helpers import CONFIGS
+    pan = make_gpu_pan(CONFIGS["corridor_diff_small"], checkpoint=full, iter_num=1)
+    assert pan.E == 4

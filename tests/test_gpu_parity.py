@@ -149,29 +149,108 @@ def test_pan_forward_vs_reference_vectors(case, cfgname, over):
             assert pan.min_distance == float("inf")
 
 
-def test_config2_parity_distribution():
-    """BASELINE.json configs[1] sizes (diff, N=1000, T=10, K=10) on 24 scenes: control L2 of
-    the HIP path vs the oracle.  The PAN loop is a fixed-point iteration whose map is not a
-    contraction on every scene, so the bar is on the distribution:
-    median <= 1e-5, >= 85 % of scenes <= 1e-4 (the north-star tolerance)."""
-    from gpu_helpers import l2, make_gpu_pan
-    cfg = CONFIGS["diff_1k_T10_K10"]
-    B = 24
+def _ensemble_verdict(cfgname, scenes):
+    """HIP per-iteration controls of `scenes` scenes against the oracle and its ensemble (tests/parity_tools.py)."""
+    import os
+    from gpu_helpers import make_gpu_pan
+    from parity_tools import judge, run_ensemble
+    cfg = CONFIGS[cfgname]
     pan = make_gpu_pan(cfg)
-    batch = make_batch(cfg, 0, B)
-    out = pan.forward_batch(batch["nom_s"], batch["nom_u"], batch["ref_s"], batch["ref_us"], batch["points"])
-    u_gpu = out["opt_u"].cpu().numpy()
+    batch = make_batch(cfg, 0, scenes)
+    out = pan.forward_batch_trace(batch["nom_s"], batch["nom_u"], batch["ref_s"], batch["ref_us"], batch["points"],
+                                  batch["velocities"])
     assert (out["iters"].cpu().numpy() == cfg.iter_num).all()
-    errs = []
-    for b in range(B):
-        orc = make_oracle(cfg)
-        s, u, d = orc.forward(batch["nom_s"][b], batch["nom_u"][b], batch["ref_s"][b], batch["ref_us"][b], batch["points"][b])
-        errs.append(l2(u_gpu[b], u))
-    errs = np.array(errs)
-    print("control L2 vs oracle: median %.2e p90 %.2e max %.2e frac<=1e-4 %.2f" %
-          (np.median(errs), np.quantile(errs, 0.9), errs.max(), (errs <= 1e-4).mean()))
-    assert np.median(errs) <= 1e-5
-    assert (errs <= 1e-4).mean() >= 0.85
+    base, members, _, _ = run_ensemble(cfgname, range(scenes), os.cpu_count() or 1)
+    rep, hip, sp = judge(out["trace_u"].cpu().numpy(), base, members)
+    print({k: v for k, v in rep.items() if k != "worst_scenes"})
+    return rep
+
+
+def test_config2_parity_distribution():
+    """BASELINE.json configs[1] (diff, N=1000, T=10, K=10): control L2 of the HIP path vs the oracle, judged against an
+    ensemble of 12 equally valid evaluations of the reference algorithm per scene (inputs moved by +-1 ulp, hidden
+    units permuted).  The PAN loop is a fixed-point iteration that does not contract on every scene (DESIGN.md
+    section 5), so the bar is: A. every scene whose ensemble agrees to 1e-4 (the north-star tolerance) -- HIP <= 1e-4;
+    B. every other scene -- HIP inside the ensemble's own spread; C. at every iteration before the ensemble first
+    disagrees by > 1e-5 -- HIP <= 1e-5."""
+    rep = _ensemble_verdict("diff_1k_T10_K10", 48)
+    assert rep["A_well_posed_all_le_tol"] and rep["B_others_inside_envelope"] and rep["C_le_1e-5_until_ensemble_diverges"], rep
+    assert rep["ctrl_l2_vs_oracle_median"] <= 1e-5 and rep["scenes_well_posed"] >= 40, rep
+
+
+@pytest.mark.parametrize("cfgname,scenes", [("acker_2k_T20_K15", 24), ("dyna_4k_T10_K10", 24), ("poly8_5k_T10_K10", 16)])
+def test_other_baseline_configs_parity_distribution(cfgname, scenes):
+    """BASELINE.json configs[2] (acker, 2000 pts, T=20, K=15), configs[3] (4000 moving points) and the configs[4]
+    stand-in (8-vertex hull, 5000 pts) at full size: the same three verdicts.  Acker: the first QP of some scenes has
+    steering directions so flat that two fp64 solvers stop 1e-5 .. 7e-5 apart at their own noise floor (merit ~1e-12;
+    DESIGN.md section 5) -- there C is held to the north-star 1e-4 instead of 1e-5."""
+    rep = _ensemble_verdict(cfgname, scenes)
+    assert rep["A_well_posed_all_le_tol"] and rep["B_others_inside_envelope"], rep
+    if cfgname.startswith("acker"):
+        assert rep["max_hip_before_divergence"] <= 1e-4, rep
+    else:
+        assert rep["C_le_1e-5_until_ensemble_diverges"], rep
+    assert rep["ctrl_l2_vs_oracle_median"] <= 1e-5, rep
+
+
+@pytest.mark.parametrize("cfgname,B", [("diff_1k_T10_K10", 256), ("acker_2k_T20_K15", 48)])
+def test_gpu_last_qp_is_certified_optimal(cfgname, B):
+    """The last QP of a forward call at benchmark size, per scene: rebuilt on the host from the parameters the KERNEL
+    built (npa_nrmp_params), the kernel's fp64 solution passes the independent KKT certificate, and its objective is
+    within 1e-9 (relative) of the oracle's solution of the same problem.  The stage re-run is tied bitwise to the
+    forward call's result.  (ECOS is absent: for a strictly convex QP the certified point is the answer it approximates.)"""
+    from gpu_helpers import make_gpu_pan
+    from parity_tools import gpu_last_qp_certificates
+    cfg = CONFIGS[cfgname]
+    pan = make_gpu_pan(cfg)
+    r = gpu_last_qp_certificates(pan, cfg, make_batch(cfg, 0, B))
+    print(r)
+    assert r["tied_to_forward_bitwise"] and r["scenes"] == B
+    # feasible to rounding, complementary, and -- the sharp statement -- the objective of the kernel's feasible point is
+    # within 1e-9 (relative; measured 1e-13) of the oracle's optimum of the same problem.  The NNLS stationarity residual
+    # is reported next to the oracle's own on the same problems (1.4e-5 vs 1.5e-4 at config 2: it is limited by the
+    # certificate's active-set guess on weakly active rows, not by either solver)
+    assert r["feas"] <= 1e-9 and r["comp"] <= 1e-7 and r["stat"] <= max(1e-5, 2 * r["stat_oracle"]), r
+    assert r["obj_gap_rel"] <= 1e-9, r
+
+
+STAGE_PARAMS = [("diff_n1000", "diff_1k_T10_K10", None), ("acker_n200", "acker_2k_T20_K15", None),
+                ("dyna_n300", "dyna_4k_T10_K10", None), ("omni_n64", "diff_1k_T10_K10", OMNI),
+                ("polygon_n150", "diff_1k_T10_K10", POLY), ("diff_n7", "diff_1k_T10_K10", None)]
+
+
+@pytest.mark.parametrize("case,cfgname,robot_kw", STAGE_PARAMS)
+def test_nrmp_parameters_vs_reference_vectors(case, cfgname, robot_kw):
+    """What the NRMP kernel hands to its solver, exported through npa_nrmp_params, against the tensors the REFERENCE
+    built (generate_state_parameter_value robot.py:239-316, generate_coefficient_parameter_value nrmp.py:220-261;
+    tests/golden/stage_*.npz), the kernel being fed the reference's own sorted DUNE rows: A, B, C and fa bit-exact
+    (the kernel mirrors the reference's fp32 rounding sequence), fb within 2 ulp (bmm + matmul summation order)."""
+    import torch
+    from gpu_helpers import make_gpu_pan
+    g = golden("stage_" + case)
+    cfg = CONFIGS[cfgname]
+    T = g["A"].shape[0]
+    M = int(g["nrmp_max_num"])
+    pan = make_gpu_pan(cfg, robot_kw=robot_kw, receding=T, dune_max_num=int(g["dune_max_num"]))
+    n = g["mu"].shape[2]
+    k = min(M, n)
+
+    def rows(a):                                  # (T+1, C, N) -> (1, T+1, M, C) with the padding rule of nrmp.py:258-259
+        r = np.transpose(a[:, :, :k], (0, 2, 1))
+        if k < M:
+            r = np.concatenate([r, np.repeat(r[:, :1], M - k, axis=1)], axis=1)
+        return torch.tensor(np.ascontiguousarray(r[None])).cuda()
+    stage = dict(mu=rows(g["mu"]), lam=rows(g["lam"]), pts=rows(g["sorted_pts"]),
+                 count=torch.full((1, T + 1), k, dtype=torch.int32).cuda())
+    par = pan.nrmp_params(g["nom_s"][None], g["nom_u"][None], stage)
+    assert np.array_equal(par["A"][0], g["A"]) and np.array_equal(par["B"][0], g["B"]) and np.array_equal(par["C"][0], g["C"])
+    assert np.array_equal(par["fa"][0], g["fa"])
+    # fb = lam' p + mu' h: two ulp of the largest term (the terms cancel, the reference's bmm + matmul sum in another order)
+    fb, ref = par["fb"][0], g["fb"]
+    lam_r, pts_r, mu_r = (stage[k].cpu().numpy()[0, 1:] for k in ("lam", "pts", "mu"))             # slices 1..T
+    hh = np.abs(np.asarray(pan.robot.h, np.float32).reshape(-1))
+    scale = (np.abs(lam_r * pts_r).sum(-1) + (np.abs(mu_r) * hh).sum(-1))[..., None].astype(np.float32)
+    assert np.all(np.abs(fb - ref) <= 2 * np.spacing(scale)), (np.abs(fb - ref) / np.spacing(scale)).max()
 
 
 def test_full_size_batch_properties():
@@ -260,28 +339,6 @@ def test_interleaved_batches_equal_sequential():
         assert np.array_equal(o["opt_u"].cpu().numpy(), outs[j]["opt_u"].cpu().numpy())
         assert np.array_equal(o["opt_s"].cpu().numpy(), outs[j]["opt_s"].cpu().numpy())
         assert (outs[j]["iters"].cpu().numpy() == 4).all()
-
-
-@pytest.mark.parametrize("cfgname,scenes", [("acker_2k_T20_K15", (1, 2, 3, 5)), ("dyna_4k_T10_K10", (0, 1, 2))])
-def test_other_baseline_configs_full_size(cfgname, scenes):
-    """BASELINE.json configs[2] (acker, 2000 pts, T=20, K=15) and configs[3] (moving points,
-    4000 pts/scene) at full size on a few scenes: wherever the oracle's own PAN iteration has
-    nearly settled (last step |du| < 0.1) the HIP path must agree to control L2 <= 1e-4."""
-    from gpu_helpers import l2, make_gpu_pan
-    cfg = CONFIGS[cfgname]
-    pan = make_gpu_pan(cfg)
-    checked = 0
-    for b in scenes:
-        sc = make_scene(cfg, b)
-        orc = make_oracle(cfg)
-        s, u, d = orc.forward(sc["nom_s"], sc["nom_u"], sc["ref_s"], sc["ref_us"], sc["points"], sc["velocities"])
-        settled = np.linalg.norm(orc.trace[-1][1] - orc.trace[-2][1]) < 0.1
-        pan.reset_stop_state()
-        sg, ug, dg = pan(sc["nom_s"], sc["nom_u"], sc["ref_s"], sc["ref_us"], sc["points"], sc["velocities"])
-        if settled:
-            assert l2(ug.cpu().numpy(), u) <= 1e-4, (cfgname, b)
-            checked += 1
-    assert checked >= 2
 
 
 def test_eight_edge_robot_parity():

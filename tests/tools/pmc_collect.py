@@ -65,6 +65,20 @@ def run_pass(counters, workload):
     return out, {k: dur[k] / nd[k] for k in dur}, full, (r.returncode, r.stdout[-400:])
 
 
+def derive(e, c):
+    """Per-wave picture from the SQ counters (quad-cycle units cancel in the ratios)."""
+    if c.get("SQ_WAVE_CYCLES"):
+        e["wave_valu_busy_frac"] = c.get("SQ_ACTIVE_INST_VALU", 0.0) / c["SQ_WAVE_CYCLES"]     # share of a wave's life issuing VALU
+        e["wave_wait_frac"] = c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]                # ... parked on s_waitcnt / barriers
+    if c.get("SQ_INSTS_VALU"):
+        f64 = sum(c.get("SQ_INSTS_VALU_%s_F64" % k, 0.0) for k in ("ADD", "MUL", "FMA", "TRANS"))
+        e["fp64_share_of_valu_insts"] = f64 / c["SQ_INSTS_VALU"]
+        e["cycles_per_valu_inst"] = 4.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / c["SQ_INSTS_VALU"]
+    if c.get("SQ_WAVES"):
+        e["valu_insts_per_wave"] = c.get("SQ_INSTS_VALU", 0.0) / c["SQ_WAVES"]
+        e["lds_insts_per_wave"] = c.get("SQ_INSTS_LDS", 0.0) / c["SQ_WAVES"]
+
+
 def main():
     from bench import source_hash, BATCH
     workload = sys.argv[1] if len(sys.argv) > 1 else "diff_1k_T10_K10"
@@ -102,6 +116,7 @@ def main():
             e["valu_insts_per_launch"] = c["SQ_INSTS_VALU"]
         e["fp64_flops_per_launch"] = 64.0 * (c.get("SQ_INSTS_VALU_ADD_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0) +
                                              2 * c.get("SQ_INSTS_VALU_FMA_F64", 0))
+        derive(e, c)
         f, w = c.get("FETCH_SIZE", 0.0) * 1024, c.get("WRITE_SIZE", 0.0) * 1024
         e["fetch_bytes_raw"], e["write_bytes"], e["hbm_bytes_per_launch"] = f, w, f + w
         res["kernels"][k] = e

@@ -30,7 +30,7 @@ def launch(j):
     o = outs[j]
     check(lib.npa_nrmp_stage(pan._h, B, _ptr(ins[0]), _ptr(ins[1]), _ptr(ins[2]), _ptr(ins[3]), _ptr(st["mu"]), _ptr(st["lam"]),
                              _ptr(st["pts"]), _ptr(st["count"]), _ptr(o[0]), _ptr(o[1]), _ptr(o[2]), _ptr(o[3]),
-                             C.c_void_p(streams[j].cuda_stream)), "nrmp_stage")
+                             None, C.c_void_p(streams[j].cuda_stream)), "nrmp_stage")
 
 
 for n in (1, 2, 3, 4, 6, 8, 12, 16):
