@@ -29,13 +29,35 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# The kernels were validated (bitwise determinism of the reduced-precision key path included -- an earlier form of its
+# packed output layer, v_pk_fma_f32 with op_sel broadcasts, produced non-deterministic keys) with
+# this compiler.  Another one builds, with a warning: run tests/test_gpu_parity.py::test_dune_stage_full_size_deterministic*
+# (all key modes) on the GPU before trusting it.
+VALIDATED_HIPCC = "7.2.26015"
+
+
+def hipcc_version():
+    try:
+        out = subprocess.run([hipcc_path(), "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
+        for line in out.splitlines():
+            if line.startswith("HIP version:"):
+                return line.split(":", 1)[1].strip()
+    except Exception:  # pragma: no cover
+        pass
+    return "unknown"
+
+
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
+    ver = hipcc_version()
+    if not ver.startswith(VALIDATED_HIPCC):
+        print(f"neupan_amd.build: WARNING: hipcc {ver} is not the validated {VALIDATED_HIPCC}: re-run the -m gpu determinism "
+              "tests of the key path before trusting this build", file=sys.stderr)
     objs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [hipcc_path(), *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc_path(), *FLAGS, f'-DNPA_HIPCC_VERSION="{ver}"', "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -33,7 +33,7 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
                                     const int* count, float* cur_s_out, float* cur_u_out, float* cur_d_out,
                                     float* out_s, float* out_u, float* out_d, float* out_min_distance,
                                     int* out_iters, float* out_nrmp_points, int* flags, float* state,
-                                    double* qp_info, float* trig_out, float* dbg_abc, float* dbg_f, double* dbg_x,
+                                    double* qp_info, double* warm, float* trig_out, float* dbg_abc, float* dbg_f, double* dbg_x,
                                     hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);
 extern "C" size_t npa_qp_shmem_bytes(int T, int M);
 extern "C" hipError_t npa_launch_nominal(int batch, int T, int kin, double dt, double L, const double* state,
@@ -66,6 +66,7 @@ struct npa_handle {
   // key_e0: select_kernel's candidate margin e0 (1 + |d|), a multiple of the key error measured at creation
   int key_terms = 1;                     // 4 = geometric keys computed by select_kernel itself (no dune_kernel launch)
   float key_e0 = 0.f, key_err = 0.f;
+  bool qp_warm = true;                   // interior-point warm start across the PAN iterations of a forward call (NPA_QP_COLD=1: off)
   int sel_debug = 0;                     // NPA_SEL_DEBUG at creation: npa_dune_stage's count[] carries candidate statistics
   bool geo_valid = false;                // the polygon could be turned into vertices (consecutive CCW edges)
   float geo_err = 0.f, geo_margin = 0.f; // largest |network - geometric distance| / margin over the bands g in [0.25, 8] m
@@ -86,7 +87,10 @@ struct npa_handle {
 };
 
 extern "C" const char* npa_last_error(void) { return g_err.c_str(); }
-extern "C" const char* npa_version(void) { return "neupan_amd 0.1 (gfx950)"; }
+#ifndef NPA_HIPCC_VERSION
+#define NPA_HIPCC_VERSION "unknown"
+#endif
+extern "C" const char* npa_version(void) { return "neupan_amd 0.2 (gfx950, hipcc " NPA_HIPCC_VERSION ")"; }
 
 static int mdim(const DevParams& P) { return P.M > 0 ? P.M : 1; }
 // per-slice stride of the key buffer inside the workspace: none with geometric keys (select_kernel keeps them in LDS)
@@ -257,6 +261,7 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
           }
   }
   h->sel_debug = getenv("NPA_SEL_DEBUG") != nullptr;
+  h->qp_warm = getenv("NPA_QP_COLD") == nullptr;
   hipError_t e = hipGetDevice(&h->device);
   if (e == hipSuccess) {
     hipDeviceProp_t prop;
@@ -510,7 +515,7 @@ extern "C" int npa_nrmp_stage(npa_handle* h, int batch, const float* nom_s, cons
     return fail(NPA_E_ARG, "npa_nrmp_stage: obstacle arrays required when nrmp_max_num > 0");
   HIP_TRY(npa_launch_qp(h->P, batch, 0, nom_s, nom_u, ref_s, ref_us, mu_sorted, lam_sorted, pts_sorted, nullptr, count,
                         out_s, out_u, out_d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                        qp_info, nullptr, nullptr, nullptr, x64, (hipStream_t)stream, nullptr, nullptr));
+                        qp_info, nullptr, nullptr, nullptr, nullptr, x64, (hipStream_t)stream, nullptr, nullptr));
   return NPA_OK;
 }
 
@@ -523,7 +528,7 @@ extern "C" int npa_nrmp_params(npa_handle* h, int batch, const float* nom_s, con
   // (the reference trajectory only enters the cost: the nominal arrays stand in for it, the kernel returns before the solve)
   HIP_TRY(npa_launch_qp(h->P, batch, 0, nom_s, nom_u, nom_s, nom_u, mu_sorted, lam_sorted, pts_sorted, nullptr, count,
                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                        nullptr, nullptr, out_abc, h->P.M > 0 ? out_f : nullptr, nullptr, (hipStream_t)stream, nullptr, nullptr));
+                        nullptr, nullptr, nullptr, out_abc, h->P.M > 0 ? out_f : nullptr, nullptr, (hipStream_t)stream, nullptr, nullptr));
   return NPA_OK;
 }
 
@@ -704,7 +709,8 @@ extern "C" int npa_forward_iter(npa_handle* h, int k) {
   EventPair* ev = next_event(h, h->ev_qp, h->n_qp);
   HIP_TRY(npa_launch_qp(P, batch, 0, cur_s, cur_u, pc->ref_s, pc->ref_us, mu, lam, pts, dist, count, cur_s, cur_u,
                         cur_d, pc->out_s, pc->out_u, pc->out_d, pc->out_md, pc->out_iters, pc->out_np, flags,
-                        pc->state, qp_info, pc->dune ? ws + L.trig : nullptr, nullptr, nullptr, nullptr, stream,
+                        pc->state, qp_info, h->qp_warm ? (double*)(ws + L.warm) : nullptr, pc->dune ? ws + L.trig : nullptr,
+                        nullptr, nullptr, nullptr, stream,
                         ev ? ev->a : nullptr, ev ? ev->b : nullptr));
   if (h->key_auto && pc->dune && k == P.K - 1)
     HIP_TRY(hipMemcpyAsync(h->sel_stats_host, h->sel_stats_dev, sizeof(unsigned), hipMemcpyDeviceToHost, stream));

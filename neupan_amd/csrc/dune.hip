@@ -33,6 +33,7 @@
 //     the 65 MFMAs.
 #include "pan_common.h"
 #include <hip/hip_ext.h>
+#include <algorithm>
 #include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -541,9 +542,11 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
   unsigned* skey = reinterpret_cast<unsigned*>(sel + SEL_CAP);   // [NPA_MAX_M] keys of the msel extracted entries
   int* lst = reinterpret_cast<int*>(skey + NPA_MAX_M);        // [64]: short list of the first extraction
   constexpr int ROW_W = E + 5;                                // mu[E], lam[2], point[2], distance
-  float* rows = reinterpret_cast<float*>(lst + 64);           // [SEL_CAP][ROW_W]: exact rows of the final candidates
+  unsigned* dkey = reinterpret_cast<unsigned*>(lst + 64);     // [n_use] keys; later the candidate list + their exact keys
+  // the exact rows of the final candidates take over the key area once the candidates stand in sel[] (the launcher
+  // sizes the area for whichever is larger)
+  float* rows = reinterpret_cast<float*>(dkey);               // [SEL_CAP][ROW_W]
   unsigned* rkey = reinterpret_cast<unsigned*>(rows + SEL_CAP * (NPA_MAX_E + 5));   // [SEL_CAP][2]: (index, exact key)
-  unsigned* dkey = rkey + 2 * SEL_CAP;                        // [n_use] keys; later the candidate list + their exact keys
   const int t = blockIdx.x + t0, b = blockIdx.y + scene0, lane = threadIdx.x;
   const int j = lane & 31, hf = lane >> 5;
   const int T = P.T, M = P.M;
@@ -854,8 +857,9 @@ extern "C" hipError_t npa_launch_select(const DevParams& P, const float* wpack, 
   const int dbg = debug ? 2 : 1;
   const bool geo = key_terms == 4;
   const int approx = key_terms == 0 ? 0 : dbg;
+  const size_t key_area = std::max<size_t>((size_t)tps * 32 * sizeof(unsigned), SEL_CAP * (NPA_MAX_E + 5 + 2) * sizeof(float));
   const size_t shmem = (11 * 32 + 8 * 32 + 8 + NPA_GEO_BANDS) * sizeof(float) + (SEL_CAP + NPA_MAX_M + 64) * sizeof(int) +
-                       SEL_CAP * (NPA_MAX_E + 5 + 2) * sizeof(float) + ((size_t)tps * 32 * sizeof(unsigned) + 15) / 16 * 16;
+                       (key_area + 15) / 16 * 16;
   // slices of more than ~15 000 points keep more than the default 64 KB of dynamic LDS (4 B per key)
 #define LAUNCH1(EE, GG)                                                                                             \
   do {                                                                                                              \

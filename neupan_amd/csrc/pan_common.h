@@ -86,7 +86,7 @@ __host__ __device__ inline size_t npa_state_floats(int T, int M, int E) {
 // ---- scratch: struct-of-arrays over the batch (offsets in 4-byte words) ---------------------
 // cur_s [B][3][T+1]  cur_u [B][2][T]  cur_d [B][T]  mu [B][T+1][M][E]  lam [B][T+1][M][2]
 // pts [B][T+1][M][2]  dist [B][T+1][M]  count [B][T+1] (int)
-// flags [B][4] (int: done, iters)
+// flags [B][4] (int: done, iters, warm start usable)   warm [B][nwarm] (double: x and multipliers of the last QP)
 // trig [B][T+1][2] (float: cos, sin of the nominal heading of every horizon step, written by whoever writes cur_s)
 // keys [B][T+1][key_stride] (uint: order-preserving distance key of every point of every slice)
 // pan.py:207 builds R from torch.cos / torch.sin of the fp32 heading (fp32 libm: within 1 ulp of the correctly rounded
@@ -98,8 +98,11 @@ __device__ inline void npa_trig(float th, float& c, float& s) {
 }
 
 struct ScratchLayout {
-  size_t cur_s, cur_u, cur_d, mu, lam, pts, dist, count, flags, qp_info, trig, keys, total;
+  size_t cur_s, cur_u, cur_d, mu, lam, pts, dist, count, flags, warm, qp_info, trig, keys, total;
 };
+__host__ __device__ inline size_t npa_warm_doubles(int T, int M) {   // per scene: x (2T + T), lf (T M), lc (8T - 4), ld (2T)
+  return (size_t)2 * T + T + (size_t)T * M + (8 * T - 4) + 2 * T;
+}
 __host__ __device__ inline ScratchLayout npa_scratch_layout(int B, int T, int M, int E, int key_stride) {
   ScratchLayout L;
   size_t o = 0;
@@ -114,6 +117,7 @@ __host__ __device__ inline ScratchLayout npa_scratch_layout(int B, int T, int M,
   L.count = take((size_t)B * (T + 1));
   L.flags = take((size_t)B * 4);
   o = (o + 3) & ~(size_t)3;                       // 16-byte alignment for the doubles
+  L.warm = take((size_t)B * npa_warm_doubles(T, M) * 2);
   L.qp_info = take((size_t)B * 16 * 2);          // per-scene solver diagnostics of the last QP (16 doubles)
   L.trig = take((size_t)B * (T + 1) * 2);        // (cos, sin) of every nominal heading, see npa_trig()
   L.keys = take((size_t)B * (T + 1) * key_stride);

@@ -222,7 +222,7 @@ def gpu_last_qp_certificates(pan, cfg, batch, scenes=None):
       * the kernel's fp64 solution is certified (oracle.nrmp_qp.kkt_certificate: stationarity with NNLS multipliers,
         complementarity, feasibility),
       * the oracle solves the same problem: objective gap and control difference.
-    Returns a dict of maxima plus `tied` = the stage re-run reproduced the forward call's controls bitwise."""
+    Returns a dict of maxima plus `tied_to_forward` = the stage re-run reproduced the forward call's controls (<= 2e-6)."""
     import torch
     from helpers import robot_numbers
     from oracle.nrmp_qp import NrmpProblem, kkt_certificate, solve_nrmp_qp
@@ -243,7 +243,9 @@ def gpu_last_qp_certificates(pan, cfg, batch, scenes=None):
     stage = pan.dune_stage(snap_s, a[4], batch.get("velocities"))
     par = pan.nrmp_params(snap_s, snap_u, stage)
     sol = pan.nrmp_stage(snap_s, snap_u, a[2], a[3], stage)
-    tied = bool(np.array_equal(sol["opt_u"].cpu().numpy(), out["opt_u"].cpu().numpy()))
+    # (the forward call may have warm-started this solve from the previous iteration's, the stage entry point starts
+    # cold: the same limit point, to the last few bits)
+    tied = bool(np.abs(sol["opt_u"].cpu().numpy() - out["opt_u"].cpu().numpy()).max() <= 2e-6)
     x64 = sol["x64"].cpu().numpy()
     ns, nu_ = snap_s.cpu().numpy(), snap_u.cpu().numpy()
     G, h, sp, ac, L = robot_numbers(cfg.robot, cfg.dt)
@@ -273,6 +275,6 @@ def gpu_last_qp_certificates(pan, cfg, batch, scenes=None):
         res["du_vs_oracle"] = max(res["du_vs_oracle"], float(np.abs(u - uo).max()))
         worst.append((float(np.abs(u - uo).max()), int(b)))
     res["scenes"] = len(worst)
-    res["tied_to_forward_bitwise"] = tied
+    res["tied_to_forward"] = tied
     res["worst_du_scenes"] = [b for _, b in sorted(worst, reverse=True)[:3]]
     return res

@@ -197,15 +197,15 @@ def test_other_baseline_configs_parity_distribution(cfgname, scenes):
 def test_gpu_last_qp_is_certified_optimal(cfgname, B):
     """The last QP of a forward call at benchmark size, per scene: rebuilt on the host from the parameters the KERNEL
     built (npa_nrmp_params), the kernel's fp64 solution passes the independent KKT certificate, and its objective is
-    within 1e-9 (relative) of the oracle's solution of the same problem.  The stage re-run is tied bitwise to the
-    forward call's result.  (ECOS is absent: for a strictly convex QP the certified point is the answer it approximates.)"""
+    within 1e-9 (relative) of the oracle's solution of the same problem.  The stage re-run reproduces the forward call's
+    controls to 2e-6 (cold start there, warm start inside the forward call).  (ECOS is absent: for a strictly convex QP the certified point is the answer it approximates.)"""
     from gpu_helpers import make_gpu_pan
     from parity_tools import gpu_last_qp_certificates
     cfg = CONFIGS[cfgname]
     pan = make_gpu_pan(cfg)
     r = gpu_last_qp_certificates(pan, cfg, make_batch(cfg, 0, B))
     print(r)
-    assert r["tied_to_forward_bitwise"] and r["scenes"] == B
+    assert r["tied_to_forward"] and r["scenes"] == B
     # feasible to rounding, complementary, and -- the sharp statement -- the objective of the kernel's feasible point is
     # within 1e-9 (relative; measured 1e-13) of the oracle's optimum of the same problem.  The NNLS stationarity residual
     # is reported next to the oracle's own on the same problems (1.4e-5 vs 1.5e-4 at config 2: it is limited by the
@@ -282,8 +282,11 @@ def test_full_size_batch_properties():
     assert (out["min_distance"].cpu().numpy() > 0).all()
 
 
-def test_dune_stage_full_size_deterministic_and_selects_nearest():
-    """The DUNE stage at full size (256 scenes x 11 slices x 1000 points), repeated: (1) bitwise
+@pytest.mark.parametrize("mode", ["default", "1", "3"])
+def test_dune_stage_full_size_deterministic_and_selects_nearest(mode):
+    """In every key mode (geometric keys; single / split fp16 products of the network key path, whose packed fp32 output
+    layer once was non-deterministic in another form -- neupan_amd/build.py pins the compiler this was validated with).
+    The DUNE stage at full size (256 scenes x 11 slices x 1000 points), repeated: (1) bitwise
     the same rows every time (the encode kernel hands tiles to waves dynamically -- results must
     not depend on which wave took which tile); (2) the emitted rows are ascending in the exact
     distance; (3) against the oracle encoder on a sample of slices: the emitted set IS the M
@@ -292,7 +295,7 @@ def test_dune_stage_full_size_deterministic_and_selects_nearest():
     from gpu_helpers import make_gpu_pan
     cfg = CONFIGS["diff_1k_T10_K10"]
     B, M = 256, cfg.nrmp_max_num
-    pan = make_gpu_pan(cfg)
+    pan = make_gpu_pan(cfg) if mode == "default" else _with_env({"NPA_KEY_TERMS": mode}, lambda: make_gpu_pan(cfg))
     batch = make_batch(cfg, 4000, B)
     first = None
     for rep in range(6):

@@ -8,6 +8,8 @@ Per QP: max |u_oracle - u_HiGHS|, objective difference (oracle - HiGHS; <= 0 mea
 good), the oracle's KKT certificate, HiGHS' status.  HiGHS stops at ~1e-7 objective accuracy, which along the flat
 steering directions of this QP is 1e-6 .. 1e-4 in u: the objective difference is the sharper statement."""
 import json, os, sys, time
+for _k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):      # before numpy loads: one BLAS thread per worker
+    os.environ.setdefault(_k, "1")
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

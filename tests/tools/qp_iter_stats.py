@@ -22,3 +22,7 @@ print("iterations histogram:", np.bincount(it).tolist())
 print("best-iterate index histogram:", np.bincount(best).tolist())
 print("iters - best:", np.bincount(it - best).tolist())
 print("status:", np.bincount(info[:, 3].astype(int)).tolist(), " merit pct50/90/100:", np.percentile(info[:, 1], [50, 90, 100]))
+tot = info[:, 14].astype(int); code = info[:, 15].astype(int)
+print("total iterations incl. dropped warm attempts: mean %.2f max %d; warm code histogram (0 cold, 1 warm used, 2/3 dropped at it 0/3, 4 not converged):" % (tot.mean(), tot.max()), np.bincount(code, minlength=5).tolist())
+for c in range(5):
+    if (code == c).any(): print("  code", c, "total iterations: mean %.1f max %d" % (tot[code == c].mean(), tot[code == c].max()))
