@@ -267,7 +267,11 @@ def main():
         line["cpu_baseline"] = {"value": round(cpu_rate, 3), "unit": "plans/s", "cores": ncore, "kind": "port",
                                 "sample": f"first {n_sc} scenes of the same workload, K={K} each, oracle/pan_oracle.py "
                                           f"(numpy fp32 + fp64 IPM), {ncore} worker processes x 1 thread (host has {host} cores); "
-                                          "rate = scenes / slowest worker's planning time"}
+                                          "rate = scenes / wall time of that phase, workers started and warm"}
+        js = getattr(run_ensemble, "last_job_seconds", None)
+        if js:
+            line["cpu_baseline"]["seconds_per_plan_in_worker"] = {"median": round(float(np.median(js)), 3), "max": round(float(max(js)), 3),
+                                                                  "jobs_seen": len(js)}
         rep["note"] = ("oracle = reference code restated + substituted fp64 QP solver (ECOS unavailable: parity unpinned at that "
                        "boundary).  Ensemble per scene = the oracle itself on inputs moved by +-1 float32 ulp (8 members) and with the "
                        "DUNE hidden units permuted (same function, other fp32 summation order; 4 members).  well posed = ensemble "

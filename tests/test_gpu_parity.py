@@ -410,6 +410,24 @@ def test_key_nominated_selection_equals_exact_key_selection(cfgname, B, mode):
         assert np.array_equal(r[k], e[k]), k
 
 
+def test_badly_fitting_checkpoint_falls_back_to_network_keys():
+    """A checkpoint whose distance is far from the geometry (the quick-fit E = 8 stand-in of round 1: 0.6 m off next to
+    the robot) must not get geometric keys: npa_create measures its margin above the 0.15 m cap and keeps network keys,
+    whose own measured margin applies; the selection is still bitwise that of exact keys."""
+    import os
+    from gpu_helpers import make_gpu_pan
+    from helpers import GOLDEN
+    cfg = CONFIGS["poly8_5k_T10_K10"]
+    ck = os.path.join(GOLDEN, "checkpoints", "poly8_model_quick.pth")
+    pan = make_gpu_pan(cfg, checkpoint=ck)
+    exact = _with_env({"NPA_DUNE_FP32KEYS": "1"}, lambda: make_gpu_pan(cfg, checkpoint=ck))
+    assert pan.key_mode()["key_terms"] in (1, 3) and exact.key_mode()["key_terms"] == 0, pan.key_mode()
+    batch = make_batch(cfg, 1000, 12)
+    r, e = _stage_np(pan, batch), _stage_np(exact, batch)
+    for k in ("mu", "lam", "pts", "dist", "count"):
+        assert np.array_equal(r[k], e[k]), k
+
+
 @pytest.mark.parametrize("cfgname", ["diff_1k_T10_K10", "acker_2k_T20_K15"])
 def test_far_clouds_equal_exact_key_selection(cfgname):
     """The key margins are MEASURED, so they hold where they were measured: geometric keys out to +-128 m in the robot
