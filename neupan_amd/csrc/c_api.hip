@@ -154,6 +154,24 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
     }
     h->geo_valid = ok;
     P.geo_rcal = 0.f;
+    // axis-aligned rectangle?  (edges alternately parallel to x and y: every vertex shares x or y with its successor)
+    P.geo_rect = 0;
+    if (ok && E == 4) {
+      bool rect = true;
+      double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+      for (int e = 0; e < 4; ++e) {
+        const int n = (e + 1) & 3;
+        const double dx = std::fabs(V[n][0] - V[e][0]), dy = std::fabs(V[n][1] - V[e][1]);
+        if (!(dx <= 1e-9 * (1 + dy) || dy <= 1e-9 * (1 + dx))) rect = false;
+        xmin = std::min(xmin, V[e][0]); xmax = std::max(xmax, V[e][0]);
+        ymin = std::min(ymin, V[e][1]); ymax = std::max(ymax, V[e][1]);
+      }
+      if (rect) {
+        P.geo_rect = 1;
+        P.rcx = (float)(0.5 * (xmin + xmax)); P.rcy = (float)(0.5 * (ymin + ymax));
+        P.rhx = (float)(0.5 * (xmax - xmin)); P.rhy = (float)(0.5 * (ymax - ymin));
+      }
+    }
   }
 
   std::vector<float> pack(WP_TOTAL, 0.f);

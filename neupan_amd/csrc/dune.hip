@@ -504,6 +504,10 @@ void dune_kernel(
 // min over the edges of the point-segment distance: ~12 VALU instructions per edge.  Only ever used as a KEY.
 template <int E>
 __device__ __forceinline__ float geo_dist(const DevParams& P, float x, float y) {
+  if (P.geo_rect) {                          // wave-uniform: distance to an axis-aligned box, ~8 instructions
+    const float dx = fmaxf(fabsf(x - P.rcx) - P.rhx, 0.f), dy = fmaxf(fabsf(y - P.rcy) - P.rhy, 0.f);
+    return __builtin_sqrtf(fmaf(dx, dx, dy * dy));
+  }
   float best = 3.0e38f;
   bool inside = true;
 #pragma unroll

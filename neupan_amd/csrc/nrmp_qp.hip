@@ -51,7 +51,7 @@
     for (int i = lane; i < mcu; i += QP_THREADS) {                                                \
       bool act = cact[i];                                                                         \
       lc[i] = act ? 1.0 : 0.0;                                                                    \
-      wc[i] = act ? fmax(cb[i], 1.0) : 1.0;                                                       \
+      wc[i] = act ? fmax(cb_of(i), 1.0) : 1.0;                                                    \
       dlc[i] = 0; dwc[i] = 0;                                                                     \
     }                                                                                             \
     LSYNC();                                                                                      \
@@ -197,8 +197,7 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
   double* dxu = xbest + nu + T;               // [nu]
   double* dxd = dxu + nu;                     // [T]
   double* invd = dxd + T;                     // [nu]   1/L_kk
-  double* rhsd = invd + nu;                   // [T]
-  double* fa0 = rhsd + T;                     // [mf] ...
+  double* fa0 = invd + nu;                    // [mf] ...
   double* fa1 = fa0 + mf;
   double* ff = fa1 + mf;
   double* lf = ff + mf;
@@ -213,8 +212,7 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
   double* dwc = dlc + mcu;
   double* r2 = dwc + mcu;
   double* iwc = r2 + mcu;                     // 1/wc
-  double* cb = iwc + mcu;                     // bound (or 0 when inactive)
-  double* ld_ = cb + mcu;                     // [2T] d rows: index 2t (d<=dmax), 2t+1 (-d<=-dmin0)
+  double* ld_ = iwc + mcu;                    // [2T] d rows: index 2t (d<=dmax), 2t+1 (-d<=-dmin0)
   double* wd = ld_ + 2 * T;
   double* dld = wd + 2 * T;
   double* dwd = dld + 2 * T;
@@ -275,8 +273,14 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
     double bd = (i < 4 * T) ? P.speed_bound[v & 1] : P.acce_bound[v & 1];
     bool act = isfinite(bd);
     cact[i] = act ? 1 : 0;
-    cb[i] = act ? bd : 0.0;
   }
+  // bound of u row i (two speed and two rate bounds: selected by index, not stored per row)
+  const double sb0 = isfinite(P.speed_bound[0]) ? P.speed_bound[0] : 0.0, sb1 = isfinite(P.speed_bound[1]) ? P.speed_bound[1] : 0.0;
+  const double ab0 = isfinite(P.acce_bound[0]) ? P.acce_bound[0] : 0.0, ab1 = isfinite(P.acce_bound[1]) ? P.acce_bound[1] : 0.0;
+  auto cb_of = [&](int i) -> double {
+    const bool odd = (((i < 4 * T) ? i : i - 4 * T) >> 1) & 1;
+    return (i < 4 * T) ? (odd ? sb1 : sb0) : (odd ? ab1 : ab0);
+  };
   LSYNC();
 
   // ---- Phi recursion: Phi[t] = A_t Phi[t-1] + [B_t at cols 2t,2t+1]; A = I + e0 A02 e2' + e1 A12 e2'
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
   double cmax = fmax(fabs(dmaxv), fabs(dmin0));
   int m_act = 0;
   for (int i = lane; i < mcu; i += QP_THREADS)
-    if (cact[i]) { cmax = fmax(cmax, fabs(cb[i])); ++m_act; }
+    if (cact[i]) { cmax = fmax(cmax, fabs(cb_of(i))); ++m_act; }
   QP_COLD_INIT();
   double gmax = obs ? (double)P.eta : 0.0;
   // g_u = Phi' lin - 2 p_u gamma_b on the speed entries
@@ -478,7 +482,7 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
         double sg = (i & 1) ? -1.0 : 1.0;
         double cx = (i < 4 * T) ? sg * xu[v] : sg * (xu[v + 2] - xu[v]);
         lc[i] = fmax(wrm[nu + T + mf + i], dl);
-        wc[i] = fmax(cb[i] - cx, dl);
+        wc[i] = fmax(cb_of(i) - cx, dl);
       }
     }
     for (int i = lane; i < 2 * T && obs; i += QP_THREADS) {
@@ -515,7 +519,7 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
         int v = (i < 4 * T) ? (i >> 1) : ((i - 4 * T) >> 1);
         double sg = (i & 1) ? -1.0 : 1.0;
         double cx = (i < 4 * T) ? sg * xu[v] : sg * (xu[v + 2] - xu[v]);
-        r = cx + wc[i] - cb[i];
+        r = cx + wc[i] - cb_of(i);
         gap += lc[i] * wc[i];
       }
       r2[i] = r;
@@ -1090,7 +1094,7 @@ extern "C" size_t npa_qp_shmem_bytes_path(int T, int M, int fast) {
   const size_t mats = fast ? (size_t)T * 6 + nu * (nu + 1) / 2 + nu * (nu - 1) / 2 + 2
                            : (size_t)T * 2 * ldp + 2 * nu * ldp;
   size_t d = (size_t)T * 3 * ldp + mats + 4 * (T * 3) + T * 12 + T * 8 + nu + T +
-             (nu + T) + nu + T + nu + T + 9 * mf + 7 * mcu + 6 * 2 * T;
+             (nu + T) + nu + T + nu + 9 * mf + 6 * mcu + 6 * 2 * T;
   size_t bytes = d * sizeof(double) + 2 * ((npair + 7) & ~(size_t)7) + ((mcu + 7) & ~(size_t)7);
   return (bytes + 15) & ~(size_t)15;
 }

@@ -24,6 +24,10 @@ struct DevParams {
   // used by the GEOMETRIC distance keys (select_kernel<E, true>), never by the rows that are emitted
   float pvx[NPA_MAX_E], pvy[NPA_MAX_E], pdx[NPA_MAX_E], pdy[NPA_MAX_E], pil[NPA_MAX_E];   // pil = 1 / |D|^2
   float geo_rcal;             // half extent of the square (robot frame) over which the geometric key's error was measured
+  // the common case -- an axis-aligned rectangle in the robot frame (robot.py:342-375 builds length x width boxes) --
+  // has a cheaper closed form: centre, half extents; geo_rect != 0 selects it
+  int geo_rect;
+  float rcx, rcy, rhx, rhy;
 };
 
 // ---- geometric distance keys ------------------------------------------------------------------------
