@@ -33,8 +33,6 @@
 #include <cstdlib>
 
 #define QP_THREADS 64          // lanes cooperating on one scene (one wavefront)
-#define QP_WAVES 4             // scenes per workgroup: one wave on each SIMD of a CU, so the
-                               // register-hungry QP waves displace as few DUNE workgroups as possible
 #define QP_MAX_IT 40
 #define QP_WARM_DELTA 0.01     // floor of the multipliers / slacks taken over from the previous solve
 #define QP_WARM_STEP 0.1       // largest control change of the previous solve after which its result is reused
@@ -43,16 +41,14 @@
 #define QP_COLD_INIT()                                                                            \
   do {                                                                                            \
     for (int a = lane; a < nu; a += QP_THREADS) { xu[a] = 0.0; xbest[a] = 0.0; }                  \
-    for (int t = lane; t < T; t += QP_THREADS) {                                                  \
-      xd[t] = d0; xbest[nu + t] = d0; dxd[t] = 0.0;                                               \
-      ld_[2 * t] = 1.0; ld_[2 * t + 1] = 1.0;                                                     \
-      wd[2 * t] = fmax(dmaxv - d0, 1.0); wd[2 * t + 1] = fmax(d0 - dmin0, 1.0);                   \
-    }                                                                                             \
-    for (int i = lane; i < mcu; i += QP_THREADS) {                                                \
-      bool act = cact[i];                                                                         \
-      lc[i] = act ? 1.0 : 0.0;                                                                    \
-      wc[i] = act ? fmax(cb_of(i), 1.0) : 1.0;                                                    \
-      dlc[i] = 0; dwc[i] = 0;                                                                     \
+    for (int t = lane; t < T; t += QP_THREADS) { xd[t] = d0; xbest[nu + t] = d0; dxd[t] = 0.0; }  \
+    for (int p = lane; p < npc; p += QP_THREADS) {                                                \
+      const PairC c = PAIR_C(p);                                                                  \
+      const double cx = p >= npu ? d0 : 0.0;      /* c'x at the cold point */                     \
+      const bool on = c.actf != 0.0;                                                              \
+      st2(lc + 2 * p, c.actf, c.actf);                                                            \
+      st2(wc + 2 * p, on ? fmax(c.bp - cx, 1.0) : 1.0, on ? fmax(c.bm + cx, 1.0) : 1.0);          \
+      st2(dlc + 2 * p, 0.0, 0.0); st2(dwc + 2 * p, 0.0, 0.0);                                     \
     }                                                                                             \
     LSYNC();                                                                                      \
     for (int i = lane; i < mf; i += QP_THREADS) {                                                 \
@@ -64,12 +60,19 @@
 // qp_info layout per scene (doubles): [0] best iteration [1] merit [2] mu [3] status [4] iterations
 // run, then (only when built with -DNPA_QP_PROF) accumulated s_memtime cycles of the solve's phases
 #define QP_INFO_STRIDE 16
+// (-DNPA_QP_PROF=1: the phases of an iteration; =2: inside the residual phase; =3: inside a predictor / corrector pass;
+// tests/tools/qp_phase_cycles.py builds the variants and names the slots)
 #ifdef NPA_QP_PROF
 #define PROF_DECL unsigned long long pt_ = __builtin_amdgcn_s_memtime(), pacc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define PROF(i) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); pacc_[i] += n_ - pt_; pt_ = n_; } while (0)
+#define PROF_AT(i) do { unsigned long long n_ = __builtin_amdgcn_s_memtime(); pacc_[i] += n_ - pt_; pt_ = n_; } while (0)
+#define PROF(i) do { if (NPA_QP_PROF == 1 || (i) == 0 || (i) == 9) PROF_AT(i); } while (0)
+#define PROF_B(i) do { if (NPA_QP_PROF == 2) PROF_AT(i); } while (0)
+#define PROF_C(i) do { if (NPA_QP_PROF == 3) PROF_AT(i); } while (0)
 #else
 #define PROF_DECL
 #define PROF(i) do { } while (0)
+#define PROF_B(i) do { } while (0)
+#define PROF_C(i) do { } while (0)
 #endif
 
 // ---- small device helpers -------------------------------------------------------------------
@@ -111,6 +114,9 @@ __device__ __forceinline__ double fast_rsqrt(double x) {    // x > 0
   y = y * fma(-0.5 * x * y, y, 1.5);
   return y;
 }
+// two adjacent doubles of an LDS array in one ds_read_b128 / ds_write_b128 (the arrays used this way start at even offsets)
+__device__ __forceinline__ double2 ld2(const double* p) { return *reinterpret_cast<const double2*>(p); }
+__device__ __forceinline__ void st2(double* p, double a, double b) { *reinterpret_cast<double2*>(p) = make_double2(a, b); }
 // wave-local ordering of LDS traffic between lanes (the waves of a workgroup are independent
 // scenes with different iteration counts: no workgroup barrier may be used)
 #define LSYNC()                                              \
@@ -141,8 +147,34 @@ struct QpBackward {
   double* dbg_x;            // [B][2T + T]: the fp64 solution (u_0x, u_0y, ..., then d) before the cast to fp32, or null
 };
 
+// Pair p of the u / d rows: rows 2p and 2p + 1 are  +c'x <= bp  and  -c'x <= bm  with c'x = x[ia] - sb x[ib] over the
+// vector x = (u, d) (xu / xd and dxu / dxd are contiguous in LDS).  p < 2T: speed of u_p; p < 4T - 2: rate
+// u_{q+2} - u_q, q = p - 2T; then d_t, t = p - (4T - 2).  actf = 0 switches a pair with an infinite bound off (its
+// multipliers stay 0, its slacks 1).  A plain function of VALUES on purpose: as a lambda over the kernel's locals the
+// selection among the bounds became a selection among ADDRESSES of closure fields, the closure went to scratch memory
+// and every use inside the solve's loop was a (twice) dependent memory load.
+struct PairC { int ia, ib; double sb, bp, bm, actf; };
+__device__ __forceinline__ PairC qp_pair(int p, int T, int npu, double sb0, double sb1, double ab0, double ab1, double sf0,
+                                         double sf1, double af0, double af1, double dmaxv, double dmin0) {
+  PairC c;
+  const bool is_d = p >= npu, is_rate = p >= 2 * T && !is_d;
+  const int q = p - 2 * T;
+  const bool odd = ((is_rate ? q : p) & 1) != 0;
+  c.ia = is_d ? 2 * T + (p - npu) : (is_rate ? q + 2 : p);
+  c.ib = is_rate ? q : 0;
+  c.sb = is_rate ? 1.0 : 0.0;
+  const double bs = odd ? sb1 : sb0, ba = odd ? ab1 : ab0, fs = odd ? sf1 : sf0, fa = odd ? af1 : af0;
+  const double bd = is_rate ? ba : bs;
+  c.actf = is_d ? 1.0 : (is_rate ? fa : fs);
+  c.bp = is_d ? dmaxv : bd;
+  c.bm = is_d ? -dmin0 : bd;
+  return c;
+}
+
 template <int TT, int MM, bool BWD = false>
-__global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
+// (at least two waves per SIMD: <= 256 registers; the T = 10 instantiation takes 165, the T = 20 one 220)
+__global__ __attribute__((amdgpu_flat_work_group_size(QP_THREADS, QP_THREADS), amdgpu_waves_per_eu(2, 3)))
+void nrmp_qp_kernel(
     DevParams P, const float* cur_s_in, const float* cur_u_in, const float* __restrict__ ref_s,
     const float* __restrict__ ref_us, const float* __restrict__ mu_sorted, const float* __restrict__ lam_sorted,
     const float* __restrict__ pts_sorted, const float* __restrict__ dist_sorted, const int* __restrict__ count,
@@ -150,19 +182,21 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
     float* __restrict__ out_u, float* __restrict__ out_d, float* __restrict__ out_min_distance,
     int* __restrict__ out_iters, float* __restrict__ out_nrmp_points, int* __restrict__ flags,
     float* __restrict__ state, double* __restrict__ qp_info, double* __restrict__ warm, int scene0, int nscene,
-    int wave_doubles, int wpg, QpBackward bw, float* __restrict__ trig_out) {
+    QpBackward bw, float* __restrict__ trig_out) {
   extern __shared__ __attribute__((aligned(16))) double sm_all[];
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const bool low_prio = wpg < 0;          // launcher knob NPA_QP_LOWPRIO: run at the default wave priority
-  if (low_prio) wpg = -wpg;
-  if (blockIdx.x * wpg + wv >= nscene) return;
-  const int b = blockIdx.x * wpg + wv + scene0;
-  double* sm = sm_all + (size_t)wv * wave_doubles;
+  // one scene (one wave) per workgroup: the dispatcher spreads the waves of a launch evenly over the CUs, and -- the
+  // reason it is fixed here and not a launch parameter -- the scene's LDS block starts at LDS address 0, so every array
+  // below is addressed with an immediate offset.  With a run-time base (several scenes per workgroup) the compiler
+  // kept ~60 array base addresses in SGPRs, spilled them to VGPR lanes and re-read ~150 of them with v_readlane in
+  // every iteration of the solve.
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x >= nscene) return;
+  const int b = blockIdx.x + scene0;
+  double* sm = sm_all;
   if (flags && flags[b * 4 + 0]) return;
-  // this wave is a long dependent chain that shares its SIMD with throughput-bound DUNE waves of
-  // the other sub-batches: win the issue arbitration, it needs few slots but needs them promptly
-  if (!low_prio) __builtin_amdgcn_s_setprio(3);
+  // this wave is a long dependent chain that shares its SIMD with throughput-bound selection waves of
+  // the other batches in flight: win the issue arbitration, it needs few slots but needs them promptly
+  __builtin_amdgcn_s_setprio(3);
 
   // with TT and MM fixed every LDS offset below folds to an immediate (one base register)
   PROF_DECL
@@ -177,50 +211,51 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
   const double dmin0 = fmax((double)P.d_min, 0.0), dmaxv = (double)P.d_max;
 
   // ---- LDS carve (doubles) -----------------------------------------------------------
-  double* Phi = sm;                           // [T][3][ldp]  s(t+1) = Phi[t] u + cv[t]
+  // Rows of the interior-point method first, at even offsets (they are read and written two at a time).  The rows on u
+  // (index i < mcu: 2v / 2v+1 = +-u_v <= speed bound, 4T + 2q / +1 = +-(u_{q+2} - u_q) <= rate bound) and the rows on d
+  // (mcu + 2t: d_t <= d_max, mcu + 2t + 1: -d_t <= -d_min) share one array each: "pair" p holds rows 2p and 2p + 1, the
+  // + and - side of one linear form.  ld_, wd, ... are the d parts under their own names.
+  const int mcd = mcu + 2 * T;
+  double* lc = sm;                            // [mcu + 2T] multipliers
+  double* wc = lc + mcd;                      // slacks
+  double* dlc = wc + mcd;
+  double* dwc = dlc + mcd;
+  double* r2 = dwc + mcd;
+  double* iwc = r2 + mcd;                     // 1/w
+  double* ld_ = lc + mcu; double* wd = wc + mcu; double* dld = dlc + mcu; double* dwd = dwc + mcu;
+  double* r2d = r2 + mcu; double* iwd = iwc + mcu;
+  const int mfe = (mf + 1) & ~1;
+  double* fa0 = iwc + mcd;                    // [mf] hinge rows ...
+  double* fa1 = fa0 + mfe;
+  double* ff = fa1 + mfe;
+  double* lf = ff + mfe;
+  double* wf = lf + mfe;
+  double* dlf = wf + mfe;
+  double* dwf = dlf + mfe;
+  double* r3 = dwf + mfe;
+  double* iwf = r3 + mfe;                     // 1/(wf + lf/ro)
+  double* Phi = iwf + mfe;                    // [T][3][ldp]  s(t+1) = Phi[t] u + cv[t]
   // generic path: Yt [T][2][ldp] = S'_t Phi_xy(t), Hm / Km [nu][ldk] full matrices.
   // fast path (TT > 0): Yt [T][6] = staging of the 3x3 P_t, Hm packed lower triangle (row a at
-  // a(a+1)/2), Km packed STRICTLY lower triangle of L (row k at k(k-1)/2) -- 31 -> 25 KB at T = 10,
-  // 93 -> 68 KB at T = 20, where it decides whether two QP workgroups fit a CU's LDS
+  // a(a+1)/2), Km = L as a full [nu][nu+1] matrix whose diagonal and upper triangle stay ZERO: the substitutions read
+  // row `lane` (forward) and column `lane` (backward) of it with no lane predicates and no copy of L in registers
   double* Yt = Phi + (size_t)T * 3 * ldp;
   double* Hm = Yt + (TT > 0 ? (size_t)T * 6 : (size_t)T * 2 * ldp);
   double* Km = Hm + (TT > 0 ? (size_t)nu * (nu + 1) / 2 : (size_t)nu * ldk);
-  double* cv = Km + (TT > 0 ? (size_t)nu * (nu - 1) / 2 + 2 : (size_t)nu * ldk);    // [T][3]
+  double* cv = Km + (size_t)nu * ldk;         // [T][3]
   double* lin = cv + T * 3;                   // [T][3]  state-cost gradient at u = 0
   double* s3 = lin + T * 3;                   // [T][3]  Phi x   /  Phi dx
   double* q3 = s3 + T * 3;                    // [T][3]  operand of Phi'
   double* Abc = q3 + T * 3;                   // [T][12]
   double* St = Abc + T * 12;                  // [T][8]  S'00 S'01 S'11 v0 v1 sigma 1/kappa r1d
-  double* xu = St + T * 8;                    // [nu]
+  double* xu = St + T * 8;                    // [nu]    (xu, xd contiguous: the pairs index them as one vector)
   double* xd = xu + nu;                       // [T]
   double* xbest = xd + T;                     // [nu+T]
-  double* dxu = xbest + nu + T;               // [nu]
+  double* dxu = xbest + nu + T;               // [nu]    (dxu, dxd contiguous)
   double* dxd = dxu + nu;                     // [T]
   double* invd = dxd + T;                     // [nu]   1/L_kk
-  double* fa0 = invd + nu;                    // [mf] ...
-  double* fa1 = fa0 + mf;
-  double* ff = fa1 + mf;
-  double* lf = ff + mf;
-  double* wf = lf + mf;
-  double* dlf = wf + mf;
-  double* dwf = dlf + mf;
-  double* r3 = dwf + mf;
-  double* iwf = r3 + mf;                      // 1/(wf + lf/ro)
-  double* lc = iwf + mf;                      // [mcu] ...
-  double* wc = lc + mcu;
-  double* dlc = wc + mcu;
-  double* dwc = dlc + mcu;
-  double* r2 = dwc + mcu;
-  double* iwc = r2 + mcu;                     // 1/wc
-  double* ld_ = iwc + mcu;                    // [2T] d rows: index 2t (d<=dmax), 2t+1 (-d<=-dmin0)
-  double* wd = ld_ + 2 * T;
-  double* dld = wd + 2 * T;
-  double* dwd = dld + 2 * T;
-  double* r2d = dwd + 2 * T;
-  double* iwd = r2d + 2 * T;
-  unsigned char* pa = reinterpret_cast<unsigned char*>(iwd + 2 * T);   // [npair]
+  unsigned char* pa = reinterpret_cast<unsigned char*>(invd + nu);     // [npair]
   unsigned char* pc = pa + ((npair + 7) & ~7);
-  unsigned char* cact = pc + ((npair + 7) & ~7);                       // [mcu] 1 = bound finite
 
   const float* s_in = cur_s_in + (size_t)b * 3 * (T + 1);
   const float* u_in = cur_u_in + (size_t)b * 2 * T;
@@ -268,19 +303,18 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
     while (a * (a + 1) / 2 > p) --a;
     pa[p] = (unsigned char)a; pc[p] = (unsigned char)(p - a * (a + 1) / 2);
   }
-  for (int i = lane; i < mcu; i += QP_THREADS) {
-    int v = (i < 4 * T) ? (i >> 1) : ((i - 4 * T) >> 1);
-    double bd = (i < 4 * T) ? P.speed_bound[v & 1] : P.acce_bound[v & 1];
-    bool act = isfinite(bd);
-    cact[i] = act ? 1 : 0;
-  }
-  // bound of u row i (two speed and two rate bounds: selected by index, not stored per row)
+  // bounds of the u rows (0 where infinite: the pair is switched off through its actf).  (No run-time index into P
+  // anywhere in this kernel: one would move the whole by-value struct to scratch memory.)
   const double sb0 = isfinite(P.speed_bound[0]) ? P.speed_bound[0] : 0.0, sb1 = isfinite(P.speed_bound[1]) ? P.speed_bound[1] : 0.0;
   const double ab0 = isfinite(P.acce_bound[0]) ? P.acce_bound[0] : 0.0, ab1 = isfinite(P.acce_bound[1]) ? P.acce_bound[1] : 0.0;
-  auto cb_of = [&](int i) -> double {
-    const bool odd = (((i < 4 * T) ? i : i - 4 * T) >> 1) & 1;
-    return (i < 4 * T) ? (odd ? sb1 : sb0) : (odd ? ab1 : ab0);
-  };
+  const double sf0 = isfinite(P.speed_bound[0]) ? 1.0 : 0.0, sf1 = isfinite(P.speed_bound[1]) ? 1.0 : 0.0;
+  const double af0 = isfinite(P.acce_bound[0]) ? 1.0 : 0.0, af1 = isfinite(P.acce_bound[1]) ? 1.0 : 0.0;
+  const int npu = mcu >> 1, npc = npu + (obs ? T : 0);
+#define PAIR_C(p) qp_pair((p), T, npu, sb0, sb1, ab0, ab1, sf0, sf1, af0, af1, dmaxv, dmin0)
+  // hinge rows two at a time (rows 2l, 2l + 1 of step t = 2l / M) when M is even
+  constexpr bool HPAIR = TT > 0 && MM > 0 && (MM % 2) == 0;
+  if constexpr (TT > 0)
+    for (int q = lane; q < nu * ldk; q += QP_THREADS) Km[q] = 0.0;
   LSYNC();
 
   // ---- Phi recursion: Phi[t] = A_t Phi[t-1] + [B_t at cols 2t,2t+1]; A = I + e0 A02 e2' + e1 A12 e2'
@@ -332,9 +366,10 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
   double hdiag = 0, hoff = 0;
   for (int q = lane; q < 3 * T; q += QP_THREADS) {
     int t = q / 3, k = q - 3 * t;
-    double qk = P.q_s[k], mk = (k == 2) ? m2 : 1.0, c = cv[q];
+    const float qsk = k == 0 ? P.q_s[0] : (k == 1 ? P.q_s[1] : P.q_s[2]);
+    double qk = qsk, mk = (k == 2) ? m2 : 1.0, c = cv[q];
     // gamma_a = q_s * ref_s is an fp32 product in the reference (nrmp.py:158)
-    double r = (double)__fmul_rn(P.q_s[k], rs[k * (T + 1) + t + 1]);
+    double r = (double)__fmul_rn(qsk, rs[k * (T + 1) + t + 1]);
     lin[q] = 2.0 * mk * qk * (qk * c - r) + P.bk * (c - (double)s_in[k * (T + 1) + t + 1]);
   }
 
@@ -347,7 +382,9 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
       float l0 = lam_sorted[row * 2], l1 = lam_sorted[row * 2 + 1];
       float tmp = fmaf(l1, pts_sorted[row * 2 + 1], __fmul_rn(l0, pts_sorted[row * 2]));
       float mh = 0.f;
-      for (int e = 0; e < E; ++e) mh = fmaf(mu_sorted[row * E + e], P.h[e], mh);
+#pragma unroll
+      for (int e = 0; e < NPA_MAX_E; ++e)
+        if (e < E) mh = fmaf(mu_sorted[row * E + e], P.h[e], mh);
       a0 = l0; a1 = l1; fb = (double)__fadd_rn(tmp, mh);
     }
     fa0[i] = a0; fa1[i] = a1;
@@ -365,9 +402,11 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
   // ---- starting point: u = 0, d mid-range, unit multipliers, slacks >= 1 --------------------
   const double d0 = 0.5 * (dmin0 + dmaxv);
   double cmax = fmax(fabs(dmaxv), fabs(dmin0));
-  int m_act = 0;
-  for (int i = lane; i < mcu; i += QP_THREADS)
-    if (cact[i]) { cmax = fmax(cmax, fabs(cb_of(i))); ++m_act; }
+  double m_act = 0;
+  for (int p = lane; p < npu; p += QP_THREADS) {
+    const PairC c = PAIR_C(p);
+    if (c.actf != 0.0) { cmax = fmax(cmax, fabs(c.bp)); m_act += 2.0; }
+  }
   QP_COLD_INIT();
   double gmax = obs ? (double)P.eta : 0.0;
   // g_u = Phi' lin - 2 p_u gamma_b on the speed entries
@@ -381,7 +420,7 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
     gmax = fmax(gmax, fabs(acc));
   }
   const double scale_d = 1.0 + wave_reduce<OpMax>(gmax), scale_p = 1.0 + wave_reduce<OpMax>(cmax);
-  const double m_tot = fmax(wave_reduce<OpSum>((double)m_act) + (double)mf + (obs ? 2.0 * T : 0.0), 1.0);
+  const double m_tot = fmax(wave_reduce<OpSum>(m_act) + (double)mf + (obs ? 2.0 * T : 0.0), 1.0);
   const double inv_m = 1.0 / m_tot;
   const double pub = (lane < nu && !(lane & 1)) ? -2.0 * pu * (double)__fmul_rn(P.p_u, rus[lane >> 1]) : 0.0;
   LSYNC();
@@ -476,19 +515,14 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
       lf[i] = l;
       wf[i] = fmax(fa0[i] * s3[t * 3] + fa1[i] * s3[t * 3 + 1] - xd[t] - ff[i] + l * iro, dl);
     }
-    for (int i = lane; i < mcu; i += QP_THREADS) {
-      if (cact[i]) {
-        int v = (i < 4 * T) ? (i >> 1) : ((i - 4 * T) >> 1);
-        double sg = (i & 1) ? -1.0 : 1.0;
-        double cx = (i < 4 * T) ? sg * xu[v] : sg * (xu[v + 2] - xu[v]);
-        lc[i] = fmax(wrm[nu + T + mf + i], dl);
-        wc[i] = fmax(cb_of(i) - cx, dl);
+    for (int p = lane; p < npc; p += QP_THREADS) {
+      const PairC c = PAIR_C(p);
+      if (c.actf != 0.0) {
+        const double cx = fma(-c.sb, xu[c.ib], xu[c.ia]);
+        const double* wl = wrm + nu + T + mf + 2 * p;          // (lc then ld in the record, like the rows)
+        st2(lc + 2 * p, fmax(wl[0], dl), fmax(wl[1], dl));
+        st2(wc + 2 * p, fmax(c.bp - cx, dl), fmax(c.bm + cx, dl));
       }
-    }
-    for (int i = lane; i < 2 * T && obs; i += QP_THREADS) {
-      int t = i >> 1;
-      ld_[i] = fmax(wrm[nu + T + mf + mcu + i], dl);
-      wd[i] = fmax((i & 1) ? xd[t] - dmin0 : dmaxv - xd[t], dl);
     }
     LSYNC();
   }
@@ -501,43 +535,50 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
       }
     }
     // ================= residuals =================
+    PROF_B(8); PROF_C(8);
     phi_mul(xu, s3);
     LSYNC();
+    PROF_B(1);
     double gap = 0, rpmax = 0;
-    for (int i = lane; i < mf; i += QP_THREADS) {
-      int t = i / M;
-      double l = lf[i], w = wf[i];
-      double r = fa0[i] * s3[t * 3] + fa1[i] * s3[t * 3 + 1] - xd[t] - ff[i] + l * iro - w;
-      r3[i] = r;
-      iwf[i] = fast_rcp(w + l * iro);
-      rpmax = fmax(rpmax, fabs(r));
-      gap += l * w;
-    }
-    for (int i = lane; i < mcu; i += QP_THREADS) {
-      double r = 0;
-      if (cact[i]) {
-        int v = (i < 4 * T) ? (i >> 1) : ((i - 4 * T) >> 1);
-        double sg = (i & 1) ? -1.0 : 1.0;
-        double cx = (i < 4 * T) ? sg * xu[v] : sg * (xu[v + 2] - xu[v]);
-        r = cx + wc[i] - cb_of(i);
-        gap += lc[i] * wc[i];
+    if constexpr (HPAIR) {
+      for (int h = lane; h < mf / 2; h += QP_THREADS) {
+        const int t = h / (MM / 2), i = 2 * h;
+        const double2 l = ld2(lf + i), w = ld2(wf + i), a0 = ld2(fa0 + i), a1 = ld2(fa1 + i), f = ld2(ff + i);
+        const double sx = s3[t * 3], sy = s3[t * 3 + 1], d = xd[t];
+        const double rx = a0.x * sx + a1.x * sy - d - f.x + l.x * iro - w.x;
+        const double ry = a0.y * sx + a1.y * sy - d - f.y + l.y * iro - w.y;
+        st2(r3 + i, rx, ry);
+        st2(iwf + i, fast_rcp(w.x + l.x * iro), fast_rcp(w.y + l.y * iro));
+        rpmax = fmax(rpmax, fmax(fabs(rx), fabs(ry)));
+        gap += l.x * w.x + l.y * w.y;
       }
-      r2[i] = r;
-      iwc[i] = fast_rcp(wc[i]);
-      rpmax = fmax(rpmax, fabs(r));
+    } else {
+      for (int i = lane; i < mf; i += QP_THREADS) {
+        int t = i / M;
+        double l = lf[i], w = wf[i];
+        double r = fa0[i] * s3[t * 3] + fa1[i] * s3[t * 3 + 1] - xd[t] - ff[i] + l * iro - w;
+        r3[i] = r;
+        iwf[i] = fast_rcp(w + l * iro);
+        rpmax = fmax(rpmax, fabs(r));
+        gap += l * w;
+      }
     }
-    for (int i = lane; i < 2 * T && obs; i += QP_THREADS) {
-      int t = i >> 1;
-      double r = (i & 1) ? (-xd[t] + wd[i] + dmin0) : (xd[t] + wd[i] - dmaxv);
-      r2d[i] = r;
-      iwd[i] = fast_rcp(wd[i]);
-      rpmax = fmax(rpmax, fabs(r));
-      gap += ld_[i] * wd[i];
+    PROF_B(2);
+    for (int p = lane; p < npc; p += QP_THREADS) {
+      const PairC c = PAIR_C(p);
+      const double2 l = ld2(lc + 2 * p), w = ld2(wc + 2 * p);
+      const double cx = fma(-c.sb, xu[c.ib], xu[c.ia]);
+      const double rp = (cx + w.x - c.bp) * c.actf, rm = (w.y - cx - c.bm) * c.actf;
+      st2(r2 + 2 * p, rp, rm);
+      st2(iwc + 2 * p, fast_rcp(w.x), fast_rcp(w.y));
+      rpmax = fmax(rpmax, fmax(fabs(rp), fabs(rm)));
+      gap += l.x * w.x + l.y * w.y;             // (a switched-off pair keeps l = 0)
     }
     LSYNC();
+    PROF_B(3);
     // per-step sums over the M hinge rows (lane = t)
     double r1dmax = 0;
-    double S0r = 0, S1r = 0, S2r = 0, v0r = 0, v1r = 0, ikr = 0, r1dr = 0;
+    double S0r = 0, S1r = 0, S2r = 0;          // (v, 1/kappa, r1_d of step t are re-read from St by the passes: registers)
     for (int t = lane; t < T; t += QP_THREADS) {
       double z0 = 0, z1 = 0, zs = 0, s00 = 0, s01 = 0, s11 = 0, v0 = 0, v1 = 0, sg = 0;
 #pragma unroll 5
@@ -562,15 +603,17 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
       q3[t * 3 + 1] = W1 * s3[t * 3 + 1] + lin[t * 3 + 1] - z1;
       q3[t * 3 + 2] = W2 * s3[t * 3 + 2] + lin[t * 3 + 2];
       r1dmax = fmax(r1dmax, fabs(r1d));
-      S0r = S[0]; S1r = S[1]; S2r = S[2]; v0r = v0; v1r = v1; ikr = ik; r1dr = r1d;
+      S0r = S[0]; S1r = S[1]; S2r = S[2];
     }
     LSYNC();
+    PROF_B(4);
     double r1u = phi_tmul(q3);                     // lane a < nu
     if (lane < nu) {
       const int a = lane;
       if (!(a & 1)) r1u += 2.0 * pu * pu * xu[a] + pub;
       r1u += ct_mul(lc, a);
     }
+    PROF_B(5);
     const double mu = wave_reduce<OpSum>(gap) * inv_m;
     const double r1max = wave_reduce<OpMax>(fmax(lane < nu ? fabs(r1u) : 0.0, r1dmax));
     const double rpm = wave_reduce<OpMax>(rpmax);
@@ -620,10 +663,10 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
         break;
       }
     }
-    PROF(1);
+    PROF(1); PROF_B(6);
 
     // ================= reduced KKT matrix, Cholesky =================
-    double arow[NU], bcol[NU];          // fast path: row `lane` of K' -> L, column `lane` of L
+    double arow[NU];                    // fast path: row `lane` of K' -> L (lives through the factorisation only)
     double myinv = 1.0;
     bool chol_ok = true;
     if constexpr (TT > 0) {
@@ -672,38 +715,33 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
         for (int c = 0; c < NU; ++c) {
           // (entries c > ar read other rows of the packed triangle: finite, and never used)
           arow[c] = fma(g0, Ph[c], fma(g1, Ph[ldp + c], fma(g2, Ph[2 * ldp + c], Hm[ar * (ar + 1) / 2 + c])));
+          // (keep the scheduler from issuing all 4 NU loads ahead of the arithmetic: that is where the register
+          // demand of this kernel peaked, above the 256 a wave may hold at two waves per SIMD)
+          if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
       }
       PROF(3);
-      // right-looking Cholesky, row i in lane i: after step k, arow[k] = L[i][k] (entries above the
-      // diagonal fill with unused garbage)
+      // right-looking Cholesky, row i in lane i: after step k, arow[k] = L[i][k] for i > k (the entries a lane
+      // computes on and above its diagonal are unused garbage and are not stored)
 #pragma unroll
       for (int k = 0; k < NU; ++k) {
         double piv = readlane_f64(arow[k], k);
         if (!(piv > 0.0)) chol_ok = false;
         double rinv = fast_rsqrt(piv);
         double l = arow[k] * rinv;
-        arow[k] = l;
         invd[k] = rinv;                      // uniform value, every lane stores it
+        arow[k] = l;
 #pragma unroll
         for (int j = k + 1; j < NU; ++j) arow[j] = fma(-l, readlane_f64(l, j), arow[j]);
       }
-      // keep the strictly lower part only (the substitutions below then need no lane predicates),
-      // and fetch the columns of L through LDS: bcol[k] = L[k][lane] for k > lane, else 0
-#pragma unroll
-      for (int c = 0; c < NU; ++c) arow[c] = (c < lane) ? arow[c] : 0.0;
+      // park the strictly lower part of row `lane` in the zero-padded LDS copy of L
       if (lane < NU) {
 #pragma unroll
         for (int c = 0; c < NU - 1; ++c)
-          if (c < lane) Km[lane * (lane - 1) / 2 + c] = arow[c];
+          if (c < lane) Km[lane * ldk + c] = arow[c];
       }
       LSYNC();
       myinv = invd[ar];
-#pragma unroll
-      for (int k = 0; k < NU; ++k) {
-        const double v = Km[k * (k - 1) / 2 + ar];        // row k holds columns 0..k-1
-        bcol[k] = k > ar ? v : 0.0;
-      }
     } else {
     for (int q = lane; q < 2 * T * nu; q += QP_THREADS) {        // Y[t][k][c] = S'_t[k][:] Phi_xy[t][:, c]
       int tk = q / nu, c = q - tk * nu, t = tk >> 1, k = tk & 1;
@@ -775,60 +813,86 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
         const float* gs = bw.grad_s + (size_t)b * 3 * (T + 1);
         for (int q = lane; q < 3 * T; q += QP_THREADS) {
           int t = q / 3, k = q - 3 * t;
-          double refv = (double)__fmul_rn(P.q_s[k], rs[k * (T + 1) + t + 1]) / (P.q_s[k] != 0.f ? (double)P.q_s[k] : 1.0);
+          const float qsk = k == 0 ? P.q_s[0] : (k == 1 ? P.q_s[1] : P.q_s[2]);
+          double refv = (double)__fmul_rn(qsk, rs[k * (T + 1) + t + 1]) / (qsk != 0.f ? (double)qsk : 1.0);
           lin[q] = (s3[q] + cv[q]) - refv;
           q3[q] = (double)gs[k * (T + 1) + t + 1];
         }
         LSYNC();
         r1u = phi_tmul(q3);
         if (lane < nu) r1u = -(r1u + (double)bw.grad_u[(size_t)b * 2 * T + (lane & 1) * T + (lane >> 1)]);
-        r1dr = (lane < T && bw.grad_d) ? -(double)bw.grad_d[(size_t)b * T + lane] : 0.0;
+        if (lane < T) St[lane * 8 + 7] = bw.grad_d ? -(double)bw.grad_d[(size_t)b * T + lane] : 0.0;
         LSYNC();
       }
     }
     // ================= predictor / corrector =================
     double sigma_mu = 0, alpha = 1.0;
+#pragma nounroll
     for (int pass = 0; pass < (adj ? 1 : 2); ++pass) {
+      PROF_C(7);
       // per-row weights of the rhs, staged in dwf/dwc/dwd (overwritten by the directions below)
       //   tfw = (r4f + lf r3)/(wf + lf/ro) ; tcw = (lc r2 - r4c)/wc ; r4 = lam w [+ dw dl - sigma mu]
-      for (int i = lane; i < mf; i += QP_THREADS) {
-        double r4 = lf[i] * wf[i] + (pass ? dwf[i] * dlf[i] - sigma_mu : 0.0);
-        dwf[i] = adj ? 0.0 : (r4 + lf[i] * r3[i]) * iwf[i];
+      // (pass 0 must not read dw / dl: they hold the previous iteration's directions, nothing at all in the first one)
+      if constexpr (HPAIR) {
+        for (int h = lane; h < mf / 2; h += QP_THREADS) {
+          const int i = 2 * h;
+          const double2 l = ld2(lf + i), w = ld2(wf + i), r = ld2(r3 + i), iw = ld2(iwf + i);
+          double r4x = l.x * w.x, r4y = l.y * w.y;
+          if (pass) { const double2 pw = ld2(dwf + i), pl = ld2(dlf + i); r4x += pw.x * pl.x - sigma_mu; r4y += pw.y * pl.y - sigma_mu; }
+          st2(dwf + i, adj ? 0.0 : (r4x + l.x * r.x) * iw.x, adj ? 0.0 : (r4y + l.y * r.y) * iw.y);
+        }
+      } else {
+        for (int i = lane; i < mf; i += QP_THREADS) {
+          double r4 = lf[i] * wf[i] + (pass ? dwf[i] * dlf[i] - sigma_mu : 0.0);
+          dwf[i] = adj ? 0.0 : (r4 + lf[i] * r3[i]) * iwf[i];
+        }
       }
-      for (int i = lane; i < mcu; i += QP_THREADS) {
-        double r4 = lc[i] * wc[i] + (pass ? dwc[i] * dlc[i] - sigma_mu : 0.0);
-        dwc[i] = (cact[i] && !adj) ? (lc[i] * r2[i] - r4) * iwc[i] : 0.0;
-      }
-      for (int i = lane; i < 2 * T && obs; i += QP_THREADS) {
-        double r4 = ld_[i] * wd[i] + (pass ? dwd[i] * dld[i] - sigma_mu : 0.0);
-        dwd[i] = adj ? 0.0 : (ld_[i] * r2d[i] - r4) * iwd[i];
+      for (int p = lane; p < npc; p += QP_THREADS) {
+        const int i = 2 * p;
+        const double af = adj ? 0.0 : PAIR_C(p).actf;
+        const double2 l = ld2(lc + i), w = ld2(wc + i), r = ld2(r2 + i), iw = ld2(iwc + i);
+        double r4x = l.x * w.x, r4y = l.y * w.y;
+        if (pass) { const double2 pw = ld2(dwc + i), pl = ld2(dlc + i); r4x += pw.x * pl.x - sigma_mu; r4y += pw.y * pl.y - sigma_mu; }
+        st2(dwc + i, af * ((l.x * r.x - r4x) * iw.x), af * ((l.y * r.y - r4y) * iw.y));
       }
       LSYNC();
+      PROF_C(1);
       double pq0 = 0, pq1 = 0, rdr = 0;
       for (int t = lane; t < T; t += QP_THREADS) {
         double z0 = 0, z1 = 0, zs = 0;
 #pragma unroll 5
         for (int j = 0; j < M; ++j) { int i = t * M + j; double w = dwf[i]; z0 += w * fa0[i]; z1 += w * fa1[i]; zs += w; }
         double rd = 0;
-        if (obs) rd = -r1dr - (dwd[2 * t] - dwd[2 * t + 1]) + zs;          // rhs of the d rows
-        double e = rd * ikr;                                                // rhs_d / kappa
+        const double* S = St + t * 8;                                       // v0 v1 at [3] [4], 1/kappa [6], r1_d [7]
+        if (obs) rd = -S[7] - (dwd[2 * t] - dwd[2 * t + 1]) + zs;           // rhs of the d rows
+        double e = rd * S[6];                                               // rhs_d / kappa
         rdr = rd;
-        pq0 = -(z0 - v0r * e);
-        pq1 = -(z1 - v1r * e);
+        pq0 = -(z0 - S[3] * e);
+        pq1 = -(z1 - S[4] * e);
         q3[t * 3 + 0] = pq0; q3[t * 3 + 1] = pq1; q3[t * 3 + 2] = 0.0;
       }
       double rr;
       PROF(5);
       LSYNC();
+      PROF_C(2);
       rr = phi_tmul(q3);
       if (lane < nu) rr += -r1u - ct_mul(dwc, lane);
+      PROF_C(3);
       if constexpr (TT > 0) {
-        // forward substitution L y = rhs, backward L' dx = y; lane i owns entry i, L in registers
+        // forward substitution L y = rhs, backward L' dx = y; lane i owns entry i and reads row i / column i of the
+        // zero-padded L (loads that do not depend on the chain: they are issued ahead of it)
+        const int lr = lane < NU ? lane : 0;
+        double Lrow[NU], Lcol[NU];
 #pragma unroll
-        for (int k = 0; k < NU; ++k) rr = fma(-arow[k], readlane_f64(rr * myinv, k), rr);
+        for (int k = 0; k < NU; ++k) Lrow[k] = Km[lr * ldk + k];
+        __builtin_amdgcn_sched_barrier(0);           // all of row `lane` is on its way before the chain starts
+#pragma unroll
+        for (int k = 0; k < NU; ++k) Lcol[k] = Km[k * ldk + lr];     // (free to overlap the forward chain)
+#pragma unroll
+        for (int k = 0; k < NU; ++k) rr = fma(-Lrow[k], readlane_f64(rr * myinv, k), rr);
         rr *= myinv;                         // y
 #pragma unroll
-        for (int k = NU - 1; k >= 0; --k) rr = fma(-bcol[k], readlane_f64(rr * myinv, k), rr);
+        for (int k = NU - 1; k >= 0; --k) rr = fma(-Lcol[k], readlane_f64(rr * myinv, k), rr);
         rr *= myinv;                         // dx_u
       } else {
         for (int k = 0; k < nu; ++k) {
@@ -844,51 +908,67 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
       }
       if (lane < nu) dxu[lane] = rr;
       LSYNC();
-      PROF(6);
+      PROF(6); PROF_C(4);
       phi_mul(dxu, s3);
       LSYNC();
       for (int t = lane; t < T && obs; t += QP_THREADS)
-        dxd[t] = (rdr + v0r * s3[t * 3] + v1r * s3[t * 3 + 1]) * ikr;
+        dxd[t] = (rdr + St[t * 8 + 3] * s3[t * 3] + St[t * 8 + 4] * s3[t * 3 + 1]) * St[t * 8 + 6];
       LSYNC();
+      PROF_C(5);
       // directions of multipliers / slacks and the step to the boundary
       double amax = 1.0, gap_aff = 0;
-      for (int i = lane; i < mf; i += QP_THREADS) {
-        int t = i / M;
-        double l = lf[i], w = wf[i];
-        double Fdx = fa0[i] * s3[t * 3] + fa1[i] * s3[t * 3 + 1] - dxd[t];
-        double dl = -(dwf[i] + l * Fdx * iwf[i]);             // -(r4 + l r3 + l Fdx)/(w + l/ro)
-        double dw = Fdx + dl * iro + r3[i];
+      // step to the boundary of one row: dl, dw < 0 bound alpha by -l/dl, -w/dw
+      auto ratio = [&](double l, double dl, double w, double dw) {
         if (dl < 0) amax = fmin(amax, -l * rough_rcp(dl));
         if (dw < 0) amax = fmin(amax, -w * rough_rcp(dw));
-        dlf[i] = dl; dwf[i] = dw;
-      }
-      for (int i = lane; i < mcu; i += QP_THREADS) {
-        double dl = 0, dw = 0;
-        if (cact[i]) {
-          int v = (i < 4 * T) ? (i >> 1) : ((i - 4 * T) >> 1);
-          double sg = (i & 1) ? -1.0 : 1.0;
-          double Cdx = (i < 4 * T) ? sg * dxu[v] : sg * (dxu[v + 2] - dxu[v]);
-          dl = dwc[i] + lc[i] * Cdx * iwc[i];                   // (lc r2 - r4 + lc Cdx)/wc
-          dw = -r2[i] - Cdx;
-          if (dl < 0) amax = fmin(amax, -lc[i] * rough_rcp(dl));
-          if (dw < 0) amax = fmin(amax, -wc[i] * rough_rcp(dw));
+      };
+      if constexpr (HPAIR) {
+        for (int h = lane; h < mf / 2; h += QP_THREADS) {
+          const int t = h / (MM / 2), i = 2 * h;
+          const double2 l = ld2(lf + i), w = ld2(wf + i), a0 = ld2(fa0 + i), a1 = ld2(fa1 + i), iw = ld2(iwf + i), tw = ld2(dwf + i), r = ld2(r3 + i);
+          const double sx = s3[t * 3], sy = s3[t * 3 + 1], d = dxd[t];
+          const double Fx = a0.x * sx + a1.x * sy - d, Fy = a0.y * sx + a1.y * sy - d;
+          const double dlx = -(tw.x + l.x * Fx * iw.x), dly = -(tw.y + l.y * Fy * iw.y);       // -(r4 + l r3 + l Fdx)/(w + l/ro)
+          const double dwx = Fx + dlx * iro + r.x, dwy = Fy + dly * iro + r.y;
+          ratio(l.x, dlx, w.x, dwx); ratio(l.y, dly, w.y, dwy);
+          st2(dlf + i, dlx, dly); st2(dwf + i, dwx, dwy);
         }
-        dlc[i] = dl; dwc[i] = dw;
+      } else {
+        for (int i = lane; i < mf; i += QP_THREADS) {
+          int t = i / M;
+          double l = lf[i], w = wf[i];
+          double Fdx = fa0[i] * s3[t * 3] + fa1[i] * s3[t * 3 + 1] - dxd[t];
+          double dl = -(dwf[i] + l * Fdx * iwf[i]);             // -(r4 + l r3 + l Fdx)/(w + l/ro)
+          double dw = Fdx + dl * iro + r3[i];
+          ratio(l, dl, w, dw);
+          dlf[i] = dl; dwf[i] = dw;
+        }
       }
-      for (int i = lane; i < 2 * T && obs; i += QP_THREADS) {
-        int t = i >> 1;
-        double Cdx = (i & 1) ? -dxd[t] : dxd[t];
-        double dl = dwd[i] + ld_[i] * Cdx * iwd[i];
-        double dw = -r2d[i] - Cdx;
-        if (dl < 0) amax = fmin(amax, -ld_[i] * rough_rcp(dl));
-        if (dw < 0) amax = fmin(amax, -wd[i] * rough_rcp(dw));
-        dld[i] = dl; dwd[i] = dw;
+      for (int p = lane; p < npc; p += QP_THREADS) {
+        const PairC c = PAIR_C(p);
+        const int i = 2 * p;
+        const double2 l = ld2(lc + i), w = ld2(wc + i), iw = ld2(iwc + i), tw = ld2(dwc + i), r = ld2(r2 + i);
+        const double Cdx = fma(-c.sb, dxu[c.ib], dxu[c.ia]);
+        const double dlx = tw.x + l.x * Cdx * iw.x, dly = tw.y - l.y * Cdx * iw.y;           // (l r2 - r4 + l Cdx)/w
+        const double dwx = (-r.x - Cdx) * c.actf, dwy = (Cdx - r.y) * c.actf;
+        ratio(l.x, dlx, w.x, dwx); ratio(l.y, dly, w.y, dwy);
+        st2(dlc + i, dlx, dly); st2(dwc + i, dwx, dwy);
       }
+      PROF_C(6);
       amax = wave_reduce<OpMin>(amax);
       if (pass == 0) {
-        for (int i = lane; i < mf; i += QP_THREADS) gap_aff += (lf[i] + amax * dlf[i]) * (wf[i] + amax * dwf[i]);
-        for (int i = lane; i < mcu; i += QP_THREADS) gap_aff += (lc[i] + amax * dlc[i]) * (wc[i] + amax * dwc[i]);
-        for (int i = lane; i < 2 * T && obs; i += QP_THREADS) gap_aff += (ld_[i] + amax * dld[i]) * (wd[i] + amax * dwd[i]);
+        if constexpr (HPAIR) {
+          for (int h = lane; h < mf / 2; h += QP_THREADS) {
+            const double2 l = ld2(lf + 2 * h), w = ld2(wf + 2 * h), dl = ld2(dlf + 2 * h), dw = ld2(dwf + 2 * h);
+            gap_aff += (l.x + amax * dl.x) * (w.x + amax * dw.x) + (l.y + amax * dl.y) * (w.y + amax * dw.y);
+          }
+        } else {
+          for (int i = lane; i < mf; i += QP_THREADS) gap_aff += (lf[i] + amax * dlf[i]) * (wf[i] + amax * dwf[i]);
+        }
+        for (int p = lane; p < npc; p += QP_THREADS) {          // (switched-off pairs: l = dl = 0)
+          const double2 l = ld2(lc + 2 * p), w = ld2(wc + 2 * p), dl = ld2(dlc + 2 * p), dw = ld2(dwc + 2 * p);
+          gap_aff += (l.x + amax * dl.x) * (w.x + amax * dw.x) + (l.y + amax * dl.y) * (w.y + amax * dw.y);
+        }
         double mu_aff = wave_reduce<OpSum>(gap_aff) * inv_m;
         double sg = mu_aff / mu;
         sigma_mu = sg * sg * sg * mu;
@@ -896,7 +976,7 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
         alpha = fmin(1.0, 0.995 * amax);
       }
       LSYNC();
-      PROF(7);
+      PROF(7); PROF_C(7);
     }
     if constexpr (BWD) {
       if (adj) {
@@ -940,9 +1020,18 @@ __global__ __launch_bounds__(QP_THREADS * QP_WAVES) void nrmp_qp_kernel(
     }
     for (int a = lane; a < nu; a += QP_THREADS) xu[a] += alpha * dxu[a];
     for (int t = lane; t < T && obs; t += QP_THREADS) xd[t] += alpha * dxd[t];
-    for (int i = lane; i < mf; i += QP_THREADS) { lf[i] += alpha * dlf[i]; wf[i] += alpha * dwf[i]; }
-    for (int i = lane; i < mcu; i += QP_THREADS) { lc[i] += alpha * dlc[i]; wc[i] += alpha * dwc[i]; }
-    for (int i = lane; i < 2 * T && obs; i += QP_THREADS) { ld_[i] += alpha * dld[i]; wd[i] += alpha * dwd[i]; }
+    if constexpr (HPAIR) {
+      for (int h = lane; h < mf / 2; h += QP_THREADS) {
+        const double2 l = ld2(lf + 2 * h), w = ld2(wf + 2 * h), dl = ld2(dlf + 2 * h), dw = ld2(dwf + 2 * h);
+        st2(lf + 2 * h, l.x + alpha * dl.x, l.y + alpha * dl.y); st2(wf + 2 * h, w.x + alpha * dw.x, w.y + alpha * dw.y);
+      }
+    } else {
+      for (int i = lane; i < mf; i += QP_THREADS) { lf[i] += alpha * dlf[i]; wf[i] += alpha * dwf[i]; }
+    }
+    for (int p = lane; p < npc; p += QP_THREADS) {
+      const double2 l = ld2(lc + 2 * p), w = ld2(wc + 2 * p), dl = ld2(dlc + 2 * p), dw = ld2(dwc + 2 * p);
+      st2(lc + 2 * p, l.x + alpha * dl.x, l.y + alpha * dl.y); st2(wc + 2 * p, w.x + alpha * dw.x, w.y + alpha * dw.y);
+    }
     LSYNC();
     PROF(8);
   }
@@ -1091,11 +1180,11 @@ static bool qp_fast_path(int T, int M) { return (T == 10 || T == 20) && M == 10;
 extern "C" size_t npa_qp_shmem_bytes_path(int T, int M, int fast) {
   const bool obs = M > 0;
   size_t nu = 2 * T, ldp = nu + 1, mcu = 8 * T - 4, mf = obs ? (size_t)T * M : 0, npair = nu * (nu + 1) / 2;
-  const size_t mats = fast ? (size_t)T * 6 + nu * (nu + 1) / 2 + nu * (nu - 1) / 2 + 2
+  const size_t mats = fast ? (size_t)T * 6 + nu * (nu + 1) / 2 + nu * ldp
                            : (size_t)T * 2 * ldp + 2 * nu * ldp;
   size_t d = (size_t)T * 3 * ldp + mats + 4 * (T * 3) + T * 12 + T * 8 + nu + T +
-             (nu + T) + nu + T + nu + 9 * mf + 6 * mcu + 6 * 2 * T;
-  size_t bytes = d * sizeof(double) + 2 * ((npair + 7) & ~(size_t)7) + ((mcu + 7) & ~(size_t)7);
+             (nu + T) + nu + T + nu + 9 * ((mf + 1) & ~(size_t)1) + 6 * mcu + 6 * 2 * T;
+  size_t bytes = d * sizeof(double) + 2 * ((npair + 7) & ~(size_t)7);
   return (bytes + 15) & ~(size_t)15;
 }
 
@@ -1111,17 +1200,9 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
                                     float* dbg_f, double* dbg_x,
                                     hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
   static const bool force_generic = getenv("NPA_QP_GENERIC") != nullptr;     // tests: the generic (LDS) instantiation for every (T, M)
-  const bool low_prio = false;
   const bool fast = qp_fast_path(P.T, P.M) && !force_generic;
-  const size_t wave_bytes = npa_qp_shmem_bytes_path(P.T, P.M, fast ? 1 : 0);
-  // One scene (wave) per workgroup by default: the dispatcher then spreads the QP waves of a launch
-  // evenly over the CUs, so that DUNE workgroups of other batches in flight are slowed uniformly
-  // (they balance inside a CU through their LDS ticket, not across CUs).  NPA_QP_WPG=2..4 packs
-  // scenes per workgroup (as many as LDS allows).
-  const int wpg = 1;
-  const size_t shmem = wave_bytes * wpg;
-  const int wave_doubles = (int)(wave_bytes / sizeof(double));
-  const int nblocks = (batch + wpg - 1) / wpg;
+  const size_t shmem = npa_qp_shmem_bytes_path(P.T, P.M, fast ? 1 : 0);      // one scene (wave) per workgroup, see the kernel
+  const int nblocks = batch;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1130,11 +1211,11 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
     attr_set = true;
   }
 #define QP_LAUNCH(TTV, MMV)                                                                                      \
-  hipExtLaunchKernelGGL((nrmp_qp_kernel<TTV, MMV>), dim3(nblocks), dim3(QP_THREADS * wpg), shmem, stream, ev_start, ev_stop, 0, \
+  hipExtLaunchKernelGGL((nrmp_qp_kernel<TTV, MMV>), dim3(nblocks), dim3(QP_THREADS), shmem, stream, ev_start, ev_stop, 0, \
                         P, cur_s_in, cur_u_in, ref_s, ref_us, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count,  \
                         cur_s_out, cur_u_out, cur_d_out, out_s, out_u, out_d, out_min_distance, out_iters,            \
-                        out_nrmp_points, flags, state, qp_info, warm, scene0, batch, wave_doubles,                   \
-                        low_prio ? -wpg : wpg, QpBackward{nullptr, nullptr, nullptr, nullptr, nullptr, dbg_abc, dbg_f, dbg_x}, trig_out)
+                        out_nrmp_points, flags, state, qp_info, warm, scene0, batch,                                 \
+                        QpBackward{nullptr, nullptr, nullptr, nullptr, nullptr, dbg_abc, dbg_f, dbg_x}, trig_out)
   if (P.T == 10 && P.M == 10 && !force_generic) QP_LAUNCH(10, 10);
   else if (P.T == 20 && P.M == 10 && !force_generic) QP_LAUNCH(20, 10);
   else QP_LAUNCH(0, 0);
@@ -1158,7 +1239,6 @@ extern "C" hipError_t npa_launch_qp_backward(const DevParams& P, int batch, cons
   hipLaunchKernelGGL((nrmp_qp_kernel<0, 0, true>), dim3(batch), dim3(QP_THREADS), wave_bytes, stream, P, nom_s, nom_u, ref_s,
                      ref_us, mu_sorted, lam_sorted, pts_sorted, (const float*)nullptr, count, out_s, out_u, out_d,
                      (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int*)nullptr, (float*)nullptr,
-                     (int*)nullptr, (float*)nullptr, qp_info, (double*)nullptr, 0, batch,
-                     (int)(wave_bytes / sizeof(double)), 1, QpBackward{grad_s, grad_u, grad_d, grad_theta, grad_nom_s, nullptr, nullptr, nullptr}, (float*)nullptr);
+                     (int*)nullptr, (float*)nullptr, qp_info, (double*)nullptr, 0, batch, QpBackward{grad_s, grad_u, grad_d, grad_theta, grad_nom_s, nullptr, nullptr, nullptr}, (float*)nullptr);
   return hipGetLastError();
 }
