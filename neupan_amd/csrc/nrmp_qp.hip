@@ -108,9 +108,10 @@ __device__ __forceinline__ double fast_rcp(double x) {      // ~1 ulp; x finite,
 }
 // step-to-the-boundary ratios only need a few digits (the step is scaled by 0.995 anyway)
 __device__ __forceinline__ double rough_rcp(double x) { return __builtin_amdgcn_rcp(x); }
+// 1/sqrt(pivot) of the Cholesky: v_rsq_f64 (about 2^-26 relative) and ONE Newton step (-> ~1e-15); L L' then differs from
+// K' by a few ulp -- an inexact Newton matrix at that level costs nothing, and the step is on the serial path of every pivot
 __device__ __forceinline__ double fast_rsqrt(double x) {    // x > 0
   double y = __builtin_amdgcn_rsq(x);
-  y = y * fma(-0.5 * x * y, y, 1.5);
   y = y * fma(-0.5 * x * y, y, 1.5);
   return y;
 }
@@ -419,7 +420,8 @@ void nrmp_qp_kernel(
     if (!(a & 1)) acc += -2.0 * pu * (double)__fmul_rn(P.p_u, rus[a >> 1]);
     gmax = fmax(gmax, fabs(acc));
   }
-  const double scale_d = 1.0 + wave_reduce<OpMax>(gmax), scale_p = 1.0 + wave_reduce<OpMax>(cmax);
+  // (the merit divides the residuals by these scales: reciprocals once, no fp64 division inside the loop)
+  const double iscale_d = 1.0 / (1.0 + wave_reduce<OpMax>(gmax)), iscale_p = 1.0 / (1.0 + wave_reduce<OpMax>(cmax));
   const double m_tot = fmax(wave_reduce<OpSum>(m_act) + (double)mf + (obs ? 2.0 * T : 0.0), 1.0);
   const double inv_m = 1.0 / m_tot;
   const double pub = (lane < nu && !(lane & 1)) ? -2.0 * pu * (double)__fmul_rn(P.p_u, rus[lane >> 1]) : 0.0;
@@ -457,10 +459,23 @@ void nrmp_qp_kernel(
       const int a = lane;
       if constexpr (TT > 0) {        // Phi[t][k][a] is stored as 0 for t < a/2: no lane-dependent trip count
         double a0 = 0, a1 = 0, a2 = 0;
+        if constexpr (TT <= 10) {
+          // column a of Phi on its way before the sums start (the loads were issued six at a time with a wait after each
+          // batch); at T = 20 the 60 values do not fit beside the rest
+          double ph[3 * TT];
 #pragma unroll
-        for (int t = 0; t < TT; ++t) {
-          const double* Pt = Phi + (size_t)t * 3 * ldp;
-          a0 = fma(Pt[a], in3[t * 3], a0); a1 = fma(Pt[ldp + a], in3[t * 3 + 1], a1); a2 = fma(Pt[2 * ldp + a], in3[t * 3 + 2], a2);
+          for (int q = 0; q < 3 * TT; ++q) ph[q] = Phi[(size_t)q * ldp + a];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < TT; ++t) {
+            a0 = fma(ph[t * 3], in3[t * 3], a0); a1 = fma(ph[t * 3 + 1], in3[t * 3 + 1], a1); a2 = fma(ph[t * 3 + 2], in3[t * 3 + 2], a2);
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < TT; ++t) {
+            const double* Pt = Phi + (size_t)t * 3 * ldp;
+            a0 = fma(Pt[a], in3[t * 3], a0); a1 = fma(Pt[ldp + a], in3[t * 3 + 1], a1); a2 = fma(Pt[2 * ldp + a], in3[t * 3 + 2], a2);
+          }
         }
         acc = a0 + a1 + a2;
       } else {
@@ -474,11 +489,13 @@ void nrmp_qp_kernel(
   };
   // C_u' y for variable a (y indexed like the u rows)
   auto ct_mul = [&](const double* y, int a) -> double {
-    int t = a >> 1;
-    double acc = y[2 * a] - y[2 * a + 1];
-    if (t >= 1) { int q = 4 * T + 2 * (a - 2); acc += y[q] - y[q + 1]; }
-    if (t <= T - 2) { int q = 4 * T + 2 * a; acc -= y[q] - y[q + 1]; }
-    return acc;
+    // (no branches: the two rate pairs that may not exist are read at a clamped index and weighted 0, so that the three
+    // 128-bit loads go out together)
+    const int t = a >> 1;
+    const double m1 = t >= 1 ? 1.0 : 0.0, m2 = t <= T - 2 ? 1.0 : 0.0;
+    const int q1 = 4 * T + 2 * (t >= 1 ? a - 2 : 0), q2 = 4 * T + 2 * (t <= T - 2 ? a : 0);
+    const double2 y0 = ld2(y + 2 * a), y1 = ld2(y + q1), y2 = ld2(y + q2);
+    return (y0.x - y0.y) + m1 * (y1.x - y1.y) - m2 * (y2.x - y2.y);
   };
 
   // ---- warm start across the PAN iterations of one forward call ------------------------------------------------
@@ -581,13 +598,26 @@ void nrmp_qp_kernel(
     double S0r = 0, S1r = 0, S2r = 0;          // (v, 1/kappa, r1_d of step t are re-read from St by the passes: registers)
     for (int t = lane; t < T; t += QP_THREADS) {
       double z0 = 0, z1 = 0, zs = 0, s00 = 0, s01 = 0, s11 = 0, v0 = 0, v1 = 0, sg = 0;
-#pragma unroll 5
-      for (int j = 0; j < M; ++j) {
-        int i = t * M + j;
-        double l = lf[i], a0 = fa0[i], a1 = fa1[i];
-        double D = l * iwf[i];
+      auto acc = [&](double l, double a0, double a1, double iw) {
+        const double D = l * iw;
         z0 += l * a0; z1 += l * a1; zs += l;
         s00 += D * a0 * a0; s01 += D * a0 * a1; s11 += D * a1 * a1; v0 += D * a0; v1 += D * a1; sg += D;
+      };
+      if constexpr (HPAIR) {
+        // all 4 M values of the step on their way (128-bit loads) before the sums start: the lanes that do this are few
+        // and the loop was a chain of load -> wait -> 12 flops per row
+        double2 l2[MM / 2], p0[MM / 2], p1[MM / 2], iw2[MM / 2];
+#pragma unroll
+        for (int j = 0; j < MM / 2; ++j) {
+          const int i = t * MM + 2 * j;
+          l2[j] = ld2(lf + i); p0[j] = ld2(fa0 + i); p1[j] = ld2(fa1 + i); iw2[j] = ld2(iwf + i);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < MM / 2; ++j) { acc(l2[j].x, p0[j].x, p1[j].x, iw2[j].x); acc(l2[j].y, p0[j].y, p1[j].y, iw2[j].y); }
+      } else {
+#pragma unroll 5
+        for (int j = 0; j < M; ++j) { const int i = t * M + j; acc(lf[i], fa0[i], fa1[i], iwf[i]); }
       }
       double kap = sg, r1d = 0;
       if (obs) {
@@ -615,9 +645,9 @@ void nrmp_qp_kernel(
     }
     PROF_B(5);
     const double mu = wave_reduce<OpSum>(gap) * inv_m;
-    const double r1max = wave_reduce<OpMax>(fmax(lane < nu ? fabs(r1u) : 0.0, r1dmax));
-    const double rpm = wave_reduce<OpMax>(rpmax);
-    const double merit = fmax(fmax(r1max / scale_d, rpm / scale_p), mu);
+    // scaled dual and primal residuals in ONE max reduction (scaling is monotone: max of scaled = scaled max)
+    const double rmax = wave_reduce<OpMax>(fmax(fmax(lane < nu ? fabs(r1u) : 0.0, r1dmax) * iscale_d, rpmax * iscale_p));
+    const double merit = fmax(rmax, mu);
     last_mu = mu;
 #ifdef NPA_QP_DBGTRACE
     if (qp_info && lane == 0 && it < 4) { double* qq = qp_info + (size_t)b * QP_INFO_STRIDE; qq[5 + 2 * it] = merit; qq[6 + 2 * it] = mu; }
@@ -676,10 +706,13 @@ void nrmp_qp_kernel(
       {
         double p00 = 0, p01 = 0, p02 = 0, p11 = 0, p12 = 0, p22 = 0;
         double* Pst = Yt;                              // [T][6] staging of P_t (uniform values)
+        // A_t = I + (a0, a1, 0)' e_2': lane t fetches its pair once, the chain below broadcasts them with v_readlane
+        // (an LDS load per step would sit on the serial path)
+        const double2 a01 = ld2(Abc + (lane < TT ? lane : 0) * 12);
 #pragma unroll
         for (int t = TT - 1; t >= 0; --t) {
           if (t < TT - 1) {
-            const double a0 = Abc[(t + 1) * 12 + 0], a1 = Abc[(t + 1) * 12 + 1];
+            const double a0 = readlane_f64(a01.x, t + 1), a1 = readlane_f64(a01.y, t + 1);
             const double pa0 = p00 * a0 + p01 * a1, pa1 = p01 * a0 + p11 * a1, pa2 = p02 * a0 + p12 * a1;
             p22 += 2.0 * pa2 + (a0 * pa0 + a1 * pa1);
             p02 += pa0; p12 += pa1;
@@ -723,25 +756,53 @@ void nrmp_qp_kernel(
       PROF(3);
       // right-looking Cholesky, row i in lane i: after step k, arow[k] = L[i][k] for i > k (the entries a lane
       // computes on and above its diagonal are unused garbage and are not stored)
+      // (written so that the next pivot's reciprocal square root -- the serial chain -- starts before the trailing
+      // update of the current column, which is independent of it)
+      double piv = readlane_f64(arow[0], 0);
+      if (!(piv > 0.0)) chol_ok = false;
+      double rinv = fast_rsqrt(piv);
 #pragma unroll
       for (int k = 0; k < NU; ++k) {
-        double piv = readlane_f64(arow[k], k);
-        if (!(piv > 0.0)) chol_ok = false;
-        double rinv = fast_rsqrt(piv);
-        double l = arow[k] * rinv;
+        const double l = arow[k] * rinv;
         invd[k] = rinv;                      // uniform value, every lane stores it
         arow[k] = l;
+        if (k + 1 < NU) {
+          arow[k + 1] = fma(-l, readlane_f64(l, k + 1), arow[k + 1]);
+          piv = readlane_f64(arow[k + 1], k + 1);
+          if (!(piv > 0.0)) chol_ok = false;
+          rinv = fast_rsqrt(piv);
+        }
+        // The rest of the trailing update is not on the pivot chain: its broadcasts of l_j go through LDS (one store of the
+        // column, uniform-address 128-bit loads of two l_j each) instead of two v_readlane per value -- a third of the
+        // VALU instructions of the factorisation.  (LDS operations of a wave execute in order: the loads see the store,
+        // and the next column's store comes after this column's loads.)
+        if constexpr (NU > 20) {              // (T = 20: the 2 x 19 values a step loads do not fit beside the 40-entry row)
 #pragma unroll
-        for (int j = k + 1; j < NU; ++j) arow[j] = fma(-l, readlane_f64(l, j), arow[j]);
+          for (int j = k + 2; j < NU; ++j) arow[j] = fma(-l, readlane_f64(l, j), arow[j]);
+        } else if (k + 2 < NU) {
+          // (dxu and dxd are dead between `update` and the substitution; lanes >= NU dump their copy into dxd[0]: no
+          // predicate, the factorisation stays one basic block)
+          dxu[lane < NU ? lane : NU] = l;
+#pragma unroll
+          for (int j0 = (k + 2) & ~1; j0 < NU; j0 += 2) {
+            const double2 lj = ld2(dxu + j0);
+            if (j0 >= k + 2) arow[j0] = fma(-l, lj.x, arow[j0]);
+            if (j0 + 1 < NU) arow[j0 + 1] = fma(-l, lj.y, arow[j0 + 1]);
+          }
+        }
       }
-      // park the strictly lower part of row `lane` in the zero-padded LDS copy of L
+      // Park the strictly lower part of row `lane`, SCALED BY 1/L_ii, in the zero-padded LDS matrix: Lf[i][k] = L[i][k]/L[i][i].
+      // Both substitutions then run without a multiplication on their serial chain:
+      //   L y = b :  y_i = b_i/L_ii - sum_{k<i} Lf[i][k] y_k                          (row i of Lf)
+      //   L'x = y :  z_i = y_i      - sum_{k>i} Lf[k][i] z_k,  z = diag(L) x,  x_i = z_i/L_ii   (column i of Lf)
+      LSYNC();
+      myinv = invd[ar];
       if (lane < NU) {
 #pragma unroll
         for (int c = 0; c < NU - 1; ++c)
-          if (c < lane) Km[lane * ldk + c] = arow[c];
+          if (c < lane) Km[lane * ldk + c] = arow[c] * myinv;
       }
       LSYNC();
-      myinv = invd[ar];
     } else {
     for (int q = lane; q < 2 * T * nu; q += QP_THREADS) {        // Y[t][k][c] = S'_t[k][:] Phi_xy[t][:, c]
       int tk = q / nu, c = q - tk * nu, t = tk >> 1, k = tk & 1;
@@ -860,8 +921,20 @@ void nrmp_qp_kernel(
       double pq0 = 0, pq1 = 0, rdr = 0;
       for (int t = lane; t < T; t += QP_THREADS) {
         double z0 = 0, z1 = 0, zs = 0;
+        if constexpr (HPAIR) {
+          double2 w2[MM / 2], p0[MM / 2], p1[MM / 2];
+#pragma unroll
+          for (int j = 0; j < MM / 2; ++j) { const int i = t * MM + 2 * j; w2[j] = ld2(dwf + i); p0[j] = ld2(fa0 + i); p1[j] = ld2(fa1 + i); }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < MM / 2; ++j) {
+            z0 += w2[j].x * p0[j].x; z1 += w2[j].x * p1[j].x; zs += w2[j].x;
+            z0 += w2[j].y * p0[j].y; z1 += w2[j].y * p1[j].y; zs += w2[j].y;
+          }
+        } else {
 #pragma unroll 5
-        for (int j = 0; j < M; ++j) { int i = t * M + j; double w = dwf[i]; z0 += w * fa0[i]; z1 += w * fa1[i]; zs += w; }
+          for (int j = 0; j < M; ++j) { int i = t * M + j; double w = dwf[i]; z0 += w * fa0[i]; z1 += w * fa1[i]; zs += w; }
+        }
         double rd = 0;
         const double* S = St + t * 8;                                       // v0 v1 at [3] [4], 1/kappa [6], r1_d [7]
         if (obs) rd = -S[7] - (dwd[2 * t] - dwd[2 * t + 1]) + zs;           // rhs of the d rows
@@ -882,17 +955,24 @@ void nrmp_qp_kernel(
         // forward substitution L y = rhs, backward L' dx = y; lane i owns entry i and reads row i / column i of the
         // zero-padded L (loads that do not depend on the chain: they are issued ahead of it)
         const int lr = lane < NU ? lane : 0;
-        double Lrow[NU], Lcol[NU];
+        rr *= myinv;                         // b_i / L_ii
+        if constexpr (NU <= 20) {
+          double Lrow[NU], Lcol[NU];
 #pragma unroll
-        for (int k = 0; k < NU; ++k) Lrow[k] = Km[lr * ldk + k];
-        __builtin_amdgcn_sched_barrier(0);           // all of row `lane` is on its way before the chain starts
+          for (int k = 0; k < NU; ++k) Lrow[k] = Km[lr * ldk + k];
+          __builtin_amdgcn_sched_barrier(0);         // all of row `lane` is on its way before the chain starts
 #pragma unroll
-        for (int k = 0; k < NU; ++k) Lcol[k] = Km[k * ldk + lr];     // (free to overlap the forward chain)
+          for (int k = 0; k < NU; ++k) Lcol[k] = Km[k * ldk + lr];   // (free to overlap the forward chain)
 #pragma unroll
-        for (int k = 0; k < NU; ++k) rr = fma(-Lrow[k], readlane_f64(rr * myinv, k), rr);
-        rr *= myinv;                         // y
+          for (int k = 0; k < NU; ++k) rr = fma(-Lrow[k], readlane_f64(rr, k), rr);          // -> y
 #pragma unroll
-        for (int k = NU - 1; k >= 0; --k) rr = fma(-Lcol[k], readlane_f64(rr * myinv, k), rr);
+          for (int k = NU - 1; k >= 0; --k) rr = fma(-Lcol[k], readlane_f64(rr, k), rr);     // -> z
+        } else {                             // (T = 20: 2 x 40 doubles ahead of the chains do not fit the register file)
+#pragma unroll
+          for (int k = 0; k < NU; ++k) rr = fma(-Km[lr * ldk + k], readlane_f64(rr, k), rr);
+#pragma unroll
+          for (int k = NU - 1; k >= 0; --k) rr = fma(-Km[k * ldk + lr], readlane_f64(rr, k), rr);
+        }
         rr *= myinv;                         // dx_u
       } else {
         for (int k = 0; k < nu; ++k) {
@@ -970,7 +1050,7 @@ void nrmp_qp_kernel(
           gap_aff += (l.x + amax * dl.x) * (w.x + amax * dw.x) + (l.y + amax * dl.y) * (w.y + amax * dw.y);
         }
         double mu_aff = wave_reduce<OpSum>(gap_aff) * inv_m;
-        double sg = mu_aff / mu;
+        double sg = mu_aff * fast_rcp(mu);
         sigma_mu = sg * sg * sg * mu;
       } else {
         alpha = fmin(1.0, 0.995 * amax);
