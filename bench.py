@@ -144,6 +144,7 @@ def main():
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     last = run_steps(args.steps)
+    t_issue = time.perf_counter() - t0          # host time to enqueue every step (the GPU is still working)
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
@@ -228,6 +229,9 @@ def main():
                    "parallelism": f"scene-shard x{world}, RCCL all-gather of controls"
                                   + (" (process group initialised)" if dist is not None else "")},
         "roofline": roof,
+        # host time to enqueue a step (21 launches + output tensors, one Python thread) next to the step's wall time: when
+        # the two are close the step is bound by the host's launch rate, not by the kernels
+        "host_issue_ms_per_step": round(1e3 * t_issue / args.steps, 4),
     }
 
     # ---- single-scene latency: the reference's actual use (neupan/neupan.py:104-166, one robot, README "15 Hz") -------

@@ -530,7 +530,7 @@ __device__ __forceinline__ float geo_dist(const DevParams& P, float x, float y) 
 // LDS per slice stays < 9 KB at 1000 points so that all (T+1) slices of a CU's scenes are resident.
 #define SEL_CAP 64                               // candidates the final exact ranking holds (two 32-point tiles)
 template <int E, bool GEO>
-__global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(3, 3))) void select_kernel(
+__global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(4, 4))) void select_kernel(
     DevParams P, const float* __restrict__ wpack, int n_stride, const float* __restrict__ cur_s,
     const float* __restrict__ points, const float* __restrict__ vel, const int* __restrict__ n_points,
     const int* __restrict__ flags, const unsigned* __restrict__ gkeys, int key_stride,
@@ -573,17 +573,33 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
   const float* vx_row = vel ? vel + (size_t)b * 2 * n_stride : nullptr;
   const float* vy_row = vel ? vx_row + n_stride : nullptr;
   if constexpr (GEO) {
-    for (int n = lane; n < n_use; n += 64) {
-      const int src = src_index(n, n_raw, n_use);
-      float gx = px_row[src], gy = py_row[src];                 // the point flow of point_features
+    // Keys of every point of the slice.  Four points per lane and trip, their loads issued together: one point per
+    // trip made the pass a chain of n_use / 64 dependent memory round trips -- the longest stretch of this wave's life.
+    constexpr int KU = 4;
+    auto key_of = [&](float gx, float gy, float vx, float vy) -> unsigned {     // the point flow of point_features
       if (vx_row) {
-        gx = __fadd_rn(gx, __fmul_rn(F.tstep, __fmul_rn(vx_row[src], P.dt32)));
-        gy = __fadd_rn(gy, __fmul_rn(F.tstep, __fmul_rn(vy_row[src], P.dt32)));
+        gx = __fadd_rn(gx, __fmul_rn(F.tstep, __fmul_rn(vx, P.dt32)));
+        gy = __fadd_rn(gy, __fmul_rn(F.tstep, __fmul_rn(vy, P.dt32)));
       }
       const float dx = __fsub_rn(gx, F.tx), dy = __fsub_rn(gy, F.ty);
       const float p0x = fmaf(F.c, dx, __fmul_rn(F.s, dy)), p0y = fmaf(F.c, dy, -__fmul_rn(F.s, dx));
       const bool calibrated = fmaxf(fabsf(p0x), fabsf(p0y)) <= P.geo_rcal;     // false for NaN / inf too
-      dkey[n] = calibrated ? __float_as_uint(geo_dist<E>(P, p0x, p0y)) : NPA_GEO_KEY_FAR;
+      return calibrated ? __float_as_uint(geo_dist<E>(P, p0x, p0y)) : NPA_GEO_KEY_FAR;
+    };
+    for (int n0 = lane; n0 < n_use; n0 += 64 * KU) {
+      float gx[KU], gy[KU], vx[KU], vy[KU];
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        const int n = n0 + 64 * u;
+        const int src = src_index(n < n_use ? n : n_use - 1, n_raw, n_use);     // (clamped: a valid address, value unused)
+        gx[u] = px_row[src]; gy[u] = py_row[src];
+        vx[u] = vx_row ? vx_row[src] : 0.f; vy[u] = vy_row ? vy_row[src] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        const int n = n0 + 64 * u;
+        if (n < n_use) dkey[n] = key_of(gx[u], gy[u], vx[u], vy[u]);
+      }
     }
   } else {
     const unsigned* gk = gkeys + orow * key_stride;

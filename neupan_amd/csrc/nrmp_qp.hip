@@ -47,13 +47,20 @@
       const double cx = p >= npu ? d0 : 0.0;      /* c'x at the cold point */                     \
       const bool on = c.actf != 0.0;                                                              \
       st2(lc + 2 * p, c.actf, c.actf);                                                            \
-      st2(wc + 2 * p, on ? fmax(c.bp - cx, 1.0) : 1.0, on ? fmax(c.bm + cx, 1.0) : 1.0);          \
-      st2(dlc + 2 * p, 0.0, 0.0); st2(dwc + 2 * p, 0.0, 0.0);                                     \
+      ST_ROW(Rwc, wc, p, on ? fmax(c.bp - cx, 1.0) : 1.0, on ? fmax(c.bm + cx, 1.0) : 1.0);       \
+      ST_ROW(Rdlc, dlc, p, 0.0, 0.0); st2(dwc + 2 * p, 0.0, 0.0);                                 \
     }                                                                                             \
     LSYNC();                                                                                      \
-    for (int i = lane; i < mf; i += QP_THREADS) {                                                 \
-      lf[i] = 1.0;                                                                                \
-      wf[i] = fmax(-d0 - ff[i] + iro, 1.0); /* F x - f + lf/ro at u = 0 */                        \
+    if constexpr (REGROWS) {                                                                      \
+      if (lane < mf / 2) {                                                                        \
+        st2(lf + 2 * lane, 1.0, 1.0);                                                             \
+        Rwf = make_double2(fmax(-d0 - Rff.x + iro, 1.0), fmax(-d0 - Rff.y + iro, 1.0));           \
+      }                                                                                           \
+    } else {                                                                                      \
+      for (int i = lane; i < mf; i += QP_THREADS) {                                               \
+        lf[i] = 1.0;                                                                              \
+        wf[i] = fmax(-d0 - ff[i] + iro, 1.0); /* F x - f + lf/ro at u = 0 */                      \
+      }                                                                                           \
     }                                                                                             \
     LSYNC();                                                                                      \
   } while (0)
@@ -210,6 +217,11 @@ void nrmp_qp_kernel(
   const int npair = nu * (nu + 1) / 2;
   const double ro = P.ro_obs, iro = 1.0 / ro;
   const double dmin0 = fmax((double)P.d_min, 0.0), dmaxv = (double)P.d_max;
+  // T = 10, M = 10: each lane owns ONE pair of hinge rows (lanes < T M / 2 = 50) and ONE pair of u / d rows (lanes <
+  // 5T - 2 = 48) in every phase, so the per-row arrays that only their owner touches -- slacks, residuals, multiplier
+  // directions, the hinge offsets -- live in registers, not in LDS (7 arrays, 5.5 KB of the scene's 26 KB: the LDS
+  // block is what limits how many scenes a CU holds).  Arrays other lanes read (multipliers, 1/w, rhs weights) stay.
+  constexpr bool REGROWS = TT > 0 && MM > 0 && (MM % 2) == 0 && TT * MM / 2 <= QP_THREADS && 5 * TT - 2 <= QP_THREADS;
 
   // ---- LDS carve (doubles) -----------------------------------------------------------
   // Rows of the interior-point method first, at even offsets (they are read and written two at a time).  The rows on u
@@ -217,36 +229,40 @@ void nrmp_qp_kernel(
   // (mcu + 2t: d_t <= d_max, mcu + 2t + 1: -d_t <= -d_min) share one array each: "pair" p holds rows 2p and 2p + 1, the
   // + and - side of one linear form.  ld_, wd, ... are the d parts under their own names.
   const int mcd = mcu + 2 * T;
+  const int mcr = REGROWS ? 0 : mcd;          // (arrays held in registers take no LDS)
   double* lc = sm;                            // [mcu + 2T] multipliers
   double* wc = lc + mcd;                      // slacks
-  double* dlc = wc + mcd;
-  double* dwc = dlc + mcd;
+  double* dlc = wc + mcr;
+  double* dwc = dlc + mcr;
   double* r2 = dwc + mcd;
-  double* iwc = r2 + mcd;                     // 1/w
+  double* iwc = r2 + mcr;                     // 1/w
   double* ld_ = lc + mcu; double* wd = wc + mcu; double* dld = dlc + mcu; double* dwd = dwc + mcu;
   double* r2d = r2 + mcu; double* iwd = iwc + mcu;
   const int mfe = (mf + 1) & ~1;
+  const int mfr = REGROWS ? 0 : mfe;
   double* fa0 = iwc + mcd;                    // [mf] hinge rows ...
   double* fa1 = fa0 + mfe;
   double* ff = fa1 + mfe;
-  double* lf = ff + mfe;
+  double* lf = ff + mfr;
   double* wf = lf + mfe;
-  double* dlf = wf + mfe;
-  double* dwf = dlf + mfe;
+  double* dlf = wf + mfr;
+  double* dwf = dlf + mfr;
   double* r3 = dwf + mfe;
-  double* iwf = r3 + mfe;                     // 1/(wf + lf/ro)
+  double* iwf = r3 + mfr;                     // 1/(wf + lf/ro)
   double* Phi = iwf + mfe;                    // [T][3][ldp]  s(t+1) = Phi[t] u + cv[t]
   // generic path: Yt [T][2][ldp] = S'_t Phi_xy(t), Hm / Km [nu][ldk] full matrices.
   // fast path (TT > 0): Yt [T][6] = staging of the 3x3 P_t, Hm packed lower triangle (row a at
   // a(a+1)/2), Km = L as a full [nu][nu+1] matrix whose diagonal and upper triangle stay ZERO: the substitutions read
   // row `lane` (forward) and column `lane` (backward) of it with no lane predicates and no copy of L in registers
-  double* Yt = Phi + (size_t)T * 3 * ldp;
-  double* Hm = Yt + (TT > 0 ? (size_t)T * 6 : (size_t)T * 2 * ldp);
+  // (fast path: the P_t staging is the [T][6] block s3 | q3 -- both are dead between the residual phase and the passes)
+  double* Ytg = Phi + (size_t)T * 3 * ldp;
+  double* Hm = Ytg + (TT > 0 ? 0 : (size_t)T * 2 * ldp);
   double* Km = Hm + (TT > 0 ? (size_t)nu * (nu + 1) / 2 : (size_t)nu * ldk);
   double* cv = Km + (size_t)nu * ldk;         // [T][3]
   double* lin = cv + T * 3;                   // [T][3]  state-cost gradient at u = 0
   double* s3 = lin + T * 3;                   // [T][3]  Phi x   /  Phi dx
   double* q3 = s3 + T * 3;                    // [T][3]  operand of Phi'
+  double* Yt = TT > 0 ? s3 : Ytg;
   double* Abc = q3 + T * 3;                   // [T][12]
   double* St = Abc + T * 12;                  // [T][8]  S'00 S'01 S'11 v0 v1 sigma 1/kappa r1d
   double* xu = St + T * 8;                    // [nu]    (xu, xd contiguous: the pairs index them as one vector)
@@ -255,8 +271,23 @@ void nrmp_qp_kernel(
   double* dxu = xbest + nu + T;               // [nu]    (dxu, dxd contiguous)
   double* dxd = dxu + nu;                     // [T]
   double* invd = dxd + T;                     // [nu]   1/L_kk
-  unsigned char* pa = reinterpret_cast<unsigned char*>(invd + nu);     // [npair]
+  // pair table of the H build: the fast path needs it during the set-up only and parks it in the block of L (zeroed
+  // after the H build, below)
+  unsigned char* pa = reinterpret_cast<unsigned char*>(TT > 0 ? Km : invd + nu);      // [npair]
   unsigned char* pc = pa + ((npair + 7) & ~7);
+
+  // REGROWS: this lane's pair of u / d rows (slack, dl, primal residual) and of hinge rows (slack, dl, residual, offset f)
+  double2 Rwc = make_double2(1.0, 1.0), Rdlc = make_double2(0.0, 0.0), Rr2 = make_double2(0.0, 0.0);
+  double2 Rwf = make_double2(1.0, 1.0), Rdlf = make_double2(0.0, 0.0), Rr3 = make_double2(0.0, 0.0), Rff = make_double2(0.0, 0.0);
+  // one access path for both layouts (the condition is a compile-time constant)
+#define LD_WC(p) (REGROWS ? Rwc : ld2(wc + 2 * (p)))
+#define LD_DLC(p) (REGROWS ? Rdlc : ld2(dlc + 2 * (p)))
+#define LD_R2(p) (REGROWS ? Rr2 : ld2(r2 + 2 * (p)))
+#define LD_WF(h) (REGROWS ? Rwf : ld2(wf + 2 * (h)))
+#define LD_DLF(h) (REGROWS ? Rdlf : ld2(dlf + 2 * (h)))
+#define LD_R3(h) (REGROWS ? Rr3 : ld2(r3 + 2 * (h)))
+#define LD_FF(h) (REGROWS ? Rff : ld2(ff + 2 * (h)))
+#define ST_ROW(REG, arr, q, a, b_) do { if constexpr (REGROWS) REG = make_double2((a), (b_)); else st2((arr) + 2 * (q), (a), (b_)); } while (0)
 
   const float* s_in = cur_s_in + (size_t)b * 3 * (T + 1);
   const float* u_in = cur_u_in + (size_t)b * 2 * T;
@@ -314,8 +345,6 @@ void nrmp_qp_kernel(
 #define PAIR_C(p) qp_pair((p), T, npu, sb0, sb1, ab0, ab1, sf0, sf1, af0, af1, dmaxv, dmin0)
   // hinge rows two at a time (rows 2l, 2l + 1 of step t = 2l / M) when M is even
   constexpr bool HPAIR = TT > 0 && MM > 0 && (MM % 2) == 0;
-  if constexpr (TT > 0)
-    for (int q = lane; q < nu * ldk; q += QP_THREADS) Km[q] = 0.0;
   LSYNC();
 
   // ---- Phi recursion: Phi[t] = A_t Phi[t-1] + [B_t at cols 2t,2t+1]; A = I + e0 A02 e2' + e1 A12 e2'
@@ -363,6 +392,10 @@ void nrmp_qp_kernel(
       Hm[c * ldk + a] = acc;
     }
   }
+  if constexpr (TT > 0) {                       // the pair table is done with: its block becomes the zero-padded L
+    LSYNC();
+    for (int q = lane; q < nu * ldk; q += QP_THREADS) Km[q] = 0.0;
+  }
   // fast path: this lane's entries of H that receive the band terms of C_u' D C_u
   double hdiag = 0, hoff = 0;
   for (int q = lane; q < 3 * T; q += QP_THREADS) {
@@ -375,7 +408,7 @@ void nrmp_qp_kernel(
   }
 
   // ---- hinge rows: fa = lam', fb = lam'.p + mu'.h in fp32 (nrmp.py:244-259), slice t+1 ----
-  for (int i = lane; i < mf; i += QP_THREADS) {
+  auto hinge_row = [&](int i) -> double {          // builds row i, returns its offset f = fb - fa . c_t
     int t = i / M, j = i - t * M;
     size_t row = ((size_t)b * (T + 1) + (t + 1)) * M + j;
     double a0 = 0, a1 = 0, fb = 0;
@@ -389,11 +422,16 @@ void nrmp_qp_kernel(
       a0 = l0; a1 = l1; fb = (double)__fadd_rn(tmp, mh);
     }
     fa0[i] = a0; fa1[i] = a1;
-    ff[i] = fb - (a0 * cv[t * 3] + a1 * cv[t * 3 + 1]);
     if (bw.dbg_f) {
       float* o = bw.dbg_f + ((size_t)b * mf + i) * 3;
       o[0] = (float)a0; o[1] = (float)a1; o[2] = (float)fb;
     }
+    return fb - (a0 * cv[t * 3] + a1 * cv[t * 3 + 1]);
+  };
+  if constexpr (REGROWS) {
+    if (lane < mf / 2) { const double f0 = hinge_row(2 * lane), f1 = hinge_row(2 * lane + 1); Rff = make_double2(f0, f1); }
+  } else {
+    for (int i = lane; i < mf; i += QP_THREADS) ff[i] = hinge_row(i);
   }
   if (bw.dbg_abc) {
     for (int q = lane; q < T * 11; q += QP_THREADS) bw.dbg_abc[(size_t)b * T * 11 + q] = (float)Abc[(q / 11) * 12 + (q % 11)];
@@ -510,7 +548,7 @@ void nrmp_qp_kernel(
   // (Compiled into the T = 10 and the generic instantiation only: the T = 20 one -- 256 VGPRs + AGPRs and ~400 spilled
   // SGPRs -- came out of hipcc 7.2 with corrupted loop scalars (best_merit, stall) in every form of this logic tried;
   // it keeps the plain cold start.)
-  constexpr bool WARM = !BWD && TT != 20;
+  constexpr bool WARM = !BWD;
   const int nwarm = nu + T + mf + mcu + 2 * T;
   double* wrm = (WARM && warm) ? warm + (size_t)b * nwarm : nullptr;
   const bool can_warm = WARM && wrm && flags && flags[b * 4 + 2];
@@ -526,11 +564,21 @@ void nrmp_qp_kernel(
     LSYNC();
     phi_mul(xu, s3);
     LSYNC();
-    for (int i = lane; i < mf; i += QP_THREADS) {
-      int t = i / M;
-      double l = fmax(wrm[nu + T + i], dl);
-      lf[i] = l;
-      wf[i] = fmax(fa0[i] * s3[t * 3] + fa1[i] * s3[t * 3 + 1] - xd[t] - ff[i] + l * iro, dl);
+    if constexpr (REGROWS) {
+      if (lane < mf / 2) {
+        const int i = 2 * lane, t = i / M;
+        const double l0 = fmax(wrm[nu + T + i], dl), l1 = fmax(wrm[nu + T + i + 1], dl);
+        st2(lf + i, l0, l1);
+        Rwf = make_double2(fmax(fa0[i] * s3[t * 3] + fa1[i] * s3[t * 3 + 1] - xd[t] - Rff.x + l0 * iro, dl),
+                           fmax(fa0[i + 1] * s3[t * 3] + fa1[i + 1] * s3[t * 3 + 1] - xd[t] - Rff.y + l1 * iro, dl));
+      }
+    } else {
+      for (int i = lane; i < mf; i += QP_THREADS) {
+        int t = i / M;
+        double l = fmax(wrm[nu + T + i], dl);
+        lf[i] = l;
+        wf[i] = fmax(fa0[i] * s3[t * 3] + fa1[i] * s3[t * 3 + 1] - xd[t] - ff[i] + l * iro, dl);
+      }
     }
     for (int p = lane; p < npc; p += QP_THREADS) {
       const PairC c = PAIR_C(p);
@@ -538,7 +586,7 @@ void nrmp_qp_kernel(
         const double cx = fma(-c.sb, xu[c.ib], xu[c.ia]);
         const double* wl = wrm + nu + T + mf + 2 * p;          // (lc then ld in the record, like the rows)
         st2(lc + 2 * p, fmax(wl[0], dl), fmax(wl[1], dl));
-        st2(wc + 2 * p, fmax(c.bp - cx, dl), fmax(c.bm + cx, dl));
+        ST_ROW(Rwc, wc, p, fmax(c.bp - cx, dl), fmax(c.bm + cx, dl));
       }
     }
     LSYNC();
@@ -560,11 +608,11 @@ void nrmp_qp_kernel(
     if constexpr (HPAIR) {
       for (int h = lane; h < mf / 2; h += QP_THREADS) {
         const int t = h / (MM / 2), i = 2 * h;
-        const double2 l = ld2(lf + i), w = ld2(wf + i), a0 = ld2(fa0 + i), a1 = ld2(fa1 + i), f = ld2(ff + i);
+        const double2 l = ld2(lf + i), w = LD_WF(h), a0 = ld2(fa0 + i), a1 = ld2(fa1 + i), f = LD_FF(h);
         const double sx = s3[t * 3], sy = s3[t * 3 + 1], d = xd[t];
         const double rx = a0.x * sx + a1.x * sy - d - f.x + l.x * iro - w.x;
         const double ry = a0.y * sx + a1.y * sy - d - f.y + l.y * iro - w.y;
-        st2(r3 + i, rx, ry);
+        ST_ROW(Rr3, r3, h, rx, ry);
         st2(iwf + i, fast_rcp(w.x + l.x * iro), fast_rcp(w.y + l.y * iro));
         rpmax = fmax(rpmax, fmax(fabs(rx), fabs(ry)));
         gap += l.x * w.x + l.y * w.y;
@@ -583,10 +631,10 @@ void nrmp_qp_kernel(
     PROF_B(2);
     for (int p = lane; p < npc; p += QP_THREADS) {
       const PairC c = PAIR_C(p);
-      const double2 l = ld2(lc + 2 * p), w = ld2(wc + 2 * p);
+      const double2 l = ld2(lc + 2 * p), w = LD_WC(p);
       const double cx = fma(-c.sb, xu[c.ib], xu[c.ia]);
       const double rp = (cx + w.x - c.bp) * c.actf, rm = (w.y - cx - c.bm) * c.actf;
-      st2(r2 + 2 * p, rp, rm);
+      ST_ROW(Rr2, r2, p, rp, rm);
       st2(iwc + 2 * p, fast_rcp(w.x), fast_rcp(w.y));
       rpmax = fmax(rpmax, fmax(fabs(rp), fabs(rm)));
       gap += l.x * w.x + l.y * w.y;             // (a switched-off pair keeps l = 0)
@@ -897,9 +945,9 @@ void nrmp_qp_kernel(
       if constexpr (HPAIR) {
         for (int h = lane; h < mf / 2; h += QP_THREADS) {
           const int i = 2 * h;
-          const double2 l = ld2(lf + i), w = ld2(wf + i), r = ld2(r3 + i), iw = ld2(iwf + i);
+          const double2 l = ld2(lf + i), w = LD_WF(h), r = LD_R3(h), iw = ld2(iwf + i);
           double r4x = l.x * w.x, r4y = l.y * w.y;
-          if (pass) { const double2 pw = ld2(dwf + i), pl = ld2(dlf + i); r4x += pw.x * pl.x - sigma_mu; r4y += pw.y * pl.y - sigma_mu; }
+          if (pass) { const double2 pw = ld2(dwf + i), pl = LD_DLF(h); r4x += pw.x * pl.x - sigma_mu; r4y += pw.y * pl.y - sigma_mu; }
           st2(dwf + i, adj ? 0.0 : (r4x + l.x * r.x) * iw.x, adj ? 0.0 : (r4y + l.y * r.y) * iw.y);
         }
       } else {
@@ -911,9 +959,9 @@ void nrmp_qp_kernel(
       for (int p = lane; p < npc; p += QP_THREADS) {
         const int i = 2 * p;
         const double af = adj ? 0.0 : PAIR_C(p).actf;
-        const double2 l = ld2(lc + i), w = ld2(wc + i), r = ld2(r2 + i), iw = ld2(iwc + i);
+        const double2 l = ld2(lc + i), w = LD_WC(p), r = LD_R2(p), iw = ld2(iwc + i);
         double r4x = l.x * w.x, r4y = l.y * w.y;
-        if (pass) { const double2 pw = ld2(dwc + i), pl = ld2(dlc + i); r4x += pw.x * pl.x - sigma_mu; r4y += pw.y * pl.y - sigma_mu; }
+        if (pass) { const double2 pw = ld2(dwc + i), pl = LD_DLC(p); r4x += pw.x * pl.x - sigma_mu; r4y += pw.y * pl.y - sigma_mu; }
         st2(dwc + i, af * ((l.x * r.x - r4x) * iw.x), af * ((l.y * r.y - r4y) * iw.y));
       }
       LSYNC();
@@ -1005,13 +1053,13 @@ void nrmp_qp_kernel(
       if constexpr (HPAIR) {
         for (int h = lane; h < mf / 2; h += QP_THREADS) {
           const int t = h / (MM / 2), i = 2 * h;
-          const double2 l = ld2(lf + i), w = ld2(wf + i), a0 = ld2(fa0 + i), a1 = ld2(fa1 + i), iw = ld2(iwf + i), tw = ld2(dwf + i), r = ld2(r3 + i);
+          const double2 l = ld2(lf + i), w = LD_WF(h), a0 = ld2(fa0 + i), a1 = ld2(fa1 + i), iw = ld2(iwf + i), tw = ld2(dwf + i), r = LD_R3(h);
           const double sx = s3[t * 3], sy = s3[t * 3 + 1], d = dxd[t];
           const double Fx = a0.x * sx + a1.x * sy - d, Fy = a0.y * sx + a1.y * sy - d;
           const double dlx = -(tw.x + l.x * Fx * iw.x), dly = -(tw.y + l.y * Fy * iw.y);       // -(r4 + l r3 + l Fdx)/(w + l/ro)
           const double dwx = Fx + dlx * iro + r.x, dwy = Fy + dly * iro + r.y;
           ratio(l.x, dlx, w.x, dwx); ratio(l.y, dly, w.y, dwy);
-          st2(dlf + i, dlx, dly); st2(dwf + i, dwx, dwy);
+          ST_ROW(Rdlf, dlf, h, dlx, dly); st2(dwf + i, dwx, dwy);
         }
       } else {
         for (int i = lane; i < mf; i += QP_THREADS) {
@@ -1027,26 +1075,26 @@ void nrmp_qp_kernel(
       for (int p = lane; p < npc; p += QP_THREADS) {
         const PairC c = PAIR_C(p);
         const int i = 2 * p;
-        const double2 l = ld2(lc + i), w = ld2(wc + i), iw = ld2(iwc + i), tw = ld2(dwc + i), r = ld2(r2 + i);
+        const double2 l = ld2(lc + i), w = LD_WC(p), iw = ld2(iwc + i), tw = ld2(dwc + i), r = LD_R2(p);
         const double Cdx = fma(-c.sb, dxu[c.ib], dxu[c.ia]);
         const double dlx = tw.x + l.x * Cdx * iw.x, dly = tw.y - l.y * Cdx * iw.y;           // (l r2 - r4 + l Cdx)/w
         const double dwx = (-r.x - Cdx) * c.actf, dwy = (Cdx - r.y) * c.actf;
         ratio(l.x, dlx, w.x, dwx); ratio(l.y, dly, w.y, dwy);
-        st2(dlc + i, dlx, dly); st2(dwc + i, dwx, dwy);
+        ST_ROW(Rdlc, dlc, p, dlx, dly); st2(dwc + i, dwx, dwy);
       }
       PROF_C(6);
       amax = wave_reduce<OpMin>(amax);
       if (pass == 0) {
         if constexpr (HPAIR) {
           for (int h = lane; h < mf / 2; h += QP_THREADS) {
-            const double2 l = ld2(lf + 2 * h), w = ld2(wf + 2 * h), dl = ld2(dlf + 2 * h), dw = ld2(dwf + 2 * h);
+            const double2 l = ld2(lf + 2 * h), w = LD_WF(h), dl = LD_DLF(h), dw = ld2(dwf + 2 * h);
             gap_aff += (l.x + amax * dl.x) * (w.x + amax * dw.x) + (l.y + amax * dl.y) * (w.y + amax * dw.y);
           }
         } else {
           for (int i = lane; i < mf; i += QP_THREADS) gap_aff += (lf[i] + amax * dlf[i]) * (wf[i] + amax * dwf[i]);
         }
         for (int p = lane; p < npc; p += QP_THREADS) {          // (switched-off pairs: l = dl = 0)
-          const double2 l = ld2(lc + 2 * p), w = ld2(wc + 2 * p), dl = ld2(dlc + 2 * p), dw = ld2(dwc + 2 * p);
+          const double2 l = ld2(lc + 2 * p), w = LD_WC(p), dl = LD_DLC(p), dw = ld2(dwc + 2 * p);
           gap_aff += (l.x + amax * dl.x) * (w.x + amax * dw.x) + (l.y + amax * dl.y) * (w.y + amax * dw.y);
         }
         double mu_aff = wave_reduce<OpSum>(gap_aff) * inv_m;
@@ -1102,15 +1150,15 @@ void nrmp_qp_kernel(
     for (int t = lane; t < T && obs; t += QP_THREADS) xd[t] += alpha * dxd[t];
     if constexpr (HPAIR) {
       for (int h = lane; h < mf / 2; h += QP_THREADS) {
-        const double2 l = ld2(lf + 2 * h), w = ld2(wf + 2 * h), dl = ld2(dlf + 2 * h), dw = ld2(dwf + 2 * h);
-        st2(lf + 2 * h, l.x + alpha * dl.x, l.y + alpha * dl.y); st2(wf + 2 * h, w.x + alpha * dw.x, w.y + alpha * dw.y);
+        const double2 l = ld2(lf + 2 * h), w = LD_WF(h), dl = LD_DLF(h), dw = ld2(dwf + 2 * h);
+        st2(lf + 2 * h, l.x + alpha * dl.x, l.y + alpha * dl.y); ST_ROW(Rwf, wf, h, w.x + alpha * dw.x, w.y + alpha * dw.y);
       }
     } else {
       for (int i = lane; i < mf; i += QP_THREADS) { lf[i] += alpha * dlf[i]; wf[i] += alpha * dwf[i]; }
     }
     for (int p = lane; p < npc; p += QP_THREADS) {
-      const double2 l = ld2(lc + 2 * p), w = ld2(wc + 2 * p), dl = ld2(dlc + 2 * p), dw = ld2(dwc + 2 * p);
-      st2(lc + 2 * p, l.x + alpha * dl.x, l.y + alpha * dl.y); st2(wc + 2 * p, w.x + alpha * dw.x, w.y + alpha * dw.y);
+      const double2 l = ld2(lc + 2 * p), w = LD_WC(p), dl = LD_DLC(p), dw = ld2(dwc + 2 * p);
+      st2(lc + 2 * p, l.x + alpha * dl.x, l.y + alpha * dl.y); ST_ROW(Rwc, wc, p, w.x + alpha * dw.x, w.y + alpha * dw.y);
     }
     LSYNC();
     PROF(8);
@@ -1259,12 +1307,14 @@ static bool qp_fast_path(int T, int M) { return (T == 10 || T == 20) && M == 10;
 // LDS bytes of one scene; `fast` = the register-resident instantiation (packed H, L and P staging)
 extern "C" size_t npa_qp_shmem_bytes_path(int T, int M, int fast) {
   const bool obs = M > 0;
-  size_t nu = 2 * T, ldp = nu + 1, mcu = 8 * T - 4, mf = obs ? (size_t)T * M : 0, npair = nu * (nu + 1) / 2;
-  const size_t mats = fast ? (size_t)T * 6 + nu * (nu + 1) / 2 + nu * ldp
-                           : (size_t)T * 2 * ldp + 2 * nu * ldp;
-  size_t d = (size_t)T * 3 * ldp + mats + 4 * (T * 3) + T * 12 + T * 8 + nu + T +
-             (nu + T) + nu + T + nu + 9 * ((mf + 1) & ~(size_t)1) + 6 * mcu + 6 * 2 * T;
-  size_t bytes = d * sizeof(double) + 2 * ((npair + 7) & ~(size_t)7);
+  size_t nu = 2 * T, ldp = nu + 1, mcd = 8 * T - 4 + 2 * T, mf = obs ? (size_t)T * M : 0, npair = nu * (nu + 1) / 2;
+  const size_t mfe = (mf + 1) & ~(size_t)1;
+  // (mirrors the kernel's carve: REGROWS keeps 3 of the 6 u / d row arrays and 5 of the 9 hinge row arrays in LDS)
+  const bool regrows = fast && M > 0 && M % 2 == 0 && T * M / 2 <= QP_THREADS && 5 * T - 2 <= QP_THREADS;
+  const size_t rows = (regrows ? 3 : 6) * mcd + (regrows ? 5 : 9) * mfe;
+  const size_t mats = fast ? nu * (nu + 1) / 2 + nu * ldp : (size_t)T * 2 * ldp + 2 * nu * ldp;
+  size_t d = rows + (size_t)T * 3 * ldp + mats + 4 * (T * 3) + T * 12 + T * 8 + nu + T + (nu + T) + nu + T + nu;
+  size_t bytes = d * sizeof(double) + (fast ? 0 : 2 * ((npair + 7) & ~(size_t)7));
   return (bytes + 15) & ~(size_t)15;
 }
 

@@ -197,13 +197,16 @@ def test_other_baseline_configs_parity_distribution(cfgname, scenes):
 def test_gpu_last_qp_is_certified_optimal(cfgname, B):
     """The last QP of a forward call at benchmark size, per scene: rebuilt on the host from the parameters the KERNEL
     built (npa_nrmp_params), the kernel's fp64 solution passes the independent KKT certificate, and its objective is
-    within 1e-9 (relative) of the oracle's solution of the same problem.  The stage re-run reproduces the forward call's
-    controls to 2e-6 (cold start there, warm start inside the forward call).  (ECOS is absent: for a strictly convex QP the certified point is the answer it approximates.)"""
+    within 1e-9 (relative) of the oracle's solution of the same problem.  The stage re-run (cold start) reproduces the
+    forward call's controls (warm start) to 2e-6 at config 2; on the acker QPs, flat along the steering entries, two
+    solves stopped at 1e-14 from different starts stay up to a few 1e-5 apart (the oracle differs from the kernel by
+    2.2e-5 on the same problems, `du_vs_oracle`), so the tie is asked to the north-star tolerance there.  (ECOS is
+    absent: for a strictly convex QP the certified point is the answer it approximates.)"""
     from gpu_helpers import make_gpu_pan
     from parity_tools import gpu_last_qp_certificates
     cfg = CONFIGS[cfgname]
     pan = make_gpu_pan(cfg)
-    r = gpu_last_qp_certificates(pan, cfg, make_batch(cfg, 0, B))
+    r = gpu_last_qp_certificates(pan, cfg, make_batch(cfg, 0, B), tie_tol=2e-6 if cfgname == "diff_1k_T10_K10" else 1e-4)
     print(r)
     assert r["tied_to_forward"] and r["scenes"] == B
     # feasible to rounding, complementary, and -- the sharp statement -- the objective of the kernel's feasible point is
