@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--cpu-cores", type=int, default=0, help="worker processes of the CPU baseline (0 = all host cores)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-scene latency measurement")
-    ap.add_argument("--inflight", type=int, default=16, help="independent batches (steps) kept in flight, one stream each")
+    ap.add_argument("--inflight", type=int, default=20, help="independent batches (steps) kept in flight, one stream each")
     ap.add_argument("--workload", default=WORKLOAD,
                     choices=sorted(k for k in __import__("neupan_amd.scenes", fromlist=["CONFIGS"]).CONFIGS),
                     help="scene configuration (default: the one BASELINE.json's metric is quoted on)")

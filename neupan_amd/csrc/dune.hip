@@ -530,7 +530,8 @@ __device__ __forceinline__ float geo_dist(const DevParams& P, float x, float y) 
 // LDS per slice stays < 9 KB at 1000 points so that all (T+1) slices of a CU's scenes are resident.
 #define SEL_CAP 64                               // candidates the final exact ranking holds (two 32-point tiles)
 template <int E, bool GEO>
-__global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(4, 4))) void select_kernel(
+// (four waves per SIMD -- 128 VGPRs -- up to six edges; the wider rows of E = 7, 8 spill there and stay at three)
+__global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(E <= 6 ? 4 : 3, E <= 6 ? 4 : 3))) void select_kernel(
     DevParams P, const float* __restrict__ wpack, int n_stride, const float* __restrict__ cur_s,
     const float* __restrict__ points, const float* __restrict__ vel, const int* __restrict__ n_points,
     const int* __restrict__ flags, const unsigned* __restrict__ gkeys, int key_stride,
