@@ -344,9 +344,18 @@ class PAN(torch.nn.Module):
         ref_us (B,T) points (B,2,N)|None velocities (B,2,N)|None n_points (B,) int32|None.
         Returns dict(opt_s, opt_u, opt_d|None, min_distance (B,), iters (B,), nrmp_points (B,2,M)|None)."""
         self.forward_begin(nom_s, nom_u, ref_s, ref_us, points, velocities, n_points, reset_state=reset_state)
-        for k in range(self.iter_num):
-            self.forward_iter(k)
-        return self.forward_end()
+        # (the K iterations and the end under ONE device context, library calls direct: a serving loop issues this per
+        # batch in flight, and the per-iteration Python was half of a step's host time)
+        lib, h = self._lib, self._h
+        with torch.cuda.device(self.device):
+            for k in range(self.iter_num):
+                rc = lib.npa_forward_iter(h, k)
+                if rc:
+                    check(rc, "npa_forward_iter")
+            check(lib.npa_forward_end(h), "npa_forward_end")
+        out, self._pending = self._pending, None
+        self.last_out = out
+        return out
 
     def forward_batch_trace(self, nom_s, nom_u, ref_s, ref_us, points=None, velocities=None, n_points=None):
         """forward_batch that also returns the controls after every PAN iteration: out["trace_u"] (B, K, 2, T), the
