@@ -1,0 +1,42 @@
+"""The bench line's contract (what the round driver parses) checked on the committed line of the last measured build, and
+the tie between the tracked PMC file and the kernel sources it was measured on.  CPU only: nothing is run here."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _line(name):
+    return json.loads(open(os.path.join(ROOT, "profiles", name)).read().strip().split("\n")[-1])
+
+
+def test_default_bench_line_carries_every_contract_field():
+    d = _line("r02_bench.json")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "plans/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 256 * d["n_gpus"] * 1e3 / d["ms_per_step"]) <= 1e-3 * d["value"]      # whole-job plans / time
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma", "valu") and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1
+    p = d["parity"]
+    assert p["A_well_posed_all_le_tol"] and p["B_others_inside_envelope"] and p["C_le_1e-5_until_ensemble_diverges"]
+
+
+def test_tracked_pmc_file_matches_the_kernel_sources():
+    """bench.py prices the roofline with profiles/r02_pmc.json only when its source_hash equals the hash of the kernel
+    sources in the tree: a kernel edit without a new counter run would silently drop `achieved` / `frac` from the line."""
+    import bench
+    pj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
+    assert pj["source_hash"] == bench.source_hash()
+    k = pj["kernels"]["nrmp_qp_kernel"]
+    assert k["fp64_flops_per_launch"] > 0 and k["hbm_bytes_per_launch"] > 0 and 0 < k["valu_issue_frac"] < 1
