@@ -94,6 +94,22 @@ __device__ __forceinline__ double dpp_f64(double v) {
   int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
+// zero-filled DPP move inside a 16-lane row, and the inclusive prefix / suffix sums of lanes 0..15 built from it
+// (row_shr:n = lane i reads lane i-n, row_shl:n = lane i reads lane i+n; lanes beyond the row end read 0)
+template <int CTRL>
+__device__ __forceinline__ double dpp0_f64(double v) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_prefix_sum(double v) {
+  v += dpp0_f64<0x111>(v); v += dpp0_f64<0x112>(v); v += dpp0_f64<0x114>(v); v += dpp0_f64<0x118>(v);
+  return v;
+}
+__device__ __forceinline__ double row_suffix_sum(double v) {
+  v += dpp0_f64<0x101>(v); v += dpp0_f64<0x102>(v); v += dpp0_f64<0x104>(v); v += dpp0_f64<0x108>(v);
+  return v;
+}
 struct OpSum { __device__ static double f(double a, double b) { return a + b; } };
 struct OpMax { __device__ static double f(double a, double b) { return fmax(a, b); } };
 struct OpMin { __device__ static double f(double a, double b) { return fmin(a, b); } };
@@ -475,7 +491,27 @@ void nrmp_qp_kernel(
   int best_it = 0, stall = 0, status = 0, it = 0;
 
   // y = Phi v for all three state rows: out3[t][k] = sum_a Phi[t][k][a] v[a]
+  // With A_t = I + (A02, A12, 0)' e_2' the three products of an iteration with Phi are sums over the horizon (lane = t,
+  // T <= 16: one DPP row), not 2T-deep chains over a stored matrix:
+  //   s = Phi v :  theta_t = sum_{r<=t} B_r[2,:] v_r ;  xy_t = sum_{r<=t} (a_r theta_{r-1} + B_r[:2,:] v_r)
+  //   w = Phi'q :  l_xy,t = sum_{r>=t} q_r[:2] ;  l_2,t = sum_{r>=t} (q_r[2] + a_{r+1} . l_xy,r+1) ;  w_t = B_t' l_t
+  // (checked against the dense forms in fp64: tests/tools/scan_forms_check.py)
+  constexpr bool SCAN = TT > 0 && TT <= 16;
   auto phi_mul = [&](const double* v, double* out3) {
+    if constexpr (SCAN) {
+      const bool on = lane < TT;
+      const int t = on ? lane : 0;
+      const double2 vt = ld2(v + 2 * t);
+      const double* o = Abc + t * 12;
+      const double2 a01 = ld2(o), b0 = ld2(o + 2), b1 = ld2(o + 4), b2 = ld2(o + 6);
+      const double bu2 = on ? b2.x * vt.x + b2.y * vt.y : 0.0;
+      const double th = row_prefix_sum(bu2), thx = th - bu2;               // theta_{t+1}, theta_t
+      const double i0 = on ? fma(a01.x, thx, b0.x * vt.x + b0.y * vt.y) : 0.0;
+      const double i1 = on ? fma(a01.y, thx, b1.x * vt.x + b1.y * vt.y) : 0.0;
+      const double x = row_prefix_sum(i0), y = row_prefix_sum(i1);
+      if (on) { out3[3 * t] = x; out3[3 * t + 1] = y; out3[3 * t + 2] = th; }
+      return;
+    }
     for (int q = lane; q < 3 * T; q += QP_THREADS) {
       int t = q / 3, k = q - 3 * t;
       const double* Pr = Phi + ((size_t)t * 3 + k) * ldp;
@@ -493,6 +529,21 @@ void nrmp_qp_kernel(
   // w_a = sum_{t,k} Phi[t][k][a] in3[t][k]   (returned for a = lane, 0 for lane >= nu)
   auto phi_tmul = [&](const double* in3) -> double {
     double acc = 0;
+    if constexpr (SCAN) {
+      const bool on = lane < TT;
+      const int t = on ? lane : 0;
+      const double q0 = on ? in3[3 * t] : 0.0, q1 = on ? in3[3 * t + 1] : 0.0, q2 = on ? in3[3 * t + 2] : 0.0;
+      const double l0 = row_suffix_sum(q0), l1 = row_suffix_sum(q1);
+      const double2 an = ld2(Abc + (t + 1 < TT ? t + 1 : t) * 12);         // a of step t+1 (meets l = 0 at the last step)
+      const double l2 = row_suffix_sum(on ? q2 + an.x * dpp0_f64<0x101>(l0) + an.y * dpp0_f64<0x101>(l1) : 0.0);
+      const double* o = Abc + t * 12;
+      const double2 b0 = ld2(o + 2), b1 = ld2(o + 4), b2 = ld2(o + 6);
+      // lane t holds w_{2t}, w_{2t+1}; the callers want w_a in lane a: through the operand's own block (it is consumed)
+      double* stage = const_cast<double*>(in3);
+      if (on) st2(stage + 2 * t, b0.x * l0 + b1.x * l1 + b2.x * l2, b0.y * l0 + b1.y * l1 + b2.y * l2);
+      LSYNC();
+      return lane < nu ? stage[lane] : 0.0;
+    }
     if (lane < nu) {
       const int a = lane;
       if constexpr (TT > 0) {        // Phi[t][k][a] is stored as 0 for t < a/2: no lane-dependent trip count
@@ -752,8 +803,26 @@ void nrmp_qp_kernel(
       // with P_t = S'_t + A(t+1)' P_{t+1} A(t+1) (3x3, backward in t; A = I + a e_2') the entries of
       // block row i are  K'[a][c] += (P_i B_i[:,a&1]) . Phi_i[:,c]  for c <= a   (3 FMAs each).
       {
+        double* Pst = Yt;                              // [T][6] staging of P_t
+        if constexpr (SCAN) {
+          // A(t+1)...A(s) = I + (c_s - c_t) e_2' with c the prefix sum of a, so the blocks of P_t are suffix sums over
+          // s >= t of S_s, S_s c_s and c_s'S_s c_s (lane = t; no serial recursion, no broadcast of S'):
+          //   P_xy,xy = sS ;  P_xy,2 = sSc - sS c_t ;  P_22 = scSc - 2 c_t . sSc + c_t' sS c_t
+          const bool on = lane < TT;
+          const double2 a01 = ld2(Abc + (on ? lane : 0) * 12);
+          const double c0 = row_prefix_sum(on ? a01.x : 0.0), c1 = row_prefix_sum(on ? a01.y : 0.0);
+          const double s00 = on ? S0r : 0.0, s01 = on ? S1r : 0.0, s11 = on ? S2r : 0.0;
+          const double sc0 = s00 * c0 + s01 * c1, sc1 = s01 * c0 + s11 * c1;
+          const double p00 = row_suffix_sum(s00), p01 = row_suffix_sum(s01), p11 = row_suffix_sum(s11);
+          const double t0 = row_suffix_sum(sc0), t1 = row_suffix_sum(sc1), t2 = row_suffix_sum(c0 * sc0 + c1 * sc1);
+          const double u0 = p00 * c0 + p01 * c1, u1 = p01 * c0 + p11 * c1;
+          if (on) {
+            st2(Pst + lane * 6, p00, p01);
+            st2(Pst + lane * 6 + 2, t0 - u0, p11);
+            st2(Pst + lane * 6 + 4, t1 - u1, t2 - 2.0 * (c0 * t0 + c1 * t1) + (c0 * u0 + c1 * u1));
+          }
+        } else {
         double p00 = 0, p01 = 0, p02 = 0, p11 = 0, p12 = 0, p22 = 0;
-        double* Pst = Yt;                              // [T][6] staging of P_t (uniform values)
         // A_t = I + (a0, a1, 0)' e_2': lane t fetches its pair once, the chain below broadcasts them with v_readlane
         // (an LDS load per step would sit on the serial path)
         const double2 a01 = ld2(Abc + (lane < TT ? lane : 0) * 12);
@@ -768,6 +837,7 @@ void nrmp_qp_kernel(
           p00 += readlane_f64(S0r, t); p01 += readlane_f64(S1r, t); p11 += readlane_f64(S2r, t);
           Pst[t * 6 + 0] = p00; Pst[t * 6 + 1] = p01; Pst[t * 6 + 2] = p02;
           Pst[t * 6 + 3] = p11; Pst[t * 6 + 4] = p12; Pst[t * 6 + 5] = p22;
+        }
         }
       }
       const int ar = lane < NU ? lane : 0;
