@@ -21,7 +21,8 @@
 // Newton system is reduced once more by eliminating d (its block of the KKT matrix is
 // diagonal), which leaves a dense SPD 2T x 2T system in u:
 //      K' = H + C_u' D C_u + sum_t Phi_xy(t)' S'_t Phi_xy(t),   S'_t = S_t - v_t v_t'/kappa_t
-// factored by a left-looking Cholesky with one matrix row per lane.
+// factored by a Cholesky with one matrix row per lane (right-looking in the register-resident instantiations, pivot
+// chain on v_readlane; left-looking over the LDS matrix in the generic one).
 //
 // Why one wave per scene: the solve is a serial chain of small dense steps (latency bound);
 // scenes are independent, so throughput comes from the batch.  Matrices live in LDS with odd
@@ -34,6 +35,11 @@
 
 #define QP_THREADS 64          // lanes cooperating on one scene (one wavefront)
 #define QP_MAX_IT 40
+// per-step records in LDS, one lane per horizon step: strides chosen so that ten (twenty) lanes hit distinct banks.  With
+// the natural strides -- 12 doubles for the linearisation, 8 for the step sums -- steps 0 / 8 (and 0 / 4 / 8) shared a bank on
+// every 64-bit access (bank = dword address mod 64 for reads, mod 32 for writes)
+#define QP_ABC_LD 14           // [T][14]: A02 A12 B00 B01 B10 B11 B20 B21 C0 C1 C2 (even: read two at a time)
+#define QP_ST_LD 9             // [T][9]:  S'00 S'01 S'11 v0 v1 sigma 1/kappa r1_d
 #define QP_WARM_DELTA 0.01     // floor of the multipliers / slacks taken over from the previous solve
 #define QP_WARM_STEP 0.1       // largest control change of the previous solve after which its result is reused
 // the cold starting point: u = 0, d mid-range, unit multipliers, slacks >= 1 (a macro: used before the loop and, in the
@@ -109,6 +115,40 @@ __device__ __forceinline__ double row_prefix_sum(double v) {
 __device__ __forceinline__ double row_suffix_sum(double v) {
   v += dpp0_f64<0x101>(v); v += dpp0_f64<0x102>(v); v += dpp0_f64<0x104>(v); v += dpp0_f64<0x108>(v);
   return v;
+}
+// The same over lanes 0..31 (horizons of 17..32 steps, lane = t): the row scan plus the other row's total.  Prefix: lane 15
+// of row 0 reaches row 1 with row_bcast:15 (rows 0 and 2 masked off, they receive 0).  Suffix: lane 16 holds row 1's total.
+// WIDE = false: a single row, nothing added.
+template <bool WIDE>
+__device__ __forceinline__ double scan_prefix(double v) {
+  v = row_prefix_sum(v);
+  if constexpr (WIDE) {
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x142, 0xA, 0xF, false);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x142, 0xA, 0xF, false);
+    v += __hiloint2double(hi, lo);
+  }
+  return v;
+}
+template <bool WIDE>
+__device__ __forceinline__ double scan_suffix(double v, double row0) {      // row0 = 1.0 in lanes 0..15, else 0.0
+  v = row_suffix_sum(v);
+  if constexpr (WIDE) {
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)__double2loint(v), 16);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)__double2hiint(v), 16);
+    v = fma(row0, __hiloint2double((int)hi, (int)lo), v);
+  }
+  return v;
+}
+// value of lane + 1 (0 behind the last lane of the scan)
+template <bool WIDE>
+__device__ __forceinline__ double scan_next(double v, int lane) {
+  double x = dpp0_f64<0x101>(v);
+  if constexpr (WIDE) {
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)__double2loint(v), 16);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)__double2hiint(v), 16);
+    if (lane == 15) x = __hiloint2double((int)hi, (int)lo);
+  }
+  return x;
 }
 struct OpSum { __device__ static double f(double a, double b) { return a + b; } };
 struct OpMax { __device__ static double f(double a, double b) { return fmax(a, b); } };
@@ -196,7 +236,8 @@ __device__ __forceinline__ PairC qp_pair(int p, int T, int npu, double sb0, doub
 }
 
 template <int TT, int MM, bool BWD = false>
-// (at least two waves per SIMD: <= 256 registers; the T = 10 instantiation takes 165, the T = 20 one 220)
+// (two waves per SIMD: <= 256 registers.  tests/test_abi.py reads the counts of the built code object and fails on any
+// spill or scratch use)
 __global__ __attribute__((amdgpu_flat_work_group_size(QP_THREADS, QP_THREADS), amdgpu_waves_per_eu(2, 3)))
 void nrmp_qp_kernel(
     DevParams P, const float* cur_s_in, const float* cur_u_in, const float* __restrict__ ref_s,
@@ -280,8 +321,8 @@ void nrmp_qp_kernel(
   double* q3 = s3 + T * 3;                    // [T][3]  operand of Phi'
   double* Yt = TT > 0 ? s3 : Ytg;
   double* Abc = q3 + T * 3;                   // [T][12]
-  double* St = Abc + T * 12;                  // [T][8]  S'00 S'01 S'11 v0 v1 sigma 1/kappa r1d
-  double* xu = St + T * 8;                    // [nu]    (xu, xd contiguous: the pairs index them as one vector)
+  double* St = Abc + T * QP_ABC_LD;           // [T][QP_ST_LD]  S'00 S'01 S'11 v0 v1 sigma 1/kappa r1d
+  double* xu = St + ((T * QP_ST_LD + 1) & ~1);                   // [nu]    (xu, xd contiguous: the pairs index them as one vector)
   double* xd = xu + nu;                       // [T]
   double* xbest = xd + T;                     // [nu+T]
   double* dxu = xbest + nu + T;               // [nu]    (dxu, dxd contiguous)
@@ -314,7 +355,7 @@ void nrmp_qp_kernel(
   for (int t = lane; t < T; t += QP_THREADS) {
     float phi = s_in[2 * (T + 1) + t], v = u_in[t], psi = u_in[T + t];
     const float dt32 = P.dt32;
-    double* o = Abc + t * 12;
+    double* o = Abc + t * QP_ABC_LD;
     float A02 = 0.f, A12 = 0.f, B00, B01 = 0.f, B10, B11 = 0.f, B20 = 0.f, B21 = 0.f, C0, C1, C2 = 0.f;
     if (P.kin == 2) {                      // omni: phi := u[1]
       double sp = sin((double)psi), cp = cos((double)psi);
@@ -365,7 +406,7 @@ void nrmp_qp_kernel(
 
   // ---- Phi recursion: Phi[t] = A_t Phi[t-1] + [B_t at cols 2t,2t+1]; A = I + e0 A02 e2' + e1 A12 e2'
   for (int t = 0; t < T; ++t) {
-    const double* o = Abc + t * 12;
+    const double* o = Abc + t * QP_ABC_LD;
     double* Pt = Phi + (size_t)t * 3 * ldp;
     const double* Pp = Pt - 3 * ldp;
     for (int c = lane; c < nu; c += QP_THREADS) {
@@ -450,7 +491,7 @@ void nrmp_qp_kernel(
     for (int i = lane; i < mf; i += QP_THREADS) ff[i] = hinge_row(i);
   }
   if (bw.dbg_abc) {
-    for (int q = lane; q < T * 11; q += QP_THREADS) bw.dbg_abc[(size_t)b * T * 11 + q] = (float)Abc[(q / 11) * 12 + (q % 11)];
+    for (int q = lane; q < T * 11; q += QP_THREADS) bw.dbg_abc[(size_t)b * T * 11 + q] = (float)Abc[(q / 11) * QP_ABC_LD + (q % 11)];
     return;
   }
 
@@ -496,19 +537,21 @@ void nrmp_qp_kernel(
   //   s = Phi v :  theta_t = sum_{r<=t} B_r[2,:] v_r ;  xy_t = sum_{r<=t} (a_r theta_{r-1} + B_r[:2,:] v_r)
   //   w = Phi'q :  l_xy,t = sum_{r>=t} q_r[:2] ;  l_2,t = sum_{r>=t} (q_r[2] + a_{r+1} . l_xy,r+1) ;  w_t = B_t' l_t
   // (checked against the dense forms in fp64: tests/tools/scan_forms_check.py)
-  constexpr bool SCAN = TT > 0 && TT <= 16;
+  constexpr bool SCAN = TT > 0 && TT <= 32;
+  constexpr bool WIDE = TT > 16;
+  const double row0 = lane < 16 ? 1.0 : 0.0;
   auto phi_mul = [&](const double* v, double* out3) {
     if constexpr (SCAN) {
       const bool on = lane < TT;
       const int t = on ? lane : 0;
       const double2 vt = ld2(v + 2 * t);
-      const double* o = Abc + t * 12;
+      const double* o = Abc + t * QP_ABC_LD;
       const double2 a01 = ld2(o), b0 = ld2(o + 2), b1 = ld2(o + 4), b2 = ld2(o + 6);
       const double bu2 = on ? b2.x * vt.x + b2.y * vt.y : 0.0;
-      const double th = row_prefix_sum(bu2), thx = th - bu2;               // theta_{t+1}, theta_t
+      const double th = scan_prefix<WIDE>(bu2), thx = th - bu2;               // theta_{t+1}, theta_t
       const double i0 = on ? fma(a01.x, thx, b0.x * vt.x + b0.y * vt.y) : 0.0;
       const double i1 = on ? fma(a01.y, thx, b1.x * vt.x + b1.y * vt.y) : 0.0;
-      const double x = row_prefix_sum(i0), y = row_prefix_sum(i1);
+      const double x = scan_prefix<WIDE>(i0), y = scan_prefix<WIDE>(i1);
       if (on) { out3[3 * t] = x; out3[3 * t + 1] = y; out3[3 * t + 2] = th; }
       return;
     }
@@ -533,10 +576,10 @@ void nrmp_qp_kernel(
       const bool on = lane < TT;
       const int t = on ? lane : 0;
       const double q0 = on ? in3[3 * t] : 0.0, q1 = on ? in3[3 * t + 1] : 0.0, q2 = on ? in3[3 * t + 2] : 0.0;
-      const double l0 = row_suffix_sum(q0), l1 = row_suffix_sum(q1);
-      const double2 an = ld2(Abc + (t + 1 < TT ? t + 1 : t) * 12);         // a of step t+1 (meets l = 0 at the last step)
-      const double l2 = row_suffix_sum(on ? q2 + an.x * dpp0_f64<0x101>(l0) + an.y * dpp0_f64<0x101>(l1) : 0.0);
-      const double* o = Abc + t * 12;
+      const double l0 = scan_suffix<WIDE>(q0, row0), l1 = scan_suffix<WIDE>(q1, row0);
+      const double2 an = ld2(Abc + (t + 1 < TT ? t + 1 : t) * QP_ABC_LD);         // a of step t+1 (meets l = 0 at the last step)
+      const double l2 = scan_suffix<WIDE>(on ? q2 + an.x * scan_next<WIDE>(l0, lane) + an.y * scan_next<WIDE>(l1, lane) : 0.0, row0);
+      const double* o = Abc + t * QP_ABC_LD;
       const double2 b0 = ld2(o + 2), b1 = ld2(o + 4), b2 = ld2(o + 6);
       // lane t holds w_{2t}, w_{2t+1}; the callers want w_a in lane a: through the operand's own block (it is consumed)
       double* stage = const_cast<double*>(in3);
@@ -596,9 +639,9 @@ void nrmp_qp_kernel(
   // of convergence).  As a backstop a warm-started solve that ends above 1e-10 is repeated from the cold start
   // (need_cold: the same loop, re-initialised at its top).
   // The limit point is the same either way (both stop at 1e-14: measured |du| <= 7e-7 against the cold solve).
-  // (Compiled into the T = 10 and the generic instantiation only: the T = 20 one -- 256 VGPRs + AGPRs and ~400 spilled
-  // SGPRs -- came out of hipcc 7.2 with corrupted loop scalars (best_merit, stall) in every form of this logic tried;
-  // it keeps the plain cold start.)
+  // (Every forward instantiation takes it.  History: while the T = 20 one still needed 256 VGPRs + AGPR copies and ~400
+  // spilled SGPRs, hipcc 7.2 produced corrupted loop scalars (best_merit, stall) for every form of this logic; the
+  // spill-free build does not show it, and npa_create's self-test re-checks warm against cold on the device.)
   constexpr bool WARM = !BWD;
   const int nwarm = nu + T + mf + mcu + 2 * T;
   double* wrm = (WARM && warm) ? warm + (size_t)b * nwarm : nullptr;
@@ -724,7 +767,7 @@ void nrmp_qp_kernel(
         r1d = -(double)P.eta + ld_[2 * t] - ld_[2 * t + 1] + zs;       // g_d + C'lam - F'lam
       }
       double ik = obs ? fast_rcp(kap) : 0.0;
-      double* S = St + t * 8;
+      double* S = St + t * QP_ST_LD;
       S[0] = s00 - v0 * v0 * ik; S[1] = s01 - v0 * v1 * ik; S[2] = s11 - v1 * v1 * ik;
       S[3] = v0; S[4] = v1; S[5] = sg; S[6] = ik; S[7] = r1d;
       // operand of Phi' for r1_u:  W .* (Phi x) + lin - [z; 0]
@@ -809,12 +852,12 @@ void nrmp_qp_kernel(
           // s >= t of S_s, S_s c_s and c_s'S_s c_s (lane = t; no serial recursion, no broadcast of S'):
           //   P_xy,xy = sS ;  P_xy,2 = sSc - sS c_t ;  P_22 = scSc - 2 c_t . sSc + c_t' sS c_t
           const bool on = lane < TT;
-          const double2 a01 = ld2(Abc + (on ? lane : 0) * 12);
-          const double c0 = row_prefix_sum(on ? a01.x : 0.0), c1 = row_prefix_sum(on ? a01.y : 0.0);
+          const double2 a01 = ld2(Abc + (on ? lane : 0) * QP_ABC_LD);
+          const double c0 = scan_prefix<WIDE>(on ? a01.x : 0.0), c1 = scan_prefix<WIDE>(on ? a01.y : 0.0);
           const double s00 = on ? S0r : 0.0, s01 = on ? S1r : 0.0, s11 = on ? S2r : 0.0;
           const double sc0 = s00 * c0 + s01 * c1, sc1 = s01 * c0 + s11 * c1;
-          const double p00 = row_suffix_sum(s00), p01 = row_suffix_sum(s01), p11 = row_suffix_sum(s11);
-          const double t0 = row_suffix_sum(sc0), t1 = row_suffix_sum(sc1), t2 = row_suffix_sum(c0 * sc0 + c1 * sc1);
+          const double p00 = scan_suffix<WIDE>(s00, row0), p01 = scan_suffix<WIDE>(s01, row0), p11 = scan_suffix<WIDE>(s11, row0);
+          const double t0 = scan_suffix<WIDE>(sc0, row0), t1 = scan_suffix<WIDE>(sc1, row0), t2 = scan_suffix<WIDE>(c0 * sc0 + c1 * sc1, row0);
           const double u0 = p00 * c0 + p01 * c1, u1 = p01 * c0 + p11 * c1;
           if (on) {
             st2(Pst + lane * 6, p00, p01);
@@ -825,7 +868,7 @@ void nrmp_qp_kernel(
         double p00 = 0, p01 = 0, p02 = 0, p11 = 0, p12 = 0, p22 = 0;
         // A_t = I + (a0, a1, 0)' e_2': lane t fetches its pair once, the chain below broadcasts them with v_readlane
         // (an LDS load per step would sit on the serial path)
-        const double2 a01 = ld2(Abc + (lane < TT ? lane : 0) * 12);
+        const double2 a01 = ld2(Abc + (lane < TT ? lane : 0) * QP_ABC_LD);
 #pragma unroll
         for (int t = TT - 1; t >= 0; --t) {
           if (t < TT - 1) {
@@ -856,7 +899,7 @@ void nrmp_qp_kernel(
       {
         const int i = ar >> 1, k2 = ar & 1;
         const double* Pi = Yt + i * 6;
-        const double* Bi = Abc + i * 12 + 2 + k2;      // B_i[:, k2] = o[2+k2], o[4+k2], o[6+k2]
+        const double* Bi = Abc + i * QP_ABC_LD + 2 + k2;      // B_i[:, k2] = o[2+k2], o[4+k2], o[6+k2]
         const double b0 = Bi[0], b1 = Bi[2], b2 = Bi[4];
         const double g0 = Pi[0] * b0 + Pi[1] * b1 + Pi[2] * b2;
         const double g1 = Pi[1] * b0 + Pi[3] * b1 + Pi[4] * b2;
@@ -925,7 +968,7 @@ void nrmp_qp_kernel(
     for (int q = lane; q < 2 * T * nu; q += QP_THREADS) {        // Y[t][k][c] = S'_t[k][:] Phi_xy[t][:, c]
       int tk = q / nu, c = q - tk * nu, t = tk >> 1, k = tk & 1;
       const double* Pt = Phi + (size_t)t * 3 * ldp;
-      const double* S = St + t * 8;
+      const double* S = St + t * QP_ST_LD;
       Yt[(size_t)tk * ldp + c] = (c <= 2 * t + 1) ? S[k] * Pt[c] + S[k + 1] * Pt[ldp + c] : 0.0;
     }
     LSYNC();
@@ -1000,7 +1043,7 @@ void nrmp_qp_kernel(
         LSYNC();
         r1u = phi_tmul(q3);
         if (lane < nu) r1u = -(r1u + (double)bw.grad_u[(size_t)b * 2 * T + (lane & 1) * T + (lane >> 1)]);
-        if (lane < T) St[lane * 8 + 7] = bw.grad_d ? -(double)bw.grad_d[(size_t)b * T + lane] : 0.0;
+        if (lane < T) St[lane * QP_ST_LD + 7] = bw.grad_d ? -(double)bw.grad_d[(size_t)b * T + lane] : 0.0;
         LSYNC();
       }
     }
@@ -1054,7 +1097,7 @@ void nrmp_qp_kernel(
           for (int j = 0; j < M; ++j) { int i = t * M + j; double w = dwf[i]; z0 += w * fa0[i]; z1 += w * fa1[i]; zs += w; }
         }
         double rd = 0;
-        const double* S = St + t * 8;                                       // v0 v1 at [3] [4], 1/kappa [6], r1_d [7]
+        const double* S = St + t * QP_ST_LD;                                       // v0 v1 at [3] [4], 1/kappa [6], r1_d [7]
         if (obs) rd = -S[7] - (dwd[2 * t] - dwd[2 * t + 1]) + zs;           // rhs of the d rows
         double e = rd * S[6];                                               // rhs_d / kappa
         rdr = rd;
@@ -1110,7 +1153,7 @@ void nrmp_qp_kernel(
       phi_mul(dxu, s3);
       LSYNC();
       for (int t = lane; t < T && obs; t += QP_THREADS)
-        dxd[t] = (rdr + St[t * 8 + 3] * s3[t * 3] + St[t * 8 + 4] * s3[t * 3 + 1]) * St[t * 8 + 6];
+        dxd[t] = (rdr + St[t * QP_ST_LD + 3] * s3[t * 3] + St[t * QP_ST_LD + 4] * s3[t * 3 + 1]) * St[t * QP_ST_LD + 6];
       LSYNC();
       PROF_C(5);
       // directions of multipliers / slacks and the step to the boundary
@@ -1300,8 +1343,21 @@ void nrmp_qp_kernel(
 
   // ---- per-forward outputs of the last executed iteration -------------------------------------
   const int cnt0 = (obs && count) ? count[(size_t)b * (T + 1)] : 0;
-  if (out_min_distance && lane == 0)
-    out_min_distance[b] = (obs && cnt0 > 0) ? dist_sorted[(size_t)b * (T + 1) * M] : __builtin_inff();
+  if (out_min_distance && lane == 0) {
+    // DUNE.min_distance is only assigned by a forward WITH points (dune.py:97-98) and keeps its value otherwise
+    // (pan.py:246-252 reads the attribute): the last value lives in the scene's state record, next to the stop
+    // criterion's memory (ints 2, 3 of its tail), so it carries over whether or not anybody read it in between
+    float mdv = __builtin_inff();
+    const bool have_md = obs && cnt0 > 0;
+    if (have_md) mdv = dist_sorted[(size_t)b * (T + 1) * M];
+    if (state) {
+      const int Ms_ = M > 0 ? M : 1;
+      int* tail = reinterpret_cast<int*>(state + (size_t)(b + 1) * npa_state_floats(T, Ms_, E)) - 4;
+      if (have_md) { tail[2] = 1; tail[3] = __float_as_int(mdv); }
+      else if (tail[2]) mdv = __int_as_float(tail[3]);
+    }
+    out_min_distance[b] = mdv;
+  }
   if (out_nrmp_points && obs)
     for (int q = lane; q < 2 * M; q += QP_THREADS) {
       int k = q / M, j = q - k * M;
@@ -1383,7 +1439,7 @@ extern "C" size_t npa_qp_shmem_bytes_path(int T, int M, int fast) {
   const bool regrows = fast && M > 0 && M % 2 == 0 && T * M / 2 <= QP_THREADS && 5 * T - 2 <= QP_THREADS;
   const size_t rows = (regrows ? 3 : 6) * mcd + (regrows ? 5 : 9) * mfe;
   const size_t mats = fast ? nu * (nu + 1) / 2 + nu * ldp : (size_t)T * 2 * ldp + 2 * nu * ldp;
-  size_t d = rows + (size_t)T * 3 * ldp + mats + 4 * (T * 3) + T * 12 + T * 8 + nu + T + (nu + T) + nu + T + nu;
+  size_t d = rows + (size_t)T * 3 * ldp + mats + 4 * (T * 3) + T * QP_ABC_LD + (((size_t)T * QP_ST_LD + 1) & ~(size_t)1) + nu + T + (nu + T) + nu + T + nu;
   size_t bytes = d * sizeof(double) + (fast ? 0 : 2 * ((npair + 7) & ~(size_t)7));
   return (bytes + 15) & ~(size_t)15;
 }

@@ -82,7 +82,8 @@ enum { V_B1 = 0, V_G1, V_BE1, V_B2, V_B3, V_G2, V_BE2, V_B4, V_B5, V_G3, V_BE3 }
 __host__ __device__ inline int npa_feat(int r, int hf) { return (r & 3) + 8 * (r >> 2) + 4 * hf; }
 
 // ---- per-scene persistent state (stop criterion memory, pan.py:100-105) -------------------
-// floats: prev_s[3(T+1)] prev_u[2T] prev_mu[(T+1) M E] prev_lam[(T+1) M 2]; ints: valid, prev_n
+// floats: prev_s[3(T+1)] prev_u[2T] prev_mu[(T+1) M E] prev_lam[(T+1) M 2]; ints: valid, prev_n, min-distance valid,
+// min-distance bits (DUNE.min_distance of the last forward WITH points, dune.py:97-98)
 __host__ __device__ inline size_t npa_state_floats(int T, int M, int E) {
   return (size_t)3 * (T + 1) + 2 * T + (size_t)(T + 1) * M * E + (size_t)(T + 1) * M * 2 + 4;
 }

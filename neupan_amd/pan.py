@@ -316,14 +316,11 @@ class PAN(torch.nn.Module):
                 _ptr(velocities), _ptr(n_points), _ptr(out_s), _ptr(out_u), _ptr(out_d), _ptr(out_md), _ptr(out_it),
                 _ptr(out_np), _ptr(ws), ws.numel(), _ptr(state), state.numel(), C.c_void_p(stream),
                 2 if reset_state else 0), "npa_forward_begin")
-        # keep inputs alive until the stream has consumed them
-        # DUNE.min_distance keeps its last value over calls without points (dune.py:97-98 runs only with points;
-        # pan.py:246-252 reads the attribute): remember the last distances that came from points
-        prev = self._last["md_keep"] if self._last is not None and self._last.get("md_keep") is not None and \
-            self._last["md_keep"].shape[0] == B else None
+        # keep inputs alive until the stream has consumed them.  (DUNE.min_distance keeps its last value over calls without
+        # points -- dune.py:97-98 runs only with points, pan.py:246-252 reads the attribute: the kernel carries that value
+        # in the scene's state record, so out_md already is the persistent value, read or not in between.)
         self._last = dict(points=points, velocities=velocities, n_points=n_points, min_distance=out_md,
-                          nrmp_points=out_np, used_points=use_pts, hold=(nom_s, nom_u, ref_s, ref_us), md_prev=prev,
-                          md_keep=None)
+                          nrmp_points=out_np, used_points=use_pts, hold=(nom_s, nom_u, ref_s, ref_us))
         self._pending = dict(opt_s=out_s, opt_u=out_u, opt_d=out_d, min_distance=out_md, iters=out_it, nrmp_points=out_np)
 
     def forward_iter(self, k):
@@ -348,10 +345,16 @@ class PAN(torch.nn.Module):
         # batch in flight, and the per-iteration Python was half of a step's host time)
         lib, h = self._lib, self._h
         with torch.cuda.device(self.device):
-            for k in range(self.iter_num):
-                rc = lib.npa_forward_iter(h, k)
-                if rc:
-                    check(rc, "npa_forward_iter")
+            try:
+                for k in range(self.iter_num):
+                    rc = lib.npa_forward_iter(h, k)
+                    if rc:
+                        check(rc, "npa_forward_iter")
+            except BaseException:
+                # close the call on the handle, or every later forward_begin fails with "previous forward not ended"
+                lib.npa_forward_end(h)
+                self._pending = None
+                raise
             check(lib.npa_forward_end(h), "npa_forward_end")
         out, self._pending = self._pending, None
         self.last_out = out
@@ -392,15 +395,7 @@ class PAN(torch.nn.Module):
         last call keeps the value of its last call WITH points (dune.py:97-98), +inf if there never was one."""
         if self.no_obs or self._last is None:
             return None
-        L = self._last
-        if L["md_keep"] is None:
-            md, prev = L["min_distance"], L["md_prev"]
-            if not L["used_points"]:
-                md = prev if prev is not None else torch.full_like(md, inf)
-            elif prev is not None:
-                md = torch.where(torch.isinf(md), prev, md)          # scenes with n_points == 0 this call
-            L["md_keep"] = md
-        return L["md_keep"]
+        return self._last["min_distance"]
 
     @property
     def min_distance(self):

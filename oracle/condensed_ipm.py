@@ -74,12 +74,20 @@ def condense(pb: NrmpProblem):
     return H, g, F, f, C, c, Phi, cv
 
 
-WARM_DELTA = 0.1        # QP_WARM_DELTA in nrmp_qp.hip
+WARM_DELTA = 0.01       # QP_WARM_DELTA in nrmp_qp.hip
+# a warm attempt is dropped (the solve restarts cold) when its merit exceeds these at iteration 0 / 3 / 7, and repeated
+# cold when it ends above WARM_ACCEPT -- the kernel's rules (nrmp_qp.hip, "a warm start that is not paying off").  The
+# gate on the PREVIOUS solve (converged, controls moved < QP_WARM_STEP) is the caller's: pass warm=None when it fails.
+WARM_DROP = {0: 0.05, 3: 1e-4, 7: 1e-8}
+WARM_ACCEPT = 1e-10
 
 
 def solve_condensed(pb: NrmpProblem, tol=1e-14, max_iter=40, trace=None, warm=None):
     """warm = (x, lc, lf) of a previous, similar solve: the kernel's warm start across the PAN
-    iterations of one forward call (multipliers and slacks floored at WARM_DELTA)."""
+    iterations of one forward call (multipliers and slacks floored at WARM_DELTA), with the kernel's drop rules: the
+    attempt is abandoned for a cold start at iteration 0 / 3 / 7 when its merit is above WARM_DROP, and a warm-started
+    solve that ends above WARM_ACCEPT is repeated cold.  info["warm_code"]: 0 cold, 1 warm start used, 2 / 3 dropped at
+    iteration 0 / later, 4 not converged (qp_info[15] of the kernel)."""
     H, g, F, f, C, c, Phi, cv = condense(pb)
     n = H.shape[0]; T = pb.T; nu = 2 * T
     ro = pb.ro_obs
@@ -113,6 +121,11 @@ def solve_condensed(pb: NrmpProblem, tol=1e-14, max_iter=40, trace=None, warm=No
             trace.append(dict(it=it, merit=merit, mu=mu, x=x.copy()))
         if not np.isfinite(merit):
             break
+        if warm is not None and it in WARM_DROP and merit > WARM_DROP[it]:
+            out = solve_condensed(pb, tol=tol, max_iter=max_iter, trace=trace)
+            out[3]["warm_code"] = 2 if it == 0 else 3
+            out[3]["iters_total"] = out[3]["iters_total"] + it
+            return out
         if merit < best[0]:
             best = (merit, x.copy(), it); stall = 0
         else:
@@ -148,8 +161,14 @@ def solve_condensed(pb: NrmpProblem, tol=1e-14, max_iter=40, trace=None, warm=No
         a = min(1.0, 0.995 * min(max_step(wc, dwc), max_step(lc, dlc), max_step(wf, dwf), max_step(lf, dlf)))
         x = x + a * dx; wc = wc + a * dwc; lc = lc + a * dlc; wf = wf + a * dwf; lf = lf + a * dlf
         lam_out = (lc, lf)
+    if warm is not None and not best[0] <= WARM_ACCEPT:
+        out = solve_condensed(pb, tol=tol, max_iter=max_iter, trace=trace)
+        out[3]["warm_code"] = 4
+        out[3]["iters_total"] = out[3]["iters_total"] + it
+        return out
     merit, x, it_used = best
     u = x[:nu].reshape(T, 2).T.copy()
     s = np.stack([Phi[t] @ x[:nu] + cv[t] for t in range(T + 1)], axis=1)
     d = None if pb.no_obs else x[nu:].reshape(1, T).copy()
-    return s, u, d, {"iters": it_used, "merit": merit, "warm": (x, lam_out[0], lam_out[1])}
+    return s, u, d, {"iters": it_used, "merit": merit, "warm": (x, lam_out[0], lam_out[1]), "iters_total": it,
+                     "warm_code": 0 if warm is None else 1}

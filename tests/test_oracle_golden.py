@@ -206,3 +206,29 @@ def test_qp_oracle_vs_highs_on_benchmark_problems(cfgname, scene, kw):
         # the sharp comparison, the controls a sanity bound
         assert c["du"] <= (5e-2 if cfgname.startswith("acker") else 2e-4), c
         assert c["cert"]["dyn"] < 1e-10 and c["cert"]["feas"] < 1e-9 and c["cert"]["comp"] < 1e-8, c
+
+
+def test_condensed_solver_warm_start_rules():
+    """oracle/condensed_ipm.py carries the kernel's warm start (nrmp_qp.hip): floor QP_WARM_DELTA = 0.01, drop rules at
+    iteration 0 / 3 / 7, cold retry.  (1) a solve started from its own solution is accepted, takes fewer iterations and
+    lands on the same point; (2) a start from an unrelated problem's solution is dropped or converges -- either way the
+    point is the cold solve's."""
+    g = golden("qp_cases")
+    n = int(g["count"])
+    fewer = 0
+    for i in range(min(n, 12)):
+        pb = _qp_problem(g, i)
+        s0, u0, d0, info0 = solve_condensed(pb)
+        assert info0["warm_code"] == 0
+        s1, u1, d1, info1 = solve_condensed(pb, warm=info0["warm"])
+        np.testing.assert_allclose(u1, u0, atol=2e-6)
+        assert info1["warm_code"] in (1, 2, 3, 4)
+        fewer += info1["warm_code"] == 1 and info1["iters_total"] < info0["iters_total"]
+        j = (i + 5) % n
+        pj = _qp_problem(g, j)
+        if pj.T == pb.T and pj.no_obs == pb.no_obs and getattr(pj, "M", None) == getattr(pb, "M", None):
+            sj = solve_condensed(pj)[3]["warm"]
+            if all(a.shape == b.shape for a, b in zip(sj, info0["warm"])):
+                s2, u2, d2, info2 = solve_condensed(pb, warm=sj)
+                np.testing.assert_allclose(u2, u0, atol=2e-6)
+    assert fewer >= 6, fewer
