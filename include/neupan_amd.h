@@ -92,6 +92,28 @@ int npa_destroy(npa_handle *h);
  *               (|x|, |y| <= 25 m), margin_e0 = 5 x that (NPA_KEY_SAFETY). */
 int npa_key_mode(const npa_handle *h, int *key_terms, float *measured_error, float *margin_e0);
 
+/* What npa_create measured about the geometric keys of THIS checkpoint (key_terms 4 or not), out[0..n), n <= 6:
+ *   [0] 1 when the polygon's rows are consecutive counter-clockwise edges (else geometric keys are never used),
+ *   [1] largest |network distance - geometric distance| [m] and [2] largest candidate margin over the bands 0.25 .. 8 m,
+ *   [3] refinement ratio: |f| measured at the CELL CENTRES of the calibration grids over what the grid nodes predicted for
+ *       the space between them (node maximum + neighbour difference), largest over the distance bands; <= 1 when the
+ *       grids resolve f, and a checkpoint above 1.25 keeps network keys (a ridge narrower than a grid cell),
+ *   [4] steepest neighbour difference per metre on the finest grid (an estimate of the Lipschitz constant of f next to
+ *       the robot), [5] g_far: points at or beyond this geometric distance are always candidates.
+ * The margin is MEASURED, not proven (LayerNorm leaves no usable analytic Lipschitz bound); npa_audit_read is the
+ * run-time check. */
+int npa_geo_report(const npa_handle *h, float *out, int n);
+
+/* Run-time audit of the geometric-key margin (key_terms 4).  Every launch of the selection kernel checks the bound
+ * |exact network distance - geometric distance| <= margin on every point it encodes exactly (the candidates), and a
+ * fraction of its slice waves (default 1 in 64; NPA_AUDIT_RATE) on 32 further points spread over the slice.  Counters
+ * since creation (or the last reset): audit tiles run, points they checked, violations seen (candidates included),
+ * largest excess over the margin [m].  While violations != 0 the kernel treats EVERY point as a candidate (exact keys for
+ * the whole slice: slow and right), so a wrong margin cannot keep producing wrong plans; the owner should then rebuild
+ * the handle with network keys (NPA_KEY_TERMS=1).  Synchronises the device.  reset != 0 zeroes the counters (and with them
+ * the distrust). */
+int npa_audit_read(npa_handle *h, uint64_t *tiles, uint64_t *points, uint64_t *violations, float *worst_excess, int reset);
+
 /* Replaces NRMP.update_adjust_parameters_value (nrmp.py:170-217). */
 int npa_set_adjust(npa_handle *h, const float q_s[3], float p_u, float eta, float d_max, float d_min);
 

@@ -20,7 +20,14 @@ extern "C" hipError_t npa_launch_trig(const float* cur_s, int batch, int T, floa
 extern "C" hipError_t npa_launch_key_calib(const DevParams& P, const float* wpack, int key_terms, int nside, float half,
                                            unsigned* out, hipStream_t stream);
 extern "C" hipError_t npa_launch_geo_calib(const DevParams& P, const float* wpack, int nside, float half, float inner,
-                                           unsigned* out, int n_cu, hipStream_t stream);
+                                           float shift, unsigned* out, int n_cu, hipStream_t stream);
+extern "C" hipError_t npa_launch_select_geo(const DevParams& P, const float* wpack, int batch, int scene0, int t0,
+                                            int n_stride, const float* cur_s, const float* points, const float* vel,
+                                            const int* n_points, const int* flags, const float* trig, float* mu_sorted,
+                                            float* lam_sorted, float* pts_sorted, float* dist_sorted, int* count,
+                                            unsigned* stats, int debug, unsigned* audit, unsigned audit_thresh,
+                                            unsigned audit_seed, float margin_scale, hipStream_t stream,
+                                            hipEvent_t ev_start, hipEvent_t ev_stop);
 extern "C" hipError_t npa_launch_select(const DevParams& P, const float* wpack, int batch, int scene0, int t0,
                                         int n_stride, const float* cur_s, const float* points, const float* vel,
                                         const int* n_points, const int* flags, const unsigned* gkeys,
@@ -70,6 +77,18 @@ struct npa_handle {
   int sel_debug = 0;                     // NPA_SEL_DEBUG at creation: npa_dune_stage's count[] carries candidate statistics
   bool geo_valid = false;                // the polygon could be turned into vertices (consecutive CCW edges)
   float geo_err = 0.f, geo_margin = 0.f; // largest |network - geometric distance| / margin over the bands g in [0.25, 8] m
+  // grid-refinement check of the margin (npa_create): largest ratio, over the bands, of |f| seen at the CELL CENTRES of a
+  // calibration grid to what its nodes predicted for the space between them (node maximum + neighbour difference);
+  // <= 1 when the grid resolves f.  geo_slope: largest neighbour difference / spacing on the finest grid (a Lipschitz
+  // estimate of f next to the robot, m per m)
+  float geo_refine = 0.f, geo_slope = 0.f;
+  bool select_v1 = false;                // NPA_SELECT_V1: the first form of the geometric-key selection (select_kernel<E, true>)
+  // run-time audit of the margin (select_geo_kernel): [0] audit tiles run, [1] points they checked, [2] bound violations seen
+  // (candidates and audit tiles), [3] float bits of the largest excess |exact - g| - margin
+  unsigned* audit_dev = nullptr;
+  unsigned audit_thresh = 0;             // fraction of the slice waves that run an audit tile, x 2^32
+  unsigned launch_seq = 0;
+  float margin_scale = 1.f;              // NPA_GEO_MARGIN_SCALE (tests only: a deliberately wrong margin)
   // key_auto: both reduced-precision modes are calibrated and the handle switches between them by what the
   // single-product keys cost in select_kernel (tiles it had to re-encode because more candidates fell inside the
   // margin than one tile holds -- walls at constant distance, dense clouds), see key_policy()
@@ -182,7 +201,7 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
     for (int L = 0; L < 4; ++L)
       for (int r = 0; r < 16; ++r)
         for (int l = 0; l < 64; ++l)
-          pack[WP_WL + (L * 16 + r) * 64 + l] = w->lin_w[1 + L][(l & 31) * 32 + npa_feat(r, l >> 5)];
+          pack[WP_WLS + (L * 64 + l) * 16 + r] = pack[WP_WL + (L * 16 + r) * 64 + l] = w->lin_w[1 + L][(l & 31) * 32 + npa_feat(r, l >> 5)];
     auto putv = [&](int slot, const float* src, float scale) {
       for (int i = 0; i < 32; ++i) pack[WP_VEC + slot * 32 + i] = src[i] * scale;
     };
@@ -315,20 +334,64 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
       e = hipMalloc(&tab, 2 * NPA_GEO_BANDS * sizeof(unsigned));
       if (e == hipSuccess) e = hipMemset(tab, 0, 2 * NPA_GEO_BANDS * sizeof(unsigned));
       const float halves[3] = {8.f, 32.f, 128.f};
+      // NPA_GEO_GRID (tests): nodes per side of the three calibration grids (default 4096; a multiple of 8)
+      int nside = 4096;
+      if (const char* env = getenv("NPA_GEO_GRID")) { int v = atoi(env); if (v >= 64 && v <= 8192) nside = v / 8 * 8; }
       for (int gI = 0; gI < 3 && e == hipSuccess; ++gI)
-        e = npa_launch_geo_calib(P, h->wpack, 4096, halves[gI], gI == 0 ? 0.f : 0.97f * halves[gI - 1], tab, h->n_cu, nullptr);
-      unsigned bits[2 * NPA_GEO_BANDS];
+        e = npa_launch_geo_calib(P, h->wpack, nside, halves[gI], gI == 0 ? 0.f : 0.97f * halves[gI - 1], 0.f, tab, h->n_cu, nullptr);
+      // the same three grids shifted by half a cell: their nodes are the cell centres of the first pass
+      unsigned* tab2 = nullptr;
+      if (e == hipSuccess) e = hipMalloc(&tab2, 2 * NPA_GEO_BANDS * sizeof(unsigned));
+      if (e == hipSuccess) e = hipMemset(tab2, 0, 2 * NPA_GEO_BANDS * sizeof(unsigned));
+      for (int gI = 0; gI < 3 && e == hipSuccess; ++gI)
+        e = npa_launch_geo_calib(P, h->wpack, nside, halves[gI], gI == 0 ? 0.f : 0.97f * halves[gI - 1], 0.5f, tab2, h->n_cu, nullptr);
+      unsigned bits[2 * NPA_GEO_BANDS], bits2[2 * NPA_GEO_BANDS];
       if (e == hipSuccess) e = hipMemcpy(bits, tab, sizeof(bits), hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(bits2, tab2, sizeof(bits2), hipMemcpyDeviceToHost);
       if (tab) hipFree(tab);
+      if (tab2) hipFree(tab2);
       if (e == hipSuccess) {
         const double sf = safety > 0 ? safety : 1.5;
         float raw[NPA_GEO_BANDS], mg[NPA_GEO_BANDS];
         bool seen[NPA_GEO_BANDS];
+        // Refinement check.  The margin rests on "between the nodes f stays within (node maximum + neighbour difference)".
+        // The cell centres are where that is most at risk; they were just measured: per band (with its two neighbours, a
+        // centre may fall into the next band) the largest |f| at the centres over what the nodes predicted.  A ratio above 1
+        // means the grid does not resolve f (a ridge narrower than a cell): the checkpoint keeps network keys.  No Lipschitz
+        // constant of the network gives a usable analytic bound (LayerNorm divides by a data-dependent deviation: the
+        // product of the layer norms is 1e6 and more for the shipped checkpoints, tests/tools/lipschitz_bound.py), so the
+        // claim is checked where it can fail, and audited at run time (select_geo_kernel).
+        float refine = 0.f, slope = 0.f;
+        {
+          float pred[NPA_GEO_BANDS], cen[NPA_GEO_BANDS];
+          for (int bnd = 0; bnd < NPA_GEO_BANDS; ++bnd) {
+            float f0, f1, c0;
+            memcpy(&f0, &bits[bnd], 4); memcpy(&f1, &bits[NPA_GEO_BANDS + bnd], 4); memcpy(&c0, &bits2[bnd], 4);
+            pred[bnd] = f0 + f1; cen[bnd] = c0;
+          }
+          for (int bnd = 0; bnd < NPA_GEO_BANDS; ++bnd) {
+            if (bits2[bnd] == 0u) continue;
+            float pr = 0.f;
+            for (int q = std::max(bnd - 1, 0); q <= std::min(bnd + 1, NPA_GEO_BANDS - 1); ++q) pr = std::max(pr, pred[q]);
+            pr = std::max(pr, 1e-3f);                  // (below a millimetre the ratio is rounding noise, and irrelevant)
+            if (!(cen[bnd] < 1e30f)) { refine = INFINITY; continue; }
+            refine = std::max(refine, cen[bnd] / pr);
+          }
+          // steepest neighbour difference next to the robot (bands below 8 m are on the finest grid) per metre
+          const float h0 = 2.0f * halves[0] / (float)(nside - 1);
+          for (int bnd = 0; bnd <= npa_geo_band(6.0f); ++bnd) {
+            float f1;
+            memcpy(&f1, &bits[NPA_GEO_BANDS + bnd], 4);
+            if (f1 < 1e30f) slope = std::max(slope, f1 / h0);
+          }
+        }
+        h->geo_refine = refine; h->geo_slope = slope;
         for (int bnd = 0; bnd < NPA_GEO_BANDS; ++bnd) {
-          float f0, f1;
+          float f0, f1, c0, c1;
           memcpy(&f0, &bits[bnd], 4); memcpy(&f1, &bits[NPA_GEO_BANDS + bnd], 4);
-          seen[bnd] = bits[bnd] != 0u || bits[NPA_GEO_BANDS + bnd] != 0u;
-          raw[bnd] = f0 + f1;
+          memcpy(&c0, &bits2[bnd], 4); memcpy(&c1, &bits2[NPA_GEO_BANDS + bnd], 4);
+          seen[bnd] = bits[bnd] != 0u || bits[NPA_GEO_BANDS + bnd] != 0u || bits2[bnd] != 0u;
+          raw[bnd] = std::max(f0, c0) + std::max(f1, c1);      // both grids feed the margin
         }
         float worst_err = 0.f, worst_margin = 0.f;
         for (int bnd = 0; bnd < NPA_GEO_BANDS; ++bnd) {
@@ -345,10 +408,18 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
           }
         }
         h->geo_err = worst_err; h->geo_margin = worst_margin;
-        geo_ok = worst_margin <= 0.15f || forced == 4;
+        // (1.25, not 1: a centre may legitimately exceed the nodes' prediction by a little where f is curved; the margin
+        // carries a factor 1.5 on top of the prediction)
+        const bool resolved = refine <= 1.25f || getenv("NPA_GEO_NOCHECK") != nullptr;
+        geo_ok = ((worst_margin <= 0.15f && resolved) || forced == 4);
         if (geo_ok) {
           e = hipMemcpy(h->wpack + WP_GEO, mg, sizeof(mg), hipMemcpyHostToDevice);
           P.geo_rcal = halves[2];
+          {
+            double rmax = 0;
+            for (int v = 0; v < P.E; ++v) rmax = std::max(rmax, std::sqrt((double)P.pvx[v] * P.pvx[v] + (double)P.pvy[v] * P.pvy[v]));
+            P.geo_far = (float)std::max(1.0, (double)halves[2] - rmax);
+          }
           h->key_terms = 4; h->key_err = worst_err; h->key_e0 = worst_margin;
         }
       }
@@ -382,6 +453,15 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
     if (e == hipSuccess) e = hipMemset(h->sel_stats_dev, 0, sizeof(unsigned));
     if (e == hipSuccess) e = hipHostMalloc(&h->sel_stats_host, sizeof(unsigned), hipHostMallocDefault);
     if (e == hipSuccess) *h->sel_stats_host = 0;
+    if (e == hipSuccess) e = hipMalloc(&h->audit_dev, 4 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(h->audit_dev, 0, 4 * sizeof(unsigned));
+    h->select_v1 = getenv("NPA_SELECT_V1") != nullptr;
+    {
+      double rate = 1.0 / 64.0;              // audit tiles: one slice wave in 64 (NPA_AUDIT_RATE in [0, 1]; 0 = candidates only)
+      if (const char* env = getenv("NPA_AUDIT_RATE")) { double v = atof(env); if (v >= 0.0 && v <= 1.0) rate = v; }
+      h->audit_thresh = rate >= 1.0 ? 0xFFFFFFFFu : (unsigned)(rate * 4294967296.0);
+      if (const char* env = getenv("NPA_GEO_MARGIN_SCALE")) { double v = atof(env); if (v > 0.0 && v <= 100.0) h->margin_scale = (float)v; }
+    }
   }
   if (e != hipSuccess) {
     npa_destroy(h);                                      // releases whatever was created so far
@@ -412,6 +492,7 @@ extern "C" int npa_destroy(npa_handle* h) {
   if (h->wpack) hipFree(h->wpack);
   if (h->sel_stats_dev) hipFree(h->sel_stats_dev);
   if (h->sel_stats_host) hipHostFree(h->sel_stats_host);
+  if (h->audit_dev) hipFree(h->audit_dev);
   if (h->stage_cand) hipFree(h->stage_cand);
   delete h;
   return NPA_OK;
@@ -422,6 +503,33 @@ extern "C" int npa_key_mode(const npa_handle* h, int* key_terms, float* measured
   if (key_terms) *key_terms = h->key_terms;
   if (measured_error) *measured_error = h->key_err;
   if (margin_e0) *margin_e0 = h->key_e0;
+  return NPA_OK;
+}
+
+extern "C" int npa_geo_report(const npa_handle* h, float* out, int n) {
+  if (!h || !out || n < 1) return fail(NPA_E_ARG, "npa_geo_report: bad argument");
+  const float v[6] = {h->geo_valid ? 1.f : 0.f, h->geo_err, h->geo_margin, h->geo_refine, h->geo_slope, h->P.geo_far};
+  for (int i = 0; i < n && i < 6; ++i) out[i] = v[i];
+  return NPA_OK;
+}
+
+extern "C" int npa_audit_read(npa_handle* h, uint64_t* tiles, uint64_t* points, uint64_t* violations, float* worst_excess, int reset) {
+  if (!h) return fail(NPA_E_ARG, "npa_audit_read: null handle");
+  unsigned v[4] = {0, 0, 0, 0};
+  if (h->audit_dev) {
+    int cur = -1;
+    HIP_TRY(hipGetDevice(&cur));
+    if (cur != h->device) HIP_TRY(hipSetDevice(h->device));
+    hipError_t e = hipDeviceSynchronize();          // the counters of every queued launch of this handle
+    if (e == hipSuccess) e = hipMemcpy(v, h->audit_dev, sizeof(v), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && reset) e = hipMemset(h->audit_dev, 0, sizeof(v));
+    if (cur != h->device) (void)hipSetDevice(cur);
+    HIP_TRY(e);
+  }
+  if (tiles) *tiles = v[0];
+  if (points) *points = v[1];
+  if (violations) *violations = v[2];
+  if (worst_excess) memcpy(worst_excess, &v[3], 4);
   return NPA_OK;
 }
 
@@ -517,9 +625,15 @@ extern "C" int npa_dune_stage(npa_handle* h, int batch, int n_stride, const floa
     HIP_TRY(npa_launch_encode(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr,
                               (unsigned*)h->stage_cand, trig, h->n_cu, 5, h->key_terms, (hipStream_t)stream,
                               nullptr, nullptr));
-  HIP_TRY(npa_launch_select(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr,
-                            (const unsigned*)h->stage_cand, trig, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count,
-                            h->key_terms, h->key_e0, h->sel_stats_dev, h->sel_debug, (hipStream_t)stream, nullptr, nullptr));
+  if (geo && !h->select_v1)
+    HIP_TRY(npa_launch_select_geo(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr, trig,
+                                  mu_sorted, lam_sorted, pts_sorted, dist_sorted, count, h->sel_stats_dev, h->sel_debug,
+                                  h->audit_dev, h->audit_thresh, h->launch_seq++, h->margin_scale, (hipStream_t)stream,
+                                  nullptr, nullptr));
+  else
+    HIP_TRY(npa_launch_select(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr,
+                              (const unsigned*)h->stage_cand, trig, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count,
+                              h->key_terms, h->key_e0, h->sel_stats_dev, h->sel_debug, (hipStream_t)stream, nullptr, nullptr));
   return NPA_OK;
 }
 
@@ -720,9 +834,15 @@ extern "C" int npa_forward_iter(npa_handle* h, int k) {
                                 ev ? ev->a : nullptr, ev ? ev->b : nullptr));
     }
     EventPair* evs = next_event(h, h->ev_sel, h->n_sel);
-    HIP_TRY(npa_launch_select(P, h->wpack, batch, 0, t0, pc->n_stride, cur_s, pc->points, pc->velocities,
-                              pc->n_points, flags, gkeys, ws + L.trig, mu, lam, pts, dist, count, h->key_terms, h->key_e0,
-                              h->sel_stats_dev, h->sel_debug, stream, evs ? evs->a : nullptr, evs ? evs->b : nullptr));
+    if (geo && !h->select_v1)
+      HIP_TRY(npa_launch_select_geo(P, h->wpack, batch, 0, t0, pc->n_stride, cur_s, pc->points, pc->velocities, pc->n_points,
+                                    flags, ws + L.trig, mu, lam, pts, dist, count, h->sel_stats_dev, h->sel_debug,
+                                    h->audit_dev, h->audit_thresh, h->launch_seq++, h->margin_scale, stream,
+                                    evs ? evs->a : nullptr, evs ? evs->b : nullptr));
+    else
+      HIP_TRY(npa_launch_select(P, h->wpack, batch, 0, t0, pc->n_stride, cur_s, pc->points, pc->velocities,
+                                pc->n_points, flags, gkeys, ws + L.trig, mu, lam, pts, dist, count, h->key_terms, h->key_e0,
+                                h->sel_stats_dev, h->sel_debug, stream, evs ? evs->a : nullptr, evs ? evs->b : nullptr));
   }
   EventPair* ev = next_event(h, h->ev_qp, h->n_qp);
   HIP_TRY(npa_launch_qp(P, batch, 0, cur_s, cur_u, pc->ref_s, pc->ref_us, mu, lam, pts, dist, count, cur_s, cur_u,

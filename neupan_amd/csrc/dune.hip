@@ -300,6 +300,71 @@ __device__ __forceinline__ void encode_tile(const WaveWeights& W, const float* v
   }
 }
 
+// The same encoder with the weights of the four 32x32 layers STREAMED from the lane-major copy (WP_WLS) instead of held
+// in 64 registers: the next layer's sixteen fragments are requested (four 16-byte loads, L1 / L2 resident: every wave of
+// the chip reads the same 16 KB) before the current layer's sixteen MFMAs start, which take ~1000 cycles.  Same
+// arithmetic in the same order as encode_tile: bitwise the same rows.
+__device__ __forceinline__ void load_layer(const float* __restrict__ wls, int L, int lane, float (&w)[16]) {
+  // (the address passes through an opaque asm: the loads are loop-invariant, and the compiler would otherwise hoist all
+  // four layers out of the tile loop and keep them in 64 registers -- the layout this form exists to avoid)
+  asm volatile("" : "+s"(wls));
+  const float4* p = reinterpret_cast<const float4*>(wls + ((size_t)L * 64 + lane) * 16);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 v = p[q];
+    w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+  }
+}
+template <int E>
+__device__ __forceinline__ void encode_tile_stream(float w1, const float* __restrict__ wls, const float* vec, const float* w6,
+                                                   const float* b6, float p0x, float p0y, int lane, float mu[E]) {
+  const int hf = lane >> 5;
+  float a[16], wa[16], wb[16];
+  // (scheduling barriers between the blocks: left alone the scheduler hoists all four layers' loads to the top -- the
+  // 64 registers this form exists to avoid)
+  load_layer(wls, 0, lane, wa);
+  {
+    f32x16 acc = bias_init(vec + V_B1 * 32, hf);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, hf ? p0y : p0x, acc, 0, 0, 0);
+    ln_tanh(acc, vec + V_G1 * 32, vec + V_BE1 * 32, hf, a);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  load_layer(wls, 1, lane, wb);
+  {
+    f32x16 acc = layer32(wa, a, bias_init(vec + V_B2 * 32, hf));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r], 0.f);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  load_layer(wls, 2, lane, wa);
+  {
+    f32x16 acc = layer32(wb, a, bias_init(vec + V_B3 * 32, hf));
+    ln_tanh(acc, vec + V_G2 * 32, vec + V_BE2 * 32, hf, a);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  load_layer(wls, 3, lane, wb);
+  {
+    f32x16 acc = layer32(wa, a, bias_init(vec + V_B4 * 32, hf));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r], 0.f);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    f32x16 acc = layer32(wb, a, bias_init(vec + V_B5 * 32, hf));
+    ln_tanh(acc, vec + V_G3 * 32, vec + V_BE3 * 32, hf, a);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    float wv[16];
+    load_vec16(w6 + e * 32, hf, wv);
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s = fmaf(wv[r], a[r], s);
+    mu[e] = fmaxf(pair_sum(s) + b6[e], 0.f);
+  }
+}
+
 __device__ __forceinline__ unsigned ordered_key(float d) {
   // monotone float -> uint map; NaN sorts last
   if (d != d) return 0xFFFFFFFEu;
@@ -394,6 +459,33 @@ __device__ __forceinline__ void point_features(const DevParams& P, const SliceFr
     ly = fmaf(F.rg[1][e], mu[e], ly);
     float tmp = __fsub_rn(fmaf(P.G[e][0], p0x, __fmul_rn(P.G[e][1], p0y)), P.h[e]);   // dune.py:121
     dist = fmaf(mu[e], tmp, dist);                                     // dune.py:124
+  }
+}
+
+// point_features with the streamed-weight encoder (exact rows; same operation order)
+template <int E>
+__device__ __forceinline__ void point_features_stream(const DevParams& P, const SliceFrame& F, float w1, const float* __restrict__ wls,
+                                                      const float* vec, const float* w6, const float* b6, const float* px_row,
+                                                      const float* py_row, const float* vx_row, const float* vy_row, int src,
+                                                      int lane, float mu[E], float& gx, float& gy, float& lx, float& ly,
+                                                      float& dist, float& p0x, float& p0y) {
+  gx = px_row[src];
+  gy = py_row[src];
+  if (vx_row) {
+    gx = __fadd_rn(gx, __fmul_rn(F.tstep, __fmul_rn(vx_row[src], P.dt32)));
+    gy = __fadd_rn(gy, __fmul_rn(F.tstep, __fmul_rn(vy_row[src], P.dt32)));
+  }
+  float dx = __fsub_rn(gx, F.tx), dy = __fsub_rn(gy, F.ty);
+  p0x = fmaf(F.c, dx, __fmul_rn(F.s, dy));
+  p0y = fmaf(F.c, dy, -__fmul_rn(F.s, dx));
+  encode_tile_stream<E>(w1, wls, vec, w6, b6, p0x, p0y, lane, mu);
+  lx = 0.f; ly = 0.f; dist = 0.f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    lx = fmaf(F.rg[0][e], mu[e], lx);
+    ly = fmaf(F.rg[1][e], mu[e], ly);
+    float tmp = __fsub_rn(fmaf(P.G[e][0], p0x, __fmul_rn(P.G[e][1], p0y)), P.h[e]);
+    dist = fmaf(mu[e], tmp, dist);
   }
 }
 
@@ -800,6 +892,368 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
   if (lane == 0) count[orow] = approx_keys == 2 ? (msel | (ncand << 8) | (fellback << 16)) : msel;
 }
 
+// ---- launch 2, geometric keys, second form --------------------------------------------------------------------
+// Same contract as select_kernel<E, true> (one wave per slice, keys from the closed-form distance g to the robot polygon,
+// every point the measured bound |network distance - g| <= margin[band(g)] cannot exclude from the M nearest becomes a
+// candidate, candidates re-encoded exactly and ranked on the exact (distance, index) key), built around what the first
+// form's instruction census showed:
+//  * key pass: strided buffer loads (32-bit offsets + immediates, out-of-range lanes read 0: no 64-bit address
+//    arithmetic, no clamping), v_sqrt_f32 instead of the correctly rounded sqrt expansion (the key only nominates), the
+//    lane minimum folded in: ~21 VALU instructions per point instead of ~60;
+//  * no exact extraction of the M smallest keys: the M-th smallest of the 64 lane minima (bisection) bounds the M-th
+//    smallest key, U = max over the lanes at or below it of g + m(g) bounds the M-th smallest EXACT distance, and the
+//    per-band rule g - m(band(g)) <= U is folded into ONE threshold g* = max over bands of min(band end, U + m(band)):
+//    the window pass is a compare per key, four keys per lane and trip (ds_read_b128);
+//  * points at or beyond g_far = (calibrated half extent - robot radius), NaN and inf keys are always candidates;
+//  * blockIdx -> (scene, slice) puts all slices of a scene on ONE XCD (workgroup w runs on XCD w % 8): the scene's
+//    cloud is fetched into one L2 instead of up to eight;
+//  * no register spills (tests/test_abi.py reads the code object).
+// Run-time audit of the bound the candidates rest on (the margin is measured, not proven):
+//  * every exactly encoded candidate is checked: |exact distance - g| <= margin[band(g)], violations counted;
+//  * a hash-selected fraction of the waves (audit_thresh / 2^32) encodes one extra tile of 32 points spread over the slice
+//    -- mostly NON-candidates -- and checks the same bound on them;
+//  * once the violation counter is non-zero every wave treats ALL points as candidates (exact keys for the whole slice:
+//    slow and right) until the host has looked (npa_audit_read) -- a wrong margin cannot keep producing wrong plans.
+__device__ __forceinline__ float dpp_f32_b1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false)); }
+__device__ __forceinline__ float wave_max_f32(float v) {
+  v = fmaxf(v, dpp_f32_b1(v));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false)));
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false)));
+  auto rl = [&](int l) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l)); };
+  return fmaxf(fmaxf(rl(0), rl(16)), fmaxf(rl(32), rl(48)));
+}
+// geometric key of a robot-frame point: v_sqrt_f32 (1 ulp) -- nominates only.  RECT: the axis-aligned box form.
+template <int E, bool RECT>
+__device__ __forceinline__ float geo_key_t(const DevParams& P, float x, float y) {
+  if constexpr (RECT) {
+    const float dx = fmaxf(fabsf(x - P.rcx) - P.rhx, 0.f), dy = fmaxf(fabsf(y - P.rcy) - P.rhy, 0.f);
+    return __builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy));
+  } else {
+    float best = 3.0e38f;
+    bool inside = true;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const float rx = x - P.pvx[e], ry = y - P.pvy[e];
+      inside = inside && (fmaf(P.pdy[e], rx, -(P.pdx[e] * ry)) <= 0.f);
+      float t = fmaf(rx, P.pdx[e], ry * P.pdy[e]) * P.pil[e];
+      t = fminf(fmaxf(t, 0.f), 1.f);
+      const float qx = fmaf(-t, P.pdx[e], rx), qy = fmaf(-t, P.pdy[e], ry);
+      best = fminf(best, fmaf(qx, qx, qy * qy));
+    }
+    return inside ? 0.f : __builtin_amdgcn_sqrtf(best);
+  }
+}
+template <int E>
+__device__ __forceinline__ float geo_key(const DevParams& P, float x, float y) {
+  return P.geo_rect ? geo_key_t<E, true>(P, x, y) : geo_key_t<E, false>(P, x, y);
+}
+
+#define SEL2_TRIP 256                            // points per trip of the key pass (4 per lane)
+// key pass of select_geo_kernel: dkey[n] = bits of g(point n) (0xFFFFFFFF behind the slice's end); returns the lane's
+// smallest key.  The wave-uniform cases (box or polygon, moving points, decimation) are template parameters: inside
+// the loop they were branches on spilled scalars plus both arms of the point flow.
+template <int E, bool RECT, bool VEL, bool DEC>
+__device__ __forceinline__ unsigned key_pass(const DevParams& P, const SliceFrame& F, const float* px_row, const float* py_row,
+                                             const float* vx_row, const float* vy_row, unsigned* dkey, int n_raw, int n_use,
+                                             int n_pad, int lane) {
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(px_row), 0, n_raw * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(py_row), 0, n_raw * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rvx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(VEL ? vx_row : px_row), 0, n_raw * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rvy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(VEL ? vy_row : py_row), 0, n_raw * 4, 0x00020000);
+  const float tdt = F.tstep;
+  unsigned lmin = 0xFFFFFFFFu;
+  for (int n0 = 0; n0 < n_pad; n0 += SEL2_TRIP) {
+    float gx[4], gy[4], vx[4], vy[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int n = n0 + lane + 64 * u;
+      unsigned off = (unsigned)n * 4u;                 // (reads behind n_raw return 0: the key is discarded below)
+      if constexpr (DEC) off = (unsigned)src_index(n < n_use ? n : n_use - 1, n_raw, n_use) * 4u;
+      gx[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
+      gy[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, off, 0, 0));
+      if constexpr (VEL) {
+        vx[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rvx, off, 0, 0));
+        vy[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rvy, off, 0, 0));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int n = n0 + lane + 64 * u;
+      float x = gx[u], y = gy[u];
+      if constexpr (VEL) {      // pan.py:182 (the reference's rounding order: the kept rows recompute it the same way)
+        x = __fadd_rn(x, __fmul_rn(tdt, __fmul_rn(vx[u], P.dt32)));
+        y = __fadd_rn(y, __fmul_rn(tdt, __fmul_rn(vy[u], P.dt32)));
+      }
+      const float dx = x - F.tx, dy = y - F.ty;
+      const float p0x = fmaf(F.c, dx, F.s * dy), p0y = fmaf(F.c, dy, -(F.s * dx));
+      unsigned k = __float_as_uint(geo_key_t<E, RECT>(P, p0x, p0y));
+      k = n < n_use ? k : 0xFFFFFFFFu;
+      dkey[n] = k;
+      lmin = min(lmin, k);
+    }
+  }
+  return lmin;
+}
+
+#define SEL2_TRIP 256                            // points per trip of the key pass (4 per lane)
+template <int E>
+__global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(E <= 6 ? 4 : 3, E <= 6 ? 4 : 3))) void select_geo_kernel(
+    DevParams P, const float* __restrict__ wpack, int n_stride, const float* __restrict__ cur_s,
+    const float* __restrict__ points, const float* __restrict__ vel, const int* __restrict__ n_points,
+    const int* __restrict__ flags, float* __restrict__ mu_sorted, float* __restrict__ lam_sorted,
+    float* __restrict__ pts_sorted, float* __restrict__ dist_sorted, int* __restrict__ count, int scene0, int t0, int nsl,
+    int nscene, int debug, unsigned* __restrict__ stats, const float* __restrict__ trig, unsigned* __restrict__ audit,
+    unsigned audit_thresh, unsigned audit_seed, float margin_scale) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* vec = smem;                       // [11][32]
+  float* w6 = vec + 11 * 32;               // [8][32]
+  float* b6 = w6 + 8 * 32;                 // [8]
+  float* etab = b6 + 8;                    // [NPA_GEO_BANDS] margin per distance band
+  int* sel = reinterpret_cast<int*>(etab + NPA_GEO_BANDS);   // [SEL_CAP]: the candidates of the final ranking
+  unsigned* skey = reinterpret_cast<unsigned*>(sel + SEL_CAP);   // [NPA_MAX_M] scratch of extract()
+  constexpr int ROW_W = E + 5;                                // mu[E], lam[2], point[2], distance
+  unsigned* dkey = reinterpret_cast<unsigned*>(skey + NPA_MAX_M);   // [n_use padded to SEL2_TRIP] keys; then the candidate list
+  float* rows = reinterpret_cast<float*>(dkey);               // [SEL_CAP][ROW_W] (takes over the key area once sel[] stands)
+  unsigned* rkey = reinterpret_cast<unsigned*>(rows + SEL_CAP * (NPA_MAX_E + 5));   // [SEL_CAP][2]: (index, exact key)
+  const int lane = threadIdx.x, j = lane & 31, hf = lane >> 5;
+  // workgroup w runs on XCD w % 8 (observed dispatch order; a speed assumption only): scene = 8 * (w / (8 nsl)) + w % 8
+  const int w = blockIdx.x, xcd = w & 7, r_ = w >> 3;
+  const int bl = (r_ / nsl) * 8 + xcd;
+  if (bl >= nscene) return;
+  const int t = r_ % nsl + t0, b = bl + scene0;
+  const int T = P.T, M = P.M;
+  if (flags && flags[b * 4 + 0]) return;
+  int n_raw = n_points ? n_points[b] : n_stride;
+  n_raw = n_raw < 0 ? 0 : (n_raw > n_stride ? n_stride : n_raw);
+  const int n_use = n_raw < P.dune_max_num ? n_raw : P.dune_max_num;
+  const size_t orow = (size_t)b * (T + 1) + t;
+  if (n_use <= 0) {
+    if (lane == 0) count[orow] = 0;
+    return;
+  }
+  for (int i = lane; i < 11 * 32 + 8 * 32 + 8; i += 64) smem[i] = wpack[WP_VEC + i];
+  for (int i = lane; i < NPA_GEO_BANDS; i += 64) etab[i] = wpack[WP_GEO + i] * margin_scale;
+  SliceFrame F;
+  load_frame<E>(P, cur_s, trig, b, t, F);
+  const float* px_row = points + (size_t)b * 2 * n_stride;
+  const float* py_row = px_row + n_stride;
+  const float* vx_row = vel ? vel + (size_t)b * 2 * n_stride : nullptr;
+  const float* vy_row = vel ? vx_row + n_stride : nullptr;
+  const bool has_vel = vel != nullptr, decim = n_use < n_raw;
+  // a violation seen by an earlier launch (or an earlier wave of this one): everything is a candidate from here on
+  const bool distrust = audit && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(audit + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0;
+  const unsigned far_thr = __float_as_uint(P.geo_far);
+
+  // ---- key pass: dkey[n] = bits of g(point n) (0xFFFFFFFF behind the slice's end), lane minimum on the way ----------
+  const int n_pad = (n_use + SEL2_TRIP - 1) & ~(SEL2_TRIP - 1);
+  unsigned lmin;
+#define KP(R_, V_, D_) lmin = key_pass<E, R_, V_, D_>(P, F, px_row, py_row, vx_row, vy_row, dkey, n_raw, n_use, n_pad, lane)
+  if (P.geo_rect && E == 4) {
+    if (has_vel) { if (decim) KP(true, true, true); else KP(true, true, false); }
+    else { if (decim) KP(true, false, true); else KP(true, false, false); }
+  } else {
+    if (has_vel) { if (decim) KP(false, true, true); else KP(false, true, false); }
+    else { if (decim) KP(false, false, true); else KP(false, false, false); }
+  }
+#undef KP
+  const float w1 = wpack[WP_W1 + lane];
+  const float* wls = wpack + WP_WLS;
+  WSYNC();
+
+  const int msel = n_use < M ? n_use : M;
+  // msel-th smallest of the 64 lane minima: an upper bound of the msel-th smallest key (each of those lanes holds a key
+  // that small; consecutive points sit in different lanes, so a run of near points -- a scan of one obstacle -- does not
+  // loosen it).  Fewer than msel lanes with a point (tiny slices): the bound is 0xFFFFFFFF and everything is a candidate.
+  unsigned bound = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned trial = bound | ((1u << bit) - 1u);
+    if (__popcll(__ballot(lmin <= trial)) < msel) bound |= 1u << bit;
+  }
+  float hi = 0.f;
+  if (lmin <= bound) {
+    const float g = __uint_as_float(lmin);
+    hi = (lmin >= far_thr) ? __builtin_inff() : g + etab[npa_geo_band(g)];       // (NaN keys are >= far_thr as bits)
+  }
+  const float U = wave_max_f32(hi);
+  // one threshold for the window: a point of band b is a candidate iff g <= U + m[b]; g* = the largest such g over the
+  // bands below g_far (a superset of the per-band rule: a band's points between U + m[b] and g* come along)
+  unsigned thr = 0xFFFFFFFEu;
+  if (!distrust && U < 3.0e38f) {
+    float gs = 0.f;
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      const int bnd = lane + 64 * rep;
+      if (bnd < NPA_GEO_BANDS) {
+        const float lo_b = __uint_as_float((unsigned)(bnd + (0x3E800000u >> 20)) << 20) - 0.25f;
+        const float hi_b = bnd == NPA_GEO_BANDS - 1 ? P.geo_far : __uint_as_float((unsigned)(bnd + 1 + (0x3E800000u >> 20)) << 20) - 0.25f;
+        const float reach = U + etab[bnd];
+        if (lo_b < P.geo_far && lo_b <= reach) gs = fmaxf(gs, fminf(hi_b, reach));
+      }
+    }
+    gs = wave_max_f32(gs);
+    thr = gs < 3.0e38f ? __float_as_uint(gs) : 0xFFFFFFFEu;
+  }
+  // ---- window pass: indices of the candidates, compacted IN PLACE over the keys already scanned ----------------------
+  int ntot = 0;
+  for (int n0 = 0; n0 < n_pad; n0 += SEL2_TRIP) {
+    const uint4 k4 = *reinterpret_cast<const uint4*>(dkey + n0 + 4 * lane);
+    const unsigned kk[4] = {k4.x, k4.y, k4.z, k4.w};
+    bool hit[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) hit[u] = kk[u] <= thr || (kk[u] - far_thr) < (0xFFFFFFFFu - far_thr);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned long long bal = __ballot(hit[u]);
+      const int pos = ntot + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+      if (hit[u]) dkey[pos] = (unsigned)(n0 + 4 * lane + u);
+      ntot += __popcll(bal);
+    }
+  }
+  WSYNC();
+  int ncand = ntot, fellback = 0;
+  bool overflow = false, all = false;
+  int total = 0;
+  if (ntot <= SEL_CAP && ntot >= msel) {
+    if (lane < ntot) sel[lane] = (int)dkey[lane];
+    WSYNC();
+  } else if (ntot < msel) {
+    // cannot happen while the threshold covers the nominating lanes' own minima (it does, by construction); if it ever
+    // did, exact keys for the whole slice are the answer, not fewer rows than promised
+    overflow = true; fellback = 1; all = true; total = n_use;
+  } else {
+    // more candidates than the final ranking holds (a wall at constant distance, a blob inside the robot, a distrusted
+    // margin): exact keys for the list -- stored behind it -- or, when it takes more than half the slice, for every point
+    overflow = true;
+    fellback = 1;
+    all = 2 * ntot > n_use;
+    total = all ? n_use : ntot;
+  }
+  unsigned* ckey = dkey + ntot;
+  auto cand_index = [&](int q) { return all ? q : (int)dkey[q]; };
+  auto extract = [&]() {                      // the msel smallest (key, index) pairs of dkey[0..n_use) -> sel[0..msel)
+    for (int m = 0; m < msel; ++m) {
+      unsigned long long best = ~0ull;
+      for (int n = lane; n < n_use; n += 64) best = umin64(best, ((unsigned long long)dkey[n] << 32) | (unsigned)n);
+      best = wave_min_u64(best);
+      const int idx = (int)(best & 0xFFFFFFFFu);
+      if (lane == 0) { sel[m] = idx; skey[m] = (unsigned)(best >> 32); dkey[idx] = 0xFFFFFFFFu; }
+      WSYNC();
+    }
+  };
+  // which waves run the extra audit tile: a hash of (launch, scene, slice)
+  bool audit_wave = false;
+  if (audit && audit_thresh) {
+    unsigned hsh = (audit_seed * 0x9E3779B1u) ^ ((unsigned)b * 0x85EBCA77u) ^ ((unsigned)t * 0xC2B2AE3Du);
+    hsh ^= hsh >> 15; hsh *= 0x2C1B3C6Du; hsh ^= hsh >> 12; hsh *= 0x297A2D39u; hsh ^= hsh >> 15;
+    audit_wave = hsh < audit_thresh || audit_thresh == 0xFFFFFFFFu;
+  }
+  // Stage 0 (overflow only): exact KEYS of the long list, the msel smallest become the candidates.  Stage 1: the final
+  // candidates (<= SEL_CAP) with their ROWS parked in LDS, ranked and emitted.  Stage 2 (audit waves): 32 points spread
+  // over the slice, bound check only.  ONE call site of the encoder for all three.
+  int viol = 0;
+  float worst = 0.f;
+#pragma unroll 1
+  for (int stage = overflow ? 0 : 1;;) {
+    const int cnt = stage == 0 ? total : (stage == 1 ? ncand : (n_use < 32 ? n_use : 32));
+#pragma unroll 1
+    for (int q0 = 0; q0 < cnt; q0 += 32) {
+      const int q = q0 + j, qc = q < cnt ? q : cnt - 1;
+      int idx;
+      if (stage == 0) idx = cand_index(qc);
+      else if (stage == 1) idx = sel[qc];
+      else {                                  // audit tile: 32 points n_use / 32 apart, the phase moves with the launch
+        const int step = n_use >> 5;
+        idx = step > 0 ? qc * step + (int)((audit_seed + (unsigned)t) % (unsigned)step) : qc;
+      }
+      float mu[E], gx, gy, lx, ly, dist, p0x, p0y;
+      point_features_stream<E>(P, F, w1, wls, vec, w6, b6, px_row, py_row, vx_row, vy_row,
+                               src_index(idx, n_raw, n_use), lane, mu, gx, gy, lx, ly, dist, p0x, p0y);
+      if (stage != 0 && audit) {
+        // the bound the candidates rest on, checked on every exactly encoded point: |exact - g| <= margin[band(g)]
+        const float g = geo_key<E>(P, p0x, p0y);
+        const float ex = fabsf(dist - g) - etab[npa_geo_band(g)];
+        const bool bad = hf == 0 && q < cnt && g < P.geo_far && ex > 0.f;          // (NaN distance: ex is NaN, not counted here;
+        viol += bad ? 1 : 0;                                                       //  a NaN row is a broken checkpoint, not a key matter)
+        worst = bad ? fmaxf(worst, ex) : worst;
+      }
+      if (hf == 0 && q < cnt) {
+        const unsigned k = ordered_key(dist);
+        if (stage == 0) {
+          if (all) dkey[idx] = k;
+          else ckey[q] = k;
+        } else if (stage == 1) {
+          float* r = rows + q * ROW_W;
+#pragma unroll
+          for (int e = 0; e < E; ++e) r[e] = mu[e];
+          r[E] = lx; r[E + 1] = ly; r[E + 2] = gx; r[E + 3] = gy; r[E + 4] = dist;
+          rkey[2 * q] = (unsigned)idx; rkey[2 * q + 1] = k;
+        }
+      }
+    }
+    WSYNC();
+    if (stage == 2) break;
+    if (stage == 1) {
+      // lane q speaks for candidate q: rank on the exact (distance, index) key, emit; rows >= msel replicate row 0
+      const bool mine = lane < ncand;
+      const unsigned long long kx = mine ? (((unsigned long long)rkey[2 * lane + 1] << 32) | rkey[2 * lane]) : ~0ull;
+      int rank = 0;
+      for (int i = 0; i < ncand; ++i) rank += readlane_u64(kx, i) < kx ? 1 : 0;
+      if (mine && rank < msel) {
+        const float* r = rows + lane * ROW_W;
+        auto put = [&](int q) {
+          const size_t o = orow * M + q;
+#pragma unroll
+          for (int e = 0; e < E; ++e) mu_sorted[o * E + e] = r[e];
+          lam_sorted[o * 2 + 0] = r[E]; lam_sorted[o * 2 + 1] = r[E + 1];
+          pts_sorted[o * 2 + 0] = r[E + 2]; pts_sorted[o * 2 + 1] = r[E + 3];
+          dist_sorted[o] = r[E + 4];
+        };
+        put(rank);
+        if (rank == 0)                          // the nearest row also fills rows >= msel: the padding rule of nrmp.py:258-259
+          for (int q = msel; q < M; ++q) put(q);
+      }
+      if (lane == 0) count[orow] = debug ? (msel | ((ntot < 255 ? ntot : 255) << 8) | (fellback << 16)) : msel;
+      if (!audit_wave) break;
+      stage = 2;
+      continue;
+    }
+    if (stats && lane == 0) atomicAdd(stats, (unsigned)((total + 31) / 32));
+    if (all) {
+      extract();
+    } else {
+      // the msel smallest exact (key, index) pairs among the candidates; lane m keeps the m-th winner
+      int mywin = 0;
+      for (int m2 = 0; m2 < msel; ++m2) {
+        unsigned long long best = ~0ull;
+        int bq = -1;
+        for (int q = lane; q < total; q += 64) {
+          const unsigned long long v = ((unsigned long long)ckey[q] << 32) | (unsigned)cand_index(q);
+          if (v < best) { best = v; bq = q; }
+        }
+        const unsigned long long win = wave_min_u64(best);
+        if (best == win && bq >= 0) ckey[bq] = 0xFFFFFFFFu;     // (key, index) pairs are distinct: one lane retires it
+        if (lane == m2) mywin = (int)(win & 0xFFFFFFFFu);
+        WSYNC();
+      }
+      if (lane < msel) sel[lane] = mywin;                       // the list was read through cand_index until here
+      WSYNC();
+    }
+    ncand = msel;
+    stage = 1;
+  }
+  if (audit) {
+    const unsigned long long vb = __ballot(viol > 0);
+    if (vb != 0ull) {                          // rare: the counters are touched only then (and by audit waves)
+      int v = viol;
+      float wv = worst;
+      for (int o = 32; o > 0; o >>= 1) { v += __shfl_xor(v, o, 64); wv = fmaxf(wv, __shfl_xor(wv, o, 64)); }
+      if (lane == 0) { atomicAdd(audit + 2, (unsigned)v); atomicMax(audit + 3, __float_as_uint(wv)); }
+    }
+    if (audit_wave && lane == 0) { atomicAdd(audit + 0, 1u); atomicAdd(audit + 1, (unsigned)(n_use < 32 ? n_use : 32)); }
+  }
+}
+
 // ---- host-side launchers (called from c_api.hip) --------------------------------------------------
 // t0 = first horizon slice to evaluate: slice 0 does not depend on the iterate (s(0) is pinned,
 // robot.py:234), so after the first PAN iteration of a forward call only slices 1..T are redone.
@@ -914,6 +1368,49 @@ extern "C" hipError_t npa_launch_select(const DevParams& P, const float* wpack, 
   return hipGetLastError();
 }
 
+extern "C" hipError_t npa_launch_select_geo(const DevParams& P, const float* wpack, int batch, int scene0, int t0,
+                                            int n_stride, const float* cur_s, const float* points, const float* vel,
+                                            const int* n_points, const int* flags, const float* trig, float* mu_sorted,
+                                            float* lam_sorted, float* pts_sorted, float* dist_sorted, int* count,
+                                            unsigned* stats, int debug, unsigned* audit, unsigned audit_thresh,
+                                            unsigned audit_seed, float margin_scale, hipStream_t stream,
+                                            hipEvent_t ev_start, hipEvent_t ev_stop) {
+  // select_geo_kernel: one wave per (scene, slice); the grid is padded to a multiple of 8 scenes so that the XCD-aware
+  // block -> (scene, slice) map covers every scene (the surplus workgroups return at once)
+  const int nsl = P.T + 1 - t0;
+  int n_use_max = n_stride < P.dune_max_num ? n_stride : P.dune_max_num;
+  if (n_use_max < 1) n_use_max = 1;
+  const size_t n_pad = ((size_t)n_use_max + SEL2_TRIP - 1) / SEL2_TRIP * SEL2_TRIP;
+  const size_t key_area = std::max<size_t>(n_pad * sizeof(unsigned), SEL_CAP * (NPA_MAX_E + 5 + 2) * sizeof(float));
+  const size_t shmem = (11 * 32 + 8 * 32 + 8 + NPA_GEO_BANDS) * sizeof(float) + (SEL_CAP + NPA_MAX_M) * sizeof(int) +
+                       (key_area + 15) / 16 * 16;
+  const int blocks = (batch + 7) / 8 * 8 * nsl;
+#define LAUNCH(EE)                                                                                                  \
+  do {                                                                                                              \
+    static bool big_lds = false;                                                                                    \
+    if (shmem > 60 * 1024 && !big_lds) {                                                                            \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(select_geo_kernel<EE>),                     \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
+      if (e_ != hipSuccess) return e_;                                                                              \
+      big_lds = true;                                                                                               \
+    }                                                                                                               \
+    hipExtLaunchKernelGGL((select_geo_kernel<EE>), dim3(blocks), dim3(64), shmem, stream, ev_start, ev_stop, 0, P, wpack,  \
+                          n_stride, cur_s, points, vel, n_points, flags, mu_sorted, lam_sorted, pts_sorted, dist_sorted, \
+                          count, scene0, t0, nsl, batch, debug, stats, trig, audit, audit_thresh, audit_seed, margin_scale); \
+  } while (0)
+  switch (P.E) {
+    case 3: LAUNCH(3); break;
+    case 4: LAUNCH(4); break;
+    case 5: LAUNCH(5); break;
+    case 6: LAUNCH(6); break;
+    case 7: LAUNCH(7); break;
+    case 8: LAUNCH(8); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef LAUNCH
+  return hipGetLastError();
+}
+
 // ---- geometric-key calibration (npa_create) ----------------------------------------------------------
 // f(p) = network distance - geometric distance is a smooth function of the robot-frame position and a property of
 // the checkpoint.  Per distance band (npa_geo_band) this records, over a square grid of spacing d, max |f| and the
@@ -923,7 +1420,7 @@ extern "C" hipError_t npa_launch_select(const DevParams& P, const float* wpack, 
 // covers) and builds margin[band] = safety x (max |f| + max |delta f|), taken over the band and its two neighbours.
 template <int E>
 __global__ __launch_bounds__(256) void geo_calib_kernel(DevParams P, const float* __restrict__ wpack, float half, int nside,
-                                                        float inner, unsigned* __restrict__ out) {
+                                                        float inner, float shift, unsigned* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* vec = smem;
   float* w6 = vec + 11 * 32;
@@ -942,7 +1439,9 @@ __global__ __launch_bounds__(256) void geo_calib_kernel(DevParams P, const float
   const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (tid >> 6), nwave = (long long)gridDim.x * (blockDim.x >> 6);
   for (long long tile = wave; tile < tiles; tile += nwave) {
     const int ix = (int)(tile % tiles_x) * 8 + (j & 7), iy = (int)(tile / tiles_x) * 4 + (j >> 3);
-    const float p0x = -half + step * (float)ix, p0y = -half + step * (float)iy;
+    // shift = 0.5: the nodes sit at the cell centres of the unshifted grid -- the points FARTHEST from its nodes, where a
+    // bound "node maximum + neighbour difference" is most at risk (npa_create compares the two grids)
+    const float p0x = -half + step * ((float)ix + shift), p0y = -half + step * ((float)iy + shift);
     float me[E];
     encode_tile<E>(W, vec, w6, b6, p0x, p0y, lane, me);
     float de = 0.f;
@@ -967,10 +1466,10 @@ __global__ __launch_bounds__(256) void geo_calib_kernel(DevParams P, const float
 }
 
 extern "C" hipError_t npa_launch_geo_calib(const DevParams& P, const float* wpack, int nside, float half, float inner,
-                                           unsigned* out, int n_cu, hipStream_t stream) {
+                                           float shift, unsigned* out, int n_cu, hipStream_t stream) {
   const size_t shmem = (11 * 32 + 8 * 32 + 8 + 2 * NPA_GEO_BANDS) * sizeof(float);
   const int blocks = n_cu * 4;
-#define LAUNCH(EE) hipLaunchKernelGGL((geo_calib_kernel<EE>), dim3(blocks), dim3(256), shmem, stream, P, wpack, half, nside, inner, out)
+#define LAUNCH(EE) hipLaunchKernelGGL((geo_calib_kernel<EE>), dim3(blocks), dim3(256), shmem, stream, P, wpack, half, nside, inner, shift, out)
   switch (P.E) {
     case 3: LAUNCH(3); break;
     case 4: LAUNCH(4); break;

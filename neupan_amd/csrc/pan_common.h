@@ -24,6 +24,7 @@ struct DevParams {
   // used by the GEOMETRIC distance keys (select_kernel<E, true>), never by the rows that are emitted
   float pvx[NPA_MAX_E], pvy[NPA_MAX_E], pdx[NPA_MAX_E], pdy[NPA_MAX_E], pil[NPA_MAX_E];   // pil = 1 / |D|^2
   float geo_rcal;             // half extent of the square (robot frame) over which the geometric key's error was measured
+  float geo_far;              // geo_rcal - (largest vertex radius): a point with a smaller geometric distance lies inside that square
   // the common case -- an axis-aligned rectangle in the robot frame (robot.py:342-375 builds length x width boxes) --
   // has a cheaper closed form: centre, half extents; geo_rect != 0 selects it
   int geo_rect;
@@ -75,7 +76,11 @@ __host__ __device__ inline int npa_geo_band(float g) {
 #define WP_KW1 (WP_KSC + 8)                       // [64]     centred Linear(2,32) A-fragment (read per lane)
 #define WP_KEY_LDS_FLOATS (WP_BF_FLOATS + 5 * 32 + 8)
 #define WP_GEO (WP_KW1 + 64)                      // [NPA_GEO_BANDS] margin of the geometric key per distance band (+inf = uncalibrated)
-#define WP_TOTAL (WP_GEO + NPA_GEO_BANDS)
+// the four 32x32 layers once more, lane-major: [layer 4][lane 64][K-step 16] -- select_geo_kernel streams a layer's sixteen
+// A-fragments with four 16-byte loads per lane right before the layer that uses them (16 + 16 registers for two layers in
+// flight instead of 64 for all four: that is what lets the kernel fit 128 registers without spills)
+#define WP_WLS (((WP_GEO + NPA_GEO_BANDS) + 3) & ~3)
+#define WP_TOTAL (WP_WLS + 4 * 64 * 16)
 // order of the per-feature vectors
 enum { V_B1 = 0, V_G1, V_BE1, V_B2, V_B3, V_G2, V_BE2, V_B4, V_B5, V_G3, V_BE3 };
 

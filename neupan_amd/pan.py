@@ -540,6 +540,25 @@ class PAN(torch.nn.Module):
         check(self._lib.npa_key_mode(self._h, C.byref(kt), C.byref(er), C.byref(e0)), "npa_key_mode")
         return dict(key_terms=kt.value, measured_error=er.value, margin_e0=e0.value)
 
+    def geo_report(self):
+        """What npa_create measured about the geometric distance keys of this checkpoint (npa_geo_report)."""
+        if self.no_obs:
+            return None
+        v = (C.c_float * 6)()
+        check(self._lib.npa_geo_report(self._h, v, 6), "npa_geo_report")
+        return dict(polygon_ok=bool(v[0]), measured_error=v[1], margin=v[2], refine_ratio=v[3], slope_estimate=v[4], g_far=v[5])
+
+    def audit(self, reset=False):
+        """Run-time audit counters of the geometric-key margin (npa_audit_read; synchronises the device):
+        dict(tiles, points, violations, worst_excess).  violations != 0 means the measured margin was exceeded by a real
+        point: the kernel has switched itself to exact keys for every slice; rebuild the planner with NPA_KEY_TERMS=1."""
+        if self.no_obs:
+            return dict(tiles=0, points=0, violations=0, worst_excess=0.0)
+        t, p, v, w = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_float()
+        with torch.cuda.device(self.device):
+            check(self._lib.npa_audit_read(self._h, C.byref(t), C.byref(p), C.byref(v), C.byref(w), 1 if reset else 0), "npa_audit_read")
+        return dict(tiles=t.value, points=p.value, violations=v.value, worst_excess=w.value)
+
     def last_qp_info(self):
         """(B,16) float64: per-scene diagnostics of the last QP solved by forward_batch
         (best iteration, merit, mu, status, iterations run)."""

@@ -4,6 +4,7 @@ the host-side mirror refuses to run without a GPU instead of falling back."""
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -96,3 +97,25 @@ def test_robot_mirror_matches_reference_geometry():
         halfplanes_from_vertices(np.array([[0, 0], [2, 0], [1, 0.2], [2, 2], [0, 2]]).T)   # non-convex
     with pytest.raises(ValueError):
         Robot(10, 0.1)                                                                      # robot.py:46-47
+
+
+def test_hot_kernels_have_no_spills_and_no_scratch():
+    """Register / scratch use of the hot kernels, read from the code objects inside the built library (AMDGPU metadata
+    notes; tests/tools/kernel_resources.py).  A VGPR spill in the selection kernel was 7 MB of scratch traffic per launch
+    (round-2 PMC), and register-starved builds of the QP kernel once came out of this compiler wrong: both
+    are build properties, so they are checked on the build."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import kernel_resources as kr
+    if not kr.tools_available():
+        pytest.skip("ROCm LLVM tools not installed")
+    res = kr.kernel_resources()
+    sel = {n: r for n, r in res.items() if "select_geo_kernel" in n}
+    assert len(sel) == 6                                        # E = 3 .. 8
+    for n, r in sel.items():
+        assert r["vgpr_spill"] == 0 and r["scratch"] == 0, (n, r)
+        assert r["vgpr"] + r["agpr"] <= 128, (n, r)             # four waves per SIMD
+    qp = {n: r for n, r in res.items() if "nrmp_qp_kernel" in n}
+    assert len(qp) >= 4
+    for n, r in qp.items():
+        assert r["vgpr_spill"] == 0 and r["scratch"] == 0, (n, r)
+        assert r["vgpr"] + r["agpr"] <= 256, (n, r)             # two waves per SIMD

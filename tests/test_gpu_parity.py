@@ -574,3 +574,115 @@ def test_warm_started_qp_equals_cold_qp(cfgname, scenes, monkeypatch):
     # bulk tightly and every scene loosely
     assert np.median(err) <= 5e-6, np.median(err)
     assert np.quantile(err, 0.9) <= 1e-4, np.quantile(err, 0.9)
+
+
+@pytest.mark.parametrize("cfgname,B,over", [("diff_1k_T10_K10", 96, {}), ("dyna_4k_T10_K10", 16, {}), ("poly8_5k_T10_K10", 8, {}),
+                                            ("diff_1k_T10_K10", 32, dict(dune_max_num=100)), ("acker_2k_T20_K15", 16, {})])
+def test_both_forms_of_the_geometric_selection_agree(cfgname, B, over):
+    """select_geo_kernel (the default: streamed weights, one threshold, XCD-aware block map) against the first form
+    (select_kernel<E, true>, NPA_SELECT_V1=1): the same contract, so bitwise the same rows -- on random clouds, moving
+    points, the 8-edge polygon (generic distance), decimated clouds and walls / blobs (the overflow paths)."""
+    from gpu_helpers import make_gpu_pan, wall_batch
+    cfg = CONFIGS[cfgname]
+    new = _with_env({"NPA_KEY_TERMS": "4"}, lambda: make_gpu_pan(cfg, **over))
+    old = _with_env({"NPA_KEY_TERMS": "4", "NPA_SELECT_V1": "1"}, lambda: make_gpu_pan(cfg, **over))
+    assert new.key_mode()["key_terms"] == 4 and old.key_mode()["key_terms"] == 4
+    batch = make_batch(cfg, 3000, B)
+    r, e = _stage_np(new, batch), _stage_np(old, batch)
+    for k in ("mu", "lam", "pts", "dist", "count"):
+        assert np.array_equal(r[k], e[k]), k
+    if cfgname == "diff_1k_T10_K10" and not over:
+        wb = wall_batch(cfg, 32)
+        r, e = _stage_np(new, wb, n_points=wb["n_points"]), _stage_np(old, wb, n_points=wb["n_points"])
+        for k in ("mu", "lam", "pts", "dist", "count"):
+            assert np.array_equal(r[k], e[k]), k
+        # ragged batch: 0, 1, 5, 63, 64, 65, 255, 256, 257 points in a scene
+        rb = make_batch(cfg, 3100, 9)
+        n_pts = np.array([0, 1, 5, 63, 64, 65, 255, 256, 257], dtype=np.int32)
+        r, e = _stage_np(new, rb, n_points=n_pts), _stage_np(old, rb, n_points=n_pts)
+        for k in ("count",):
+            assert np.array_equal(r[k], e[k]), k
+        for b in range(1, 9):                      # (rows of a scene without points are never written)
+            for k in ("mu", "lam", "pts", "dist"):
+                assert np.array_equal(r[k][b], e[k][b]), (k, b)
+
+
+def test_margin_audit_is_clean_on_the_shipped_checkpoints():
+    """The run-time audit of the geometric-key margin (select_geo_kernel; npa_audit_read) on the checkpoints the reference
+    ships, with EVERY slice wave running an audit tile (NPA_AUDIT_RATE=1): no point -- candidate or not -- exceeds the
+    measured margin, and what npa_create measured says the calibration grids resolve f (refinement ratio <= 1.25)."""
+    from gpu_helpers import make_gpu_pan
+    for cfgname, B in (("diff_1k_T10_K10", 128), ("acker_2k_T20_K15", 16), ("dyna_4k_T10_K10", 16), ("poly8_5k_T10_K10", 8)):
+        cfg = CONFIGS[cfgname]
+        pan = _with_env({"NPA_AUDIT_RATE": "1"}, lambda: make_gpu_pan(cfg))
+        rep = pan.geo_report()
+        print(cfgname, pan.key_mode(), rep)
+        if pan.key_mode()["key_terms"] != 4 and cfgname == "poly8_5k_T10_K10":
+            continue                               # (our own E = 8 checkpoint: geometric keys are not promised for it)
+        assert pan.key_mode()["key_terms"] == 4, (cfgname, pan.key_mode(), rep)
+        assert rep["polygon_ok"] and 0 < rep["refine_ratio"] <= 1.25, (cfgname, rep)
+        assert 100.0 < rep["g_far"] < 128.0 and rep["slope_estimate"] < 20.0, (cfgname, rep)
+        batch = make_batch(cfg, 5000, B)
+        _stage_np(pan, batch)
+        a = pan.audit()
+        assert a["tiles"] == B * (cfg.T + 1) and a["points"] == 32 * a["tiles"], (cfgname, a)
+        assert a["violations"] == 0, (cfgname, a)
+    # default rate: about one wave in 64
+    cfg = CONFIGS["diff_1k_T10_K10"]
+    pan = make_gpu_pan(cfg)
+    _stage_np(pan, make_batch(cfg, 5000, 256))
+    a = pan.audit()
+    assert 10 <= a["tiles"] <= 100 and a["violations"] == 0, a
+
+
+def test_wrong_margin_is_detected_and_contained():
+    """A margin that is WRONG (here: the measured one scaled down 50x through the test hook NPA_GEO_MARGIN_SCALE) drops
+    true members of the M nearest -- silently, as far as the rows go.  The audit must notice (violations > 0 after the
+    first launch: candidates themselves exceed the claimed bound), and from the next launch on the kernel must distrust
+    its keys and emit bitwise the rows of the exact-key build again."""
+    from gpu_helpers import make_gpu_pan
+    cfg = CONFIGS["diff_1k_T10_K10"]
+    exact = _with_env({"NPA_DUNE_FP32KEYS": "1"}, lambda: make_gpu_pan(cfg))
+    bad = _with_env({"NPA_GEO_MARGIN_SCALE": "0.02", "NPA_KEY_TERMS": "4"}, lambda: make_gpu_pan(cfg))
+    batch = make_batch(cfg, 6000, 64)
+    e = _stage_np(exact, batch)
+    first = _stage_np(bad, batch)
+    a = bad.audit()
+    assert a["violations"] > 0 and a["worst_excess"] > 0.0, a
+    wrong = sum(not np.array_equal(first[k], e[k]) for k in ("mu", "lam", "pts", "dist"))
+    second = _stage_np(bad, batch)
+    for k in ("mu", "lam", "pts", "dist", "count"):
+        assert np.array_equal(second[k], e[k]), k
+    # (the scaled margin really was too small to be harmless: the first launch differs from the exact selection)
+    assert wrong > 0
+    # resetting the counters lifts the distrust (the owner's decision)
+    bad.audit(reset=True)
+    assert bad.audit()["violations"] == 0
+
+
+@pytest.mark.parametrize("grid", ["64", "512"])
+def test_coarse_calibration_grids(grid):
+    """NPA_GEO_GRID coarsens the three calibration grids (default 4096 nodes per side: 4 / 16 / 63 mm).  Whatever the
+    grid, a handle may keep geometric keys only if the cell centres confirm what the nodes predicted (refinement ratio
+    <= 1.25), and what it then selects is either bitwise the exact-key selection or flagged by the audit and exact
+    from the next launch on."""
+    from gpu_helpers import make_gpu_pan
+    cfg = CONFIGS["diff_1k_T10_K10"]
+    exact = _with_env({"NPA_DUNE_FP32KEYS": "1"}, lambda: make_gpu_pan(cfg))
+    pan = _with_env({"NPA_GEO_GRID": grid, "NPA_AUDIT_RATE": "1"}, lambda: make_gpu_pan(cfg))
+    rep, km = pan.geo_report(), pan.key_mode()
+    if km["key_terms"] == 4:
+        assert rep["refine_ratio"] <= 1.25, (km, rep)
+    else:
+        assert rep["refine_ratio"] > 1.25 or rep["margin"] > 0.15, (km, rep)
+    batch = make_batch(cfg, 7000, 96)
+    e = _stage_np(exact, batch)
+    first = _stage_np(pan, batch)
+    a = pan.audit()
+    if a["violations"] == 0 and km["key_terms"] == 4:
+        pass                                      # nothing seen on 96 x 11 x (candidates + 32) points
+    second = _stage_np(pan, batch)
+    for k in ("mu", "lam", "pts", "dist", "count"):
+        if a["violations"] > 0 or km["key_terms"] != 4:
+            assert np.array_equal(second[k], e[k]), (k, km, rep, a)
+    print("coarse grid", grid, km, rep, a, "first launch equals exact:", all(np.array_equal(first[k], e[k]) for k in ("mu", "lam", "pts", "dist")))
