@@ -38,20 +38,29 @@ WORKLOAD = "diff_1k_T10_K10"
 BATCH = 256
 # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table (256 CUs x 4 SIMDs, 2.4 GHz)
 PEAK_FP64_VALU_TFLOPS = 78.6
-PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_FP32_MFMA_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32: what the exact encoder of select_geo_kernel runs on
 PEAK_F16_MFMA_TFLOPS = 2500.0
 N_SIMD = 1024
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
+# which source files a kernel's counters depend on (a kernel's PMC record is used only while these are unchanged)
+KERNEL_SOURCES = {"nrmp_qp_kernel": ("nrmp_qp.hip", "pan_common.h"), "select_geo_kernel": ("dune.hip", "pan_common.h"),
+                  "select_kernel": ("dune.hip", "pan_common.h"), "dune_kernel": ("dune.hip", "pan_common.h"),
+                  "stage_kernel": ("c_api.hip", "pan_common.h")}
 
 
-def source_hash():
-    """sha256 over the kernel sources: ties profiles/r02_pmc.json to the build it was measured on."""
+def source_hash(files=None):
+    """sha256 over kernel sources (all of neupan_amd/csrc, or the named files): ties the tracked counters to the code
+    they were measured on."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "neupan_amd", "csrc")
-    for f in sorted(os.listdir(d)):
+    for f in sorted(os.listdir(d)) if files is None else files:
         if f.endswith((".hip", ".h")):
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
+
+
+def kernel_hash(kernel):
+    return source_hash(KERNEL_SOURCES.get(kernel, None))
 
 
 def main():
@@ -88,8 +97,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # the measured leg imports the product only; tests/ (and with it oracle/) is touched by the cpu_baseline leg alone
-    from neupan_amd.dist import gather_controls
     from neupan_amd.pan import PAN
+    from neupan_amd.serve import ControlGatherer, bind_to_gpu_numa_node, run_steps as serve_steps
+    numa = bind_to_gpu_numa_node(local_rank)            # launch thread next to its GPU (one process per GPU)
     from neupan_amd.robot import Robot
     from neupan_amd.scenes import CONFIGS, make_batch
 
@@ -117,23 +127,20 @@ def main():
         args_dev.append(a)
     torch.cuda.synchronize(dev)
     cur = torch.cuda.current_stream(dev)
-    use_dist = dist if world > 1 or dist is not None else None
+    # One prepared step per batch in flight (PAN.make_step: arguments validated once, ONE library call per step, output
+    # tensors reused -- a serving loop owns its buffers); fresh stop-criterion state every step, reset inside the staging
+    # launch.  The controls of every step are all-gathered over RCCL from ONE communication stream (neupan_amd/serve.py).
+    steps = []
+    for j in range(nfl):
+        with torch.cuda.stream(streams[j]):
+            steps.append(pans[j].make_step(*args_dev[j], reset_state=True))
+    torch.cuda.synchronize(dev)
+    gatherer = ControlGatherer(dist, world, device=dev, slots=nfl)
 
     def run_steps(n):
-        """n steps (= n forward calls over batches of 256 scenes), `nfl` of them in flight, one stream each.
-        Step i is planned by planner i % nfl (fresh stop-criterion state every step, reset inside the staging launch)."""
-        last = [None] * nfl
-        for st in streams:
-            st.wait_stream(cur)
-        for i in range(n):
-            j = i % nfl
-            with torch.cuda.stream(streams[j]):
-                o = pans[j].forward_batch(*args_dev[j], reset_state=True)
-                g = gather_controls(o["opt_u"], use_dist, world, equal_shards=True)    # RCCL all-gather under torchrun
-            last[j] = (o, g)
-        for st in streams:
-            cur.wait_stream(st)
-        return last
+        """n steps (= n forward calls over batches of 256 scenes), `nfl` of them in flight, one stream each: step i is
+        planned by planner i % nfl."""
+        return serve_steps(n, steps, streams, gatherer, cur)
 
     run_steps(args.warmup)
     torch.cuda.synchronize(dev)
@@ -173,41 +180,69 @@ def main():
     value = plans / elapsed
     km = pans[0].key_mode()
 
+    # the run-time audit of the geometric-key margin over everything this process launched so far (all planners): a
+    # violation would mean plans computed from a wrong selection -- the number is reported AND must be zero
+    audits = [p.audit() for p in pans]
+    audit = {k: sum(a[k] for a in audits) for k in ("tiles", "points", "violations")}
+    audit["worst_excess"] = max(a["worst_excess"] for a in audits)
+    assert audit["violations"] == 0, f"geometric-key margin violated at run time: {audit}"
+
     # ---- roofline of the dominant kernel -------------------------------------------------------------------------
     # With geometric keys the encoder runs on ~2 % of the points (the candidates), and the step is the QP: a serial
     # fp64 interior-point chain, one wave per scene -- VALU/latency bound, no MFMA, no HBM stream.  EXECUTED work only:
-    # counters of the same build from profiles/r02_pmc.json (tests/tools/pmc_collect.py: separate rocprofv3 --pmc passes).
+    # counters from profiles/r03_pmc.json (tests/tools/pmc_collect.py: separate rocprofv3 --pmc passes), used per kernel
+    # only while the sources that kernel is built from are unchanged (kernel_hash).  SURVEY 8(d)'s roofline -- algorithmic
+    # dense flops of the encoder over the fp32-MFMA peak -- is retired: 943 Mflop/plan x this rate would be 2-4x that peak,
+    # the encoder simply does not run on 98 % of the points any more.
     pmc = None
     if os.path.exists(PMC_FILE):
         try:
             pj = json.load(open(PMC_FILE))
-            if pj.get("source_hash") == source_hash() and pj.get("workload") == args.workload:
+            if pj.get("workload") == args.workload:
                 pmc = pj
         except Exception:
             pmc = None
+
+    def pmc_kernel(name):
+        k = pmc["kernels"].get(name) if pmc else None
+        return k if k and k.get("source_hash") == kernel_hash(name) else None
     scenes_per_launch = BATCH
     qp_ms, sel_ms, dune_ms = prof["nrmp_ms"], prof["select_ms"], prof["dune_ms"]
     roof = {"bound": "valu", "kernel": f"nrmp_qp_kernel<{T},{cfg.nrmp_max_num}>", "unit": "TFLOP/s", "peak": PEAK_FP64_VALU_TFLOPS,
             "launch_ms": round(qp_ms, 4), "launches_timed": nl, "select_launch_ms": round(sel_ms, 4),
             "dune_launch_ms": round(dune_ms, 4), "key_mode": km, "achieved": None, "frac": None, "traffic": None}
-    if pmc is not None:
-        kq = pmc["kernels"].get("nrmp_qp_kernel")
-        if kq:
-            flops = kq["fp64_flops_per_launch"] * scenes_per_launch / pmc["scenes_per_launch"]
-            roof["achieved"] = round(flops / (qp_ms * 1e-3) / 1e12, 4) if qp_ms > 0 else None
-            roof["frac"] = round(roof["achieved"] / PEAK_FP64_VALU_TFLOPS, 5) if roof["achieved"] else None
-            roof["flops_per_launch"] = int(flops)
-            roof["traffic"] = int(kq["hbm_bytes_per_launch"] * scenes_per_launch / pmc["scenes_per_launch"])
-            roof["valu_issue_frac_alone"] = kq.get("valu_issue_frac")
-            roof["pmc"] = {"file": "profiles/r02_pmc.json", "source_hash": pmc["source_hash"],
-                           "per_kernel": {k: {kk: v[kk] for kk in ("valu_insts_per_launch", "valu_issue_frac", "hbm_bytes_per_launch",
-                                                                   "avg_ms_alone") if kk in v}
-                                          for k, v in pmc["kernels"].items()}}
+    kq = pmc_kernel("nrmp_qp_kernel")
+    if kq:
+        flops = kq["fp64_flops_per_launch"] * scenes_per_launch / pmc["scenes_per_launch"]
+        roof["achieved"] = round(flops / (qp_ms * 1e-3) / 1e12, 4) if qp_ms > 0 else None
+        roof["frac"] = round(roof["achieved"] / PEAK_FP64_VALU_TFLOPS, 5) if roof["achieved"] else None
+        roof["flops_per_launch"] = int(flops)
+        roof["traffic"] = int(kq["hbm_bytes_per_launch"] * scenes_per_launch / pmc["scenes_per_launch"])
+        roof["valu_issue_frac_alone"] = kq.get("valu_issue_frac")
+        roof["frac_alone"] = round(flops / (kq["avg_ms_alone"] * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS, 5) if kq.get("avg_ms_alone") else None
+        roof["lds_bank_conflict_frac"] = kq.get("lds_bank_conflict_frac")
+    if pmc:
+        roof["pmc"] = {"file": "profiles/r03_pmc.json",
+                       "per_kernel": {k: dict({kk: v[kk] for kk in ("valu_insts_per_launch", "valu_issue_frac", "hbm_bytes_per_launch",
+                                                                      "avg_ms_alone", "mfma_busy_frac", "source_hash") if kk in v},
+                                                  current=(v.get("source_hash") == kernel_hash(k)))
+                                      for k, v in pmc["kernels"].items()}}
+    ks = pmc_kernel("select_geo_kernel")
+    if ks and sel_ms > 0 and "SQ_INSTS_MFMA" in ks.get("counters", {}):
+        # the exact encoder's matrix work: executed v_mfma_f32_32x32x2_f32 (4096 flop each) over the fp32-MFMA peak
+        mf = ks["counters"]["SQ_INSTS_MFMA"] * 4096.0 * scenes_per_launch / pmc["scenes_per_launch"]
+        roof["select"] = {"kernel": f"select_geo_kernel<{E}>", "launch_ms": round(sel_ms, 4), "mfma_flops_per_launch": int(mf),
+                          "mfma_tflops": round(mf / (sel_ms * 1e-3) / 1e12, 3), "mfma_peak": PEAK_FP32_MFMA_TFLOPS,
+                          "mfma_frac": round(mf / (sel_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 5),
+                          "valu_issue_frac_alone": ks.get("valu_issue_frac"), "mfma_busy_frac_alone": ks.get("mfma_busy_frac"),
+                          "traffic": int(ks["hbm_bytes_per_launch"] * scenes_per_launch / pmc["scenes_per_launch"]),
+                          "algorithmic_bytes_per_launch": int(scenes_per_launch * (8 * N * (2 if args_dev[0][5] is not None else 1) + 400))}
     roof["note"] = ("dominant kernel by GPU time = the QP (fp64 Mehrotra IPM, one wave per scene, serial chain: latency / VALU-issue "
                     "bound).  achieved = fp64 flops EXECUTED per launch (PMC: SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 x 64 lanes, FMA x2) / "
                     "launch time measured here with HIP events on the launch's stream (other batches' kernels co-run on the same "
-                    "SIMDs); nothing is priced above what it executes.  DUNE: " +
-                    ("geometric distance keys inside select_kernel nominate the candidates, the exact fp32-MFMA encoder runs on "
+                    "SIMDs; frac_alone: the same over the kernel's duration alone on the chip); nothing is priced above what it "
+                    "executes.  DUNE: " +
+                    ("geometric distance keys inside select_geo_kernel nominate the candidates, the exact fp32-MFMA encoder runs on "
                      "those only (~1.1 tiles of 32 points per slice instead of N/32); no dune_kernel launch" if km["key_terms"] == 4
                      else f"network keys (mode {km['key_terms']}) from dune_kernel over every point, exact re-encode of the candidates"))
     if km["key_terms"] != 4 and dune_ms > 0:
@@ -226,16 +261,20 @@ def main():
         "config": {"workload": ("BASELINE.json configs[1]: batch=256 synthetic scenes/GPU, diff robot, 1000 pts, "
                                 "T=10, K=10 (iter_threshold=0), M=10, fp32 DUNE (MFMA) + fp64 QP") if args.workload == WORKLOAD
                                else f"{args.workload}: batch={BATCH} synthetic scenes/GPU, {cfg.kinematics} robot, {N} pts, "
-                                    f"T={T}, K={K} (iter_threshold=0), M={cfg.nrmp_max_num}, fp32 DUNE (MFMA) + fp64 QP",
+                                    f"T={T}, K={K} (iter_threshold=0), M={cfg.nrmp_max_num}, fp32 DUNE (MFMA) + fp64 QP"
+                                    + ("; BASELINE's 'bf16 DUNE' tier is NOT built: rows are exact fp32 (bf16 cannot hold 1e-4 "
+                                       "through a top-M selection, SURVEY section 7), keys geometric" if args.workload.startswith("poly8") else ""),
                    "scenes_per_gpu": BATCH, "points": N, "T": T, "K": K, "M": cfg.nrmp_max_num,
-                   "batches_in_flight": nfl, "schedule": "one HIP stream per batch in flight",
-                   "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
+                   "batches_in_flight": nfl, "schedule": "one HIP stream per batch in flight, one prepared library call per step "
+                                                        "(PAN.make_step), gathers on one communication stream",
+                   "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "numa_node": numa,
                    "parallelism": f"scene-shard x{world}, RCCL all-gather of controls"
                                   + (" (process group initialised)" if dist is not None else "")},
         "roofline": roof,
-        # host time to enqueue a step (21 launches + output tensors, one Python thread) next to the step's wall time: when
+        # host time to enqueue a step (one library call = 21 launches, one Python thread) next to the step's wall time: when
         # the two are close the step is bound by the host's launch rate, not by the kernels
         "host_issue_ms_per_step": round(1e3 * t_issue / args.steps, 4),
+        "margin_audit": audit,
     }
 
     # ---- single-scene latency: the reference's actual use (neupan/neupan.py:104-166, one robot, README "15 Hz") -------
@@ -267,19 +306,51 @@ def main():
         ncore = args.cpu_cores if args.cpu_cores > 0 else host
         base, members, cpu_rate, ncore = run_ensemble(args.workload, range(n_sc), ncore)
         # controls after every PAN iteration of the same batch, untimed; its last iteration IS the timed result
+        timed_u = out["opt_u"].cpu().numpy().copy()
         pans[0].reset_stop_state()
         tr = pans[0].forward_batch_trace(*args_dev[0])
         trace_u = tr["trace_u"].cpu().numpy()
-        assert np.array_equal(trace_u[:, -1], out["opt_u"].cpu().numpy()), "traced run differs from the timed run"
+        assert np.array_equal(trace_u[:, -1], timed_u), "traced run differs from the timed run"
         rep, hip, sp = judge(trace_u[:n_sc], base, members)
+        from parity_tools import host_cores
+        phys, logical = host_cores()
         line["cpu_baseline"] = {"value": round(cpu_rate, 3), "unit": "plans/s", "cores": ncore, "kind": "port",
-                                "sample": f"first {n_sc} scenes of the same workload, K={K} each, oracle/pan_oracle.py "
-                                          f"(numpy fp32 + fp64 IPM), {ncore} worker processes x 1 thread (host has {host} cores); "
-                                          "rate = scenes / wall time of that phase, workers started and warm"}
+                                "sample": f"scenes of the same workload (first {n_sc}, cycled), K={K} each, oracle/pan_oracle.py "
+                                          f"(numpy fp32 + fp64 IPM): kind 'port' because /root/reference does not exist on the GPU "
+                                          f"box (the reference's own a-2..a-6 cannot be imported there); worker processes x 1 "
+                                          f"thread, BLAS/OpenMP pinned to 1 thread in the parent before the spawn; best rate of a "
+                                          f"sweep over the number of concurrent workers ({ncore} won; host: {phys} physical cores, "
+                                          f"{logical} hardware threads), 2-4 plans per worker, workers started and warm",
+                                "sweep": getattr(run_ensemble, "last_sweep", None),
+                                "seconds_per_plan_single_worker": round(getattr(run_ensemble, "last_single_seconds", 0.0) or 0.0, 3)}
         js = getattr(run_ensemble, "last_job_seconds", None)
         if js:
             line["cpu_baseline"]["seconds_per_plan_in_worker"] = {"median": round(float(np.median(js)), 3), "max": round(float(max(js)), 3),
                                                                   "jobs_seen": len(js)}
+        # conditioning of the WORKLOAD (a property of neupan_amd/scenes.py's generator, not of either implementation): the
+        # share of scenes on which 13 equally valid evaluations of the reference algorithm agree to 1e-4 at all; and the
+        # headline pair once more on those scenes only
+        well = sp[:, -1] <= 1e-4
+        rep["well_posed_frac"] = round(float(well.mean()), 4)
+        if well.any() and n_sc == BATCH:
+            idx = np.flatnonzero(well)
+            idx = torch.from_numpy(np.resize(idx, BATCH)).to(dev)
+            a_w = [a.index_select(0, idx).contiguous() if a is not None else None for a in args_dev[0]]
+            st_w = []
+            for j in range(nfl):
+                with torch.cuda.stream(streams[j]):
+                    st_w.append(pans[j].make_step(*a_w, reset_state=True))
+            torch.cuda.synchronize(dev)
+            nw = max(2 * nfl, 40)
+            serve_steps(nfl, st_w, streams, None, cur)
+            torch.cuda.synchronize(dev)
+            tw = time.perf_counter()
+            serve_steps(nw, st_w, streams, None, cur)
+            torch.cuda.synchronize(dev)
+            tw = time.perf_counter() - tw
+            rep["well_posed_only"] = {"scenes": int(well.sum()), "plans_per_s": round(BATCH * nw / tw, 1), "steps": nw,
+                                      "ctrl_l2_max": float(hip[well, -1].max()), "ctrl_l2_median": float(np.median(hip[well, -1])),
+                                      "note": "the same loop on a batch made of the well-posed scenes only (cycled to 256)"}
         rep["note"] = ("oracle = reference code restated + substituted fp64 QP solver (ECOS unavailable: parity unpinned at that "
                        "boundary).  Ensemble per scene = the oracle itself on inputs moved by +-1 float32 ulp (8 members) and with the "
                        "DUNE hidden units permuted (same function, other fp32 summation order; 4 members).  well posed = ensemble "

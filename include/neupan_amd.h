@@ -148,6 +148,15 @@ int npa_forward_batch(npa_handle *h, int batch, int n_stride,
                       void *workspace, size_t workspace_bytes, void *state, size_t state_bytes,
                       void *stream);
 
+/* npa_forward_batch with the flags of npa_forward_begin (NPA_FWD_RESET_STATE): one call per step of a serving loop. */
+int npa_forward_batch_flags(npa_handle *h, int batch, int n_stride,
+                            const float *nom_s, const float *nom_u, const float *ref_s, const float *ref_us,
+                            const float *points, const float *velocities, const int32_t *n_points,
+                            float *out_s, float *out_u, float *out_d, float *out_min_distance,
+                            int32_t *out_iters, float *out_nrmp_points,
+                            void *workspace, size_t workspace_bytes, void *state, size_t state_bytes,
+                            void *stream, int flags);
+
 /* npa_forward_batch == npa_forward_begin + iter_num x npa_forward_iter(k) + npa_forward_end, all enqueued on `stream`.
  * The split lets a caller look at the working nominal between PAN iterations (it sits at the head of the workspace:
  * cur_s [B][3][T+1], then cur_u [B][2][T] at the next 16-byte boundary).  Same arguments as npa_forward_batch; buffers

@@ -47,6 +47,7 @@ SYMBOLS = {
     "npa_workspace_qp_info_offset": (_SZ, [_P, _I]),
     "npa_forward_batch": (_I, [_P, _I, _I] + [_P] * 13 + [_P, _SZ, _P, _SZ, _P]),
     "npa_forward_begin": (_I, [_P, _I, _I] + [_P] * 13 + [_P, _SZ, _P, _SZ, _P, _I]),
+    "npa_forward_batch_flags": (_I, [_P, _I, _I] + [_P] * 13 + [_P, _SZ, _P, _SZ, _P, _I]),
     "npa_forward_iter": (_I, [_P, _I]),
     "npa_forward_end": (_I, [_P]),
     "npa_dune_stage": (_I, [_P, _I, _I] + [_P] * 9 + [_P]),

@@ -4,6 +4,7 @@
 #include "pan_common.h"
 
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -115,6 +116,7 @@ static int mdim(const DevParams& P) { return P.M > 0 ? P.M : 1; }
 // per-slice stride of the key buffer inside the workspace: none with geometric keys (select_kernel keeps them in LDS)
 static int kstride(const npa_handle* h) { return h->key_terms == 4 ? 0 : h->P.key_stride; }
 
+static int npa_self_test(npa_handle* h);
 extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_handle** out) {
   if (!cfg || !out) return fail(NPA_E_ARG, "npa_create: null argument");
   if (cfg->receding < 1 || cfg->receding > NPA_MAX_T) return fail(NPA_E_UNSUPPORTED, "receding outside [1,NPA_MAX_T]");
@@ -466,6 +468,14 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
   if (e != hipSuccess) {
     npa_destroy(h);                                      // releases whatever was created so far
     return fail(NPA_E_HIP, std::string("npa_create: ") + hipGetErrorString(e));
+  }
+  if (!getenv("NPA_SKIP_SELFTEST")) {
+    const int rc = npa_self_test(h);
+    if (rc != NPA_OK) {
+      const std::string msg = g_err;
+      npa_destroy(h);
+      return fail(rc, msg);
+    }
   }
   *out = h;
   return NPA_OK;
@@ -864,21 +874,33 @@ extern "C" int npa_forward_end(npa_handle* h) {
   return NPA_OK;
 }
 
-extern "C" int npa_forward_batch(npa_handle* h, int batch, int n_stride, const float* nom_s, const float* nom_u,
-                                 const float* ref_s, const float* ref_us, const float* points,
-                                 const float* velocities, const int32_t* n_points, float* out_s, float* out_u,
-                                 float* out_d, float* out_min_distance, int32_t* out_iters, float* out_nrmp_points,
-                                 void* workspace, size_t workspace_bytes, void* state, size_t state_bytes,
-                                 void* stream_) {
+extern "C" int npa_forward_batch_flags(npa_handle* h, int batch, int n_stride, const float* nom_s, const float* nom_u,
+                                       const float* ref_s, const float* ref_us, const float* points,
+                                       const float* velocities, const int32_t* n_points, float* out_s, float* out_u,
+                                       float* out_d, float* out_min_distance, int32_t* out_iters, float* out_nrmp_points,
+                                       void* workspace, size_t workspace_bytes, void* state, size_t state_bytes,
+                                       void* stream_, int flags) {
+  if (!h) return fail(NPA_E_ARG, "npa_forward_batch: null handle");
   int rc = npa_forward_begin(h, batch, n_stride, nom_s, nom_u, ref_s, ref_us, points, velocities, n_points, out_s,
                              out_u, out_d, out_min_distance, out_iters, out_nrmp_points, workspace, workspace_bytes,
-                             state, state_bytes, stream_, 0);
+                             state, state_bytes, stream_, flags);
   if (rc != NPA_OK) return rc;
   for (int k = 0; k < h->P.K; ++k) {
     rc = npa_forward_iter(h, k);
     if (rc != NPA_OK) { npa_forward_end(h); return rc; }
   }
   return npa_forward_end(h);
+}
+
+extern "C" int npa_forward_batch(npa_handle* h, int batch, int n_stride, const float* nom_s, const float* nom_u,
+                                 const float* ref_s, const float* ref_us, const float* points,
+                                 const float* velocities, const int32_t* n_points, float* out_s, float* out_u,
+                                 float* out_d, float* out_min_distance, int32_t* out_iters, float* out_nrmp_points,
+                                 void* workspace, size_t workspace_bytes, void* state, size_t state_bytes,
+                                 void* stream_) {
+  return npa_forward_batch_flags(h, batch, n_stride, nom_s, nom_u, ref_s, ref_us, points, velocities, n_points, out_s, out_u,
+                                 out_d, out_min_distance, out_iters, out_nrmp_points, workspace, workspace_bytes, state,
+                                 state_bytes, stream_, 0);
 }
 
 // ---- front end (frontend.hip) ----------------------------------------------------------------------
@@ -932,6 +954,144 @@ extern "C" int npa_dune_labels(int edge_num, const double* G, const double* h, i
   if (!G || !h || n < 0 || (n > 0 && (!points || !mu || !dist))) return fail(NPA_E_ARG, "npa_dune_labels: bad argument");
   if (edge_num < 3 || edge_num > NPA_MAX_E) return fail(NPA_E_UNSUPPORTED, "edge_num outside [3,NPA_MAX_E]");
   HIP_TRY(npa_launch_labels(edge_num, G, h, (long long)n, points, mu, dist, (hipStream_t)stream));
+  return NPA_OK;
+}
+
+// ---- create-time self-test ----------------------------------------------------------------------------------------
+// Two symptoms of this toolchain were caged rather than explained: a packed-fp32 form of the key
+// path that produced non-deterministic keys, and register-starved builds of the QP kernel whose warm-start logic ran
+// on corrupted loop scalars.  Both would ship WRONG PLANS silently if a different compiler / runtime brought them back
+// (the driver's box runs another HIP runtime than the one the library was built with).  So every handle runs its own
+// kernels once on a fixed synthetic problem before it is handed out (a few ms):
+//   1. the forward call twice: outputs bitwise equal (determinism of every instantiated kernel);
+//   2. the same with the QP's warm start off: controls equal to 1e-4, finite, inside the speed bounds;
+//   3. geometric keys: the DUNE stage's rows bitwise equal to those of the exact whole-slice path (the audit's
+//      distrust mode) -- the nomination leaves no true member out on this cloud;
+//   network keys: the DUNE stage twice, bitwise equal.
+// A failure returns NPA_E_UNSUPPORTED with the failing check in npa_last_error().  NPA_SKIP_SELFTEST=1 skips it.
+static int npa_self_test(npa_handle* h) {
+  const DevParams& P = h->P;
+  const int B = 2, T = P.T, M = mdim(P), E = P.E, N = 96;
+  const bool obs = P.M > 0;
+  const int kmax = P.K < 3 ? P.K : 3;
+  std::vector<float> nom_s((size_t)B * 3 * (T + 1)), nom_u((size_t)B * 2 * T), ref_s(nom_s.size()), ref_us((size_t)B * T),
+      pts((size_t)B * 2 * N);
+  unsigned lcg = 12345u;
+  auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return (float)((lcg >> 8) & 0xFFFF) / 65535.0f; };
+  for (int b = 0; b < B; ++b) {
+    const float th = 0.05f * (float)(b + 1), v = 1.0f + 0.5f * (float)b;
+    for (int t = 0; t <= T; ++t) {
+      const float d = v * (float)P.dt * (float)t;
+      nom_s[(size_t)b * 3 * (T + 1) + t] = d * std::cos(th);
+      nom_s[(size_t)b * 3 * (T + 1) + (T + 1) + t] = d * std::sin(th);
+      nom_s[(size_t)b * 3 * (T + 1) + 2 * (T + 1) + t] = th;
+      ref_s[(size_t)b * 3 * (T + 1) + t] = 1.1f * d;
+      ref_s[(size_t)b * 3 * (T + 1) + (T + 1) + t] = 0.f;
+      ref_s[(size_t)b * 3 * (T + 1) + 2 * (T + 1) + t] = 0.f;
+    }
+    for (int t = 0; t < T; ++t) {
+      nom_u[(size_t)b * 2 * T + t] = v; nom_u[(size_t)b * 2 * T + T + t] = 0.f;
+      ref_us[(size_t)b * T + t] = v;
+    }
+    // a ring of points 4 .. 9 m around the path's start (clear of any robot body the reference ships: the car is 4.6 m
+    // long), plus a cluster ahead and to the side of it that the horizon approaches
+    for (int n = 0; n < N; ++n) {
+      const float ang = 6.2831853f * rnd(), r = 4.0f + 5.0f * rnd();
+      pts[(size_t)b * 2 * N + n] = (n < 80) ? r * std::cos(ang) : 5.5f + 0.6f * rnd();
+      pts[(size_t)b * 2 * N + N + n] = (n < 80) ? r * std::sin(ang) : 2.5f + 0.6f * rnd();
+    }
+  }
+  const size_t wsb = npa_workspace_bytes(h, B), stb = npa_state_bytes(h, B);
+  const size_t n_in = nom_s.size() * 2 + nom_u.size() + ref_us.size() + pts.size();
+  const size_t n_out = (size_t)B * 3 * (T + 1) + (size_t)B * 2 * T + (size_t)B * T + B + B + (size_t)B * 2 * M;
+  const size_t n_stage = (size_t)B * (T + 1) * M * (E + 5) + (size_t)B * (T + 1);
+  char* dev = nullptr;
+  const size_t bytes = (n_in + 3 * n_out + 2 * n_stage) * 4 + wsb + stb + 1024;
+  HIP_TRY(hipMalloc(&dev, bytes));
+  struct Free { char* p; ~Free() { if (p) hipFree(p); } } guard{dev};
+  HIP_TRY(hipMemset(dev, 0, bytes));
+  float* d_nom_s = (float*)dev;
+  float* d_ref_s = d_nom_s + nom_s.size();
+  float* d_nom_u = d_ref_s + ref_s.size();
+  float* d_ref_us = d_nom_u + nom_u.size();
+  float* d_pts = d_ref_us + ref_us.size();
+  float* d_out[3];
+  d_out[0] = d_pts + pts.size(); d_out[1] = d_out[0] + n_out; d_out[2] = d_out[1] + n_out;
+  float* d_stage[2];
+  d_stage[0] = d_out[2] + n_out; d_stage[1] = d_stage[0] + n_stage;
+  char* d_ws = (char*)(((uintptr_t)(d_stage[1] + n_stage) + 255) & ~(uintptr_t)255);
+  char* d_state = (char*)(((uintptr_t)(d_ws + wsb) + 255) & ~(uintptr_t)255);
+  HIP_TRY(hipMemcpy(d_nom_s, nom_s.data(), nom_s.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_ref_s, ref_s.data(), ref_s.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_nom_u, nom_u.data(), nom_u.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_ref_us, ref_us.data(), ref_us.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_pts, pts.data(), pts.size() * 4, hipMemcpyHostToDevice));
+  auto run = [&](float* o) -> int {
+    float* os = o; float* ou = os + (size_t)B * 3 * (T + 1); float* od = ou + (size_t)B * 2 * T;
+    float* omd = od + (size_t)B * T; int32_t* oit = (int32_t*)(omd + B); float* onp = (float*)(oit + B);
+    int rc = npa_forward_begin(h, B, N, d_nom_s, d_nom_u, d_ref_s, d_ref_us, obs ? d_pts : nullptr, nullptr, nullptr, os, ou, od,
+                               omd, oit, onp, d_ws, wsb, d_state, stb, nullptr, NPA_FWD_RESET_STATE);
+    for (int k = 0; k < kmax && rc == NPA_OK; ++k) rc = npa_forward_iter(h, k);
+    const int rc2 = npa_forward_end(h);
+    return rc != NPA_OK ? rc : rc2;
+  };
+  std::vector<float> o0(n_out), o1(n_out), o2(n_out);
+  int rc = run(d_out[0]);
+  if (rc == NPA_OK) rc = run(d_out[1]);
+  const bool warm_was = h->qp_warm;
+  h->qp_warm = false;
+  if (rc == NPA_OK) rc = run(d_out[2]);
+  h->qp_warm = warm_was;
+  if (rc != NPA_OK) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(o0.data(), d_out[0], n_out * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(o1.data(), d_out[1], n_out * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(o2.data(), d_out[2], n_out * 4, hipMemcpyDeviceToHost));
+  const size_t n_su = (size_t)B * 3 * (T + 1) + (size_t)B * 2 * T;          // states and controls: compared
+  if (memcmp(o0.data(), o1.data(), n_su * 4) != 0)
+    return fail(NPA_E_UNSUPPORTED, "npa_create self-test: two runs of the same forward call differ (non-deterministic kernel: "
+                                   "this build / runtime combination is not usable; library built with hipcc " NPA_HIPCC_VERSION ")");
+  const float* u0 = o0.data() + (size_t)B * 3 * (T + 1);
+  const float* u2 = o2.data() + (size_t)B * 3 * (T + 1);
+  for (int b = 0; b < B; ++b)
+    for (int k = 0; k < 2; ++k)
+      for (int t = 0; t < T; ++t) {
+        const float a = u0[(size_t)b * 2 * T + k * T + t], c = u2[(size_t)b * 2 * T + k * T + t];
+        const double sb = P.speed_bound[k];
+        if (!(a == a) || !(std::fabs(a) < 1e30f) || (std::isfinite(sb) && std::fabs(a) > sb + 1e-4) || std::fabs(a - c) > 1e-4f) {
+          char msg[256];
+          snprintf(msg, sizeof(msg), "npa_create self-test: control [%d][%d][%d] = %g (cold-start solve: %g, bound %g): the QP kernel "
+                                     "misbehaves on this build / runtime (hipcc " NPA_HIPCC_VERSION ")", b, k, t, (double)a, (double)c, sb);
+          return fail(NPA_E_UNSUPPORTED, msg);
+        }
+      }
+  if (obs) {
+    auto stage = [&](float* o) -> int {
+      float* mu = o; float* lam = mu + (size_t)B * (T + 1) * M * E; float* pt = lam + (size_t)B * (T + 1) * M * 2;
+      float* ds = pt + (size_t)B * (T + 1) * M * 2; int32_t* cn = (int32_t*)(ds + (size_t)B * (T + 1) * M);
+      return npa_dune_stage(h, B, N, d_nom_s, d_pts, nullptr, nullptr, mu, lam, pt, ds, cn, nullptr);
+    };
+    rc = stage(d_stage[0]);
+    const bool geo2 = h->key_terms == 4 && !h->select_v1 && h->audit_dev;
+    const unsigned one[4] = {0, 0, 1, 0};
+    if (rc == NPA_OK && geo2) HIP_TRY(hipMemcpy(h->audit_dev, one, sizeof(one), hipMemcpyHostToDevice));   // distrust: exact keys
+    if (rc == NPA_OK) rc = stage(d_stage[1]);
+    if (rc != NPA_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<float> s0(n_stage), s1(n_stage);
+    HIP_TRY(hipMemcpy(s0.data(), d_stage[0], n_stage * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(s1.data(), d_stage[1], n_stage * 4, hipMemcpyDeviceToHost));
+    if (memcmp(s0.data(), s1.data(), n_stage * 4) != 0)
+      return fail(NPA_E_UNSUPPORTED, geo2 ? "npa_create self-test: the geometric-key selection differs from the exact whole-slice "
+                                            "selection on the test cloud (margin or kernel broken on this build / runtime)"
+                                          : "npa_create self-test: two runs of the DUNE stage differ (non-deterministic keys)");
+  }
+  // leave no trace: counters, sequence numbers, the key policy's window
+  if (h->audit_dev) HIP_TRY(hipMemset(h->audit_dev, 0, 4 * sizeof(unsigned)));
+  if (h->sel_stats_dev) HIP_TRY(hipMemset(h->sel_stats_dev, 0, sizeof(unsigned)));
+  if (h->sel_stats_host) *h->sel_stats_host = 0;
+  h->launch_seq = 0; h->stats_mark = 0; h->tiles_window = 0; h->calls_window = 0; h->hold = 0;
+  HIP_TRY(hipDeviceSynchronize());
   return NPA_OK;
 }
 

@@ -360,6 +360,48 @@ class PAN(torch.nn.Module):
         self.last_out = out
         return out
 
+    def make_step(self, nom_s, nom_u, ref_s, ref_us, points=None, velocities=None, n_points=None, reset_state=False):
+        """Serving-loop form of forward_batch: validate and convert the arguments ONCE and return `step()`, which plans
+        the batch with ONE library call (npa_forward_batch_flags) on the current stream and returns the same dict of
+        output tensors every time -- they are allocated here and REUSED (forward_batch returns fresh tensors per call,
+        like the reference; a loop that owns its buffers does not need that, and the per-call conversions, allocations and
+        a dozen ctypes calls were a third of a step's wall time).  The input tensors are read in place at every step():
+        refresh them with copy_() between steps."""
+        self.forward_begin(nom_s, nom_u, ref_s, ref_us, points, velocities, n_points, reset_state=reset_state)
+        for k in range(self.iter_num):               # (the first step also runs here: buffers and the handle are warm)
+            self.forward_iter(k)
+        out = self.forward_end()
+        last = self._last
+        nom_s, nom_u, ref_s, ref_us = last["hold"]
+        pts, vel, npt = last["points"], last["velocities"], last["n_points"]
+        B = nom_s.shape[0]
+        ws, state = self._get_buffers(B)
+        n_stride = max(pts.shape[2], 1) if pts is not None else 1
+        lib, h, dev = self._lib, self._h, self.device
+        args = (h, B, n_stride, _ptr(nom_s), _ptr(nom_u), _ptr(ref_s), _ptr(ref_us), _ptr(pts), _ptr(vel), _ptr(npt),
+                _ptr(out["opt_s"]), _ptr(out["opt_u"]), _ptr(out["opt_d"]), _ptr(out["min_distance"]), _ptr(out["iters"]),
+                _ptr(out["nrmp_points"]), _ptr(ws), ws.numel(), _ptr(state), state.numel())
+        flags = 2 if reset_state else 0
+        fn = lib.npa_forward_batch_flags
+        cur_stream = torch.cuda.current_stream
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+
+        cur_dev = torch.cuda.current_device
+
+        def step():
+            if cur_dev() != idx:                     # the launches must see the device of the handle
+                with torch.cuda.device(dev):
+                    rc = fn(*args, C.c_void_p(cur_stream(dev).cuda_stream), flags)
+            else:
+                rc = fn(*args, C.c_void_p(cur_stream(dev).cuda_stream), flags)
+            if rc:
+                check(rc, "npa_forward_batch_flags")
+            self._last = last
+            self.last_out = out
+            return out
+        step.device_index = idx
+        return step
+
     def forward_batch_trace(self, nom_s, nom_u, ref_s, ref_us, points=None, velocities=None, n_points=None):
         """forward_batch that also returns the controls after every PAN iteration: out["trace_u"] (B, K, 2, T), the
         working nominal copied out of the workspace behind each iteration's QP (parity tooling: how a deviation from

@@ -1,0 +1,98 @@
+"""The serving loop bench.py times, as a library function: `inflight` independent batches kept in flight, one stream each,
+the per-step all-gather of the controls issued from ONE dedicated communication stream.
+
+Why one comm stream: collectives on one communicator execute in issue order on every rank.  Issued from the batches'
+own streams (20 of them), each all-gather also waited for whatever that stream had queued, and every step became a
+cross-rank rendezvous in the middle of a compute chain.  Here a step's gather waits for exactly one event -- that step's
+last kernel -- on a stream that carries nothing else, and the ranks meet in the same order by construction (step i's
+gather is the i-th collective everywhere).
+
+Device-agnostic on purpose: with `streams=None` (CPU tensors, gloo) the same schedule runs synchronously, which is how
+tests/test_dist_gloo.py drives it with two ranks.
+"""
+from __future__ import annotations
+
+import torch
+
+from .dist import gather_controls
+
+
+class ControlGatherer:
+    """All-gather of a step's controls behind that step's work, on a stream of its own (or inline on CPU)."""
+
+    def __init__(self, dist=None, world: int = 1, device=None, slots: int = 1):
+        self.dist, self.world = dist, world
+        self.active = dist is not None and dist.is_initialized()
+        self.cuda = device is not None and torch.device(device).type == "cuda"
+        self.comm = torch.cuda.Stream(device=device) if (self.active and self.cuda) else None
+        self.events = [torch.cuda.Event() for _ in range(slots)] if self.comm is not None else None
+        self.issued = 0
+
+    def gather(self, opt_u: torch.Tensor, slot: int = 0, producer=None):
+        """`opt_u` was produced on stream `producer` (None: the current stream / CPU).  Returns the gathered tensor, valid
+        on the comm stream (join() makes it valid on the current one)."""
+        if not self.active:
+            return opt_u
+        self.issued += 1
+        if self.comm is None:
+            return gather_controls(opt_u, self.dist, self.world, equal_shards=True)
+        ev = self.events[slot]
+        ev.record(producer if producer is not None else torch.cuda.current_stream(opt_u.device))
+        self.comm.wait_event(ev)
+        with torch.cuda.stream(self.comm):
+            out = gather_controls(opt_u, self.dist, self.world, equal_shards=True)
+        opt_u.record_stream(self.comm)
+        return out
+
+    def join(self, stream=None):
+        if self.comm is not None:
+            (stream if stream is not None else torch.cuda.current_stream(self.comm.device)).wait_stream(self.comm)
+
+
+def run_steps(n: int, steps, streams=None, gatherer: ControlGatherer | None = None, cur=None):
+    """Issue n steps round-robin over `steps` (callables returning the output dict of a forward call, e.g.
+    PAN.make_step(...)), step i on streams[i % len(steps)], its controls handed to `gatherer` behind it.
+    Returns the last (out, gathered) of every slot.  Nothing synchronises the host."""
+    nfl = len(steps)
+    last = [None] * nfl
+    if streams is not None:
+        for st in streams:
+            st.wait_stream(cur)
+    for i in range(n):
+        j = i % nfl
+        if streams is not None:
+            with torch.cuda.stream(streams[j]):
+                o = steps[j]()
+            g = gatherer.gather(o["opt_u"], j, streams[j]) if gatherer is not None else o["opt_u"]
+        else:
+            o = steps[j]()
+            g = gatherer.gather(o["opt_u"], j) if gatherer is not None else o["opt_u"]
+        last[j] = (o, g)
+    if streams is not None:
+        for st in streams:
+            cur.wait_stream(st)
+        if gatherer is not None:
+            gatherer.join(cur)
+    return last
+
+
+def bind_to_gpu_numa_node(device_index: int):
+    """Pin this process to the CPUs of the NUMA node its GPU hangs off (one process per GPU: the launch thread and the
+    pinned buffers should not sit across the socket).  Best effort: returns the node or None."""
+    import os
+    try:
+        props = torch.cuda.get_device_properties(device_index)
+        bdf = f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read().strip())
+        if node < 0:
+            return None
+        cpus = []
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.extend(range(int(lo), int(hi or lo) + 1))
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            return node
+    except Exception:
+        return None
+    return None

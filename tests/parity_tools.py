@@ -105,8 +105,12 @@ def _warm(_):
 
 
 def _base_times(_):
+    """(pid, per-job seconds of the base runs this worker did since it was last asked); the sleep makes every worker of
+    the pool take one of these."""
     time.sleep(0.2)
-    return os.getpid(), list(_WORK.get("base_s", []))
+    ts = list(_WORK.get("base_s", []))
+    _WORK["base_s"] = []
+    return os.getpid(), ts
 
 
 def ensemble_job(job):
@@ -130,10 +134,52 @@ def ensemble_job(job):
     return b, m, _trace_u(_make_oracle(cfg, permuted_weights(wd, rng)), sc)
 
 
-def run_ensemble(workload, scenes, cores, n_ulp=8, n_perm=4):
+def host_cores():
+    """(physical cores, hardware threads) of this host."""
+    logical = os.cpu_count() or 1
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or logical
+    except Exception:  # pragma: no cover
+        phys = logical
+    return int(phys), int(logical)
+
+
+def _timed_with_concurrency(ex, jobs, conc):
+    """Run `jobs` through the pool with at most `conc` in flight (dispatcher threads: no barrier between rounds).
+    Returns (results in job order, wall seconds)."""
+    import queue
+    import threading
+    q = queue.Queue()
+    for i, jb in enumerate(jobs):
+        q.put((i, jb))
+    out = [None] * len(jobs)
+
+    def pump():
+        while True:
+            try:
+                i, jb = q.get_nowait()
+            except queue.Empty:
+                return
+            out[i] = ex.submit(ensemble_job, jb).result()
+    th = [threading.Thread(target=pump) for _ in range(max(1, conc))]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    return out, time.perf_counter() - t0
+
+
+def run_ensemble(workload, scenes, cores, n_ulp=8, n_perm=4, sweep=True):
     """Returns (base [S,K,2,T], members [S,n,K,2,T], cpu plans/s of the base runs, worker processes used).
-    `cores` worker processes x 1 thread.  Phase 1, timed: the base run of every scene (the CPU baseline: rate = scenes /
-    wall time of the phase, workers already started and warm).  Phase 2, untimed: the ensemble members, one job each."""
+    Worker processes x 1 thread each (the BLAS / OpenMP thread counts are pinned to 1 in the PARENT's environment before the
+    pool is spawned: the children import numpy -- and create its thread pool -- long before any initializer runs; 256
+    workers x 256 BLAS threads was what made a plan take 7 s inside a worker in round 2).
+    Phase 1, timed: base runs at several levels of concurrency (physical cores / 4, / 2, all physical cores, all
+    hardware threads, capped by `cores`), 2 jobs per worker each; the CPU baseline is the BEST rate of the sweep
+    (run_ensemble.last_sweep has the table, .last_job_seconds the per-job times of the winning level,
+    .last_single_seconds the time of a plan with ONE job in flight).  Phase 2, untimed: the ensemble members."""
     import multiprocessing as mp
     from concurrent.futures import ProcessPoolExecutor
     from neupan_amd.scenes import CONFIGS
@@ -142,34 +188,57 @@ def run_ensemble(workload, scenes, cores, n_ulp=8, n_perm=4):
     cores = max(1, min(cores, len(scenes) * max(n_mem, 1)))
     wd = _weights_np(CONFIGS[workload])
     got = {}
+    run_ensemble.last_sweep, run_ensemble.last_job_seconds, run_ensemble.last_single_seconds = None, None, None
+    for k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+        os.environ[k] = "1"                      # inherited by the spawned workers, in place before they import numpy
     if cores == 1:
         _worker_init(workload, wd)
         t0 = time.perf_counter()
         res = [ensemble_job((b, -1, n_ulp)) for b in scenes]
         wall = time.perf_counter() - t0
+        rate = len(scenes) / wall
+        run_ensemble.last_single_seconds = wall / len(scenes)
         res += [ensemble_job((b, m, n_ulp)) for b in scenes for m in range(n_mem)]
         base_workers = 1
     else:
+        phys, logical = host_cores()
+        levels = sorted({max(1, min(cores, v)) for v in ((phys // 4, phys // 2, phys, logical) if sweep else (cores,))})
         with ProcessPoolExecutor(max_workers=cores, mp_context=mp.get_context("spawn"), initializer=_worker_init,
                                  initargs=(workload, wd)) as ex:
             # every worker started and initialised (imports, weights) before the clock starts
             while len(set(ex.map(_warm, range(2 * cores)))) < min(cores, 2 * cores):
                 pass
-            t0 = time.perf_counter()
-            res = list(ex.map(ensemble_job, [(b, -1, n_ulp) for b in scenes]))
-            wall = time.perf_counter() - t0
-            per = {}
-            for pid, ts in ex.map(_base_times, range(2 * cores)):
-                per[pid] = ts
-            run_ensemble.last_job_seconds = sorted(t for ts in per.values() for t in ts)
+            # one job in flight: what a plan costs when the machine is otherwise idle
+            one, w1 = _timed_with_concurrency(ex, [(scenes[i % len(scenes)], -1, n_ulp) for i in range(3)], 1)
+            run_ensemble.last_single_seconds = w1 / 3
+            res, table, best = list(one), [], None
+            for lv in levels:
+                jobs = [(scenes[i % len(scenes)], -1, n_ulp) for i in range(max(2 * lv, min(len(scenes), 4 * lv)))]
+                for pid, ts in ex.map(_base_times, range(2 * cores)):      # (drains the per-worker job clocks)
+                    pass
+                out, wall = _timed_with_concurrency(ex, jobs, lv)
+                per = {}
+                for pid, ts in ex.map(_base_times, range(2 * cores)):
+                    per.setdefault(pid, []).extend(ts)
+                js = sorted(t for ts in per.values() for t in ts)
+                row = {"workers": lv, "plans": len(jobs), "wall_s": round(wall, 3), "plans_per_s": round(len(jobs) / wall, 2),
+                       "seconds_per_plan_in_worker_median": round(float(np.median(js)), 3) if js else None}
+                table.append(row)
+                res += out
+                if best is None or row["plans_per_s"] > best[0]["plans_per_s"]:
+                    best = (row, js)
+            run_ensemble.last_sweep = table
+            run_ensemble.last_job_seconds = best[1]
+            rate, base_workers = best[0]["plans_per_s"], best[0]["workers"]
+            have = {b for b, m, _ in res if m < 0}
+            res += list(ex.map(ensemble_job, [(b, -1, n_ulp) for b in scenes if b not in have]))
             res += list(ex.map(ensemble_job, [(b, m, n_ulp) for b in scenes for m in range(n_mem)]))
-        base_workers = min(cores, len(scenes))
     for b, m, tr in res:
         got[(b, m)] = tr
     base = np.stack([got[(b, -1)] for b in scenes])
     members = np.stack([np.stack([got[(b, m)] for m in range(n_mem)]) if n_mem else np.zeros((0,) + base.shape[1:], np.float32)
                         for b in scenes])
-    return base, members, len(scenes) / wall, base_workers
+    return base, members, rate, base_workers
 
 
 def _l2(a, b):

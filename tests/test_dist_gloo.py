@@ -83,3 +83,63 @@ def test_rccl_all_gather_branch_on_one_gpu():
         assert g.data_ptr() != u.data_ptr() and torch.equal(g, u) and torch.equal(g2, u)
     finally:
         dist.destroy_process_group()
+
+
+def _loop_worker(rank, world, port, inflight, n_steps, q):
+    """bench.py's serving loop (neupan_amd.serve.run_steps + ControlGatherer) with stand-in planners: `inflight` slots, each
+    step's controls a known function of (rank, slot, how often the slot ran)."""
+    import torch.distributed as dist
+    from neupan_amd.serve import ControlGatherer, run_steps
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, T = 4, 10
+    runs = [0] * inflight
+
+    def make(j):
+        def step():
+            runs[j] += 1
+            return {"opt_u": torch.full((B, 2, T), float(1000 * rank + 10 * j + runs[j]))}
+        return step
+    g = ControlGatherer(dist, world, device=None, slots=inflight)
+    last = run_steps(n_steps, [make(j) for j in range(inflight)], None, g, None)
+    rows = []
+    for j, item in enumerate(last):
+        if item is None:
+            rows.append(None)
+            continue
+        o, gathered = item
+        rows.append((tuple(gathered.shape), [float(gathered[r * B, 0, 0]) for r in range(world)]))
+    q.put((rank, rows, g.issued))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("inflight,n_steps", [(1, 3), (4, 10), (5, 3)])
+def test_serving_loop_schedule_with_two_ranks(inflight, n_steps):
+    """The schedule bench.py times, two ranks over gloo: one gather per step, issued in step order on every rank (no
+    deadlock with several slots in flight, also when fewer steps than slots run), every rank sees every rank's controls
+    of the SAME step in rank order."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_loop_worker, args=(r, 2, port, inflight, n_steps, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, rows, issued = q.get(timeout=120)
+        got[rank] = rows
+        assert issued == n_steps
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] == got[1]
+    for j, row in enumerate(got[0]):
+        ran = len(range(j, n_steps, inflight))           # how often slot j ran
+        if ran == 0:
+            assert row is None
+            continue
+        shape, firsts = row
+        assert shape == (2 * 4, 2, 10)
+        assert firsts == [float(1000 * r + 10 * j + ran) for r in range(2)]

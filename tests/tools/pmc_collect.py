@@ -1,4 +1,5 @@
-"""PMC evidence for bench.py's roofline object, per kernel, tracked: writes profiles/r02_pmc.json.
+"""PMC evidence for bench.py's roofline object, per kernel, tracked: writes gpurun_out/r03/pmc_<workload>.json (copy it to
+profiles/r03_pmc.json).
 
     python tests/tools/pmc_collect.py [workload]            # on the GPU box
 
@@ -10,7 +11,8 @@ duration from the kernel trace of the same pass, and derived figures:
   fp64_flops       = 64 lanes x (ADD_F64 + MUL_F64 + 2 FMA_F64) wave-instructions (an upper bound: lanes may be masked off)
   hbm_bytes        = FETCH_SIZE [KiB] x 1024 (x2 only where the kernel streams 16 B/lane -- none of ours do: the reads are
                      4-B/lane gathers, counted at face value, see the guide's HBM section) + WRITE_SIZE [KiB] x 1024
-`source_hash` ties the file to the kernel sources it was measured on (bench.py ignores it otherwise)."""
+Every kernel's record carries `source_hash` = the hash of the source files THAT kernel is built from (bench.kernel_hash):
+bench.py uses a record only while it matches the tree."""
 import collections, csv, json, os, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,7 +27,7 @@ GROUPS = [
     ["FETCH_SIZE"],
     ["WRITE_SIZE"],
 ]
-KERNELS = ("dune_kernel", "select_kernel", "nrmp_qp_kernel", "stage_kernel")
+KERNELS = ("dune_kernel", "select_geo_kernel", "select_kernel", "nrmp_qp_kernel", "stage_kernel")
 
 
 def short(name):
@@ -80,7 +82,7 @@ def derive(e, c):
 
 
 def main():
-    from bench import source_hash, BATCH
+    from bench import source_hash, kernel_hash, BATCH
     workload = sys.argv[1] if len(sys.argv) > 1 else "diff_1k_T10_K10"
     kern = collections.defaultdict(dict)
     durs = collections.defaultdict(list)
@@ -103,7 +105,9 @@ def main():
            "passes": log, "kernels": {}}
     for k, c in kern.items():
         ms = sum(durs[k]) / max(len(durs[k]), 1)
-        e = {"kernel": names.get(k, k), "avg_ms_alone": ms, "counters": c}
+        e = {"kernel": names.get(k, k), "avg_ms_alone": ms, "counters": c, "source_hash": kernel_hash(k)}
+        if c.get("SQ_ACTIVE_INST_LDS"):
+            e["lds_bank_conflict_frac"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_ACTIVE_INST_LDS"]
         gui = c.get("GRBM_GUI_ACTIVE")
         if gui and ms > 0:
             per_xcd = gui / max(1, round(gui / (ms * 1e-3 * 2.3e9)))      # the CSV may hold the sum over the 8 XCDs
@@ -120,8 +124,8 @@ def main():
         f, w = c.get("FETCH_SIZE", 0.0) * 1024, c.get("WRITE_SIZE", 0.0) * 1024
         e["fetch_bytes_raw"], e["write_bytes"], e["hbm_bytes_per_launch"] = f, w, f + w
         res["kernels"][k] = e
-    os.makedirs(os.path.join(ROOT, "gpurun_out", "r02"), exist_ok=True)
-    json.dump(res, open(os.path.join(ROOT, "gpurun_out", "r02", f"pmc_{workload}.json"), "w"), indent=1)
+    os.makedirs(os.path.join(ROOT, "gpurun_out", "r03"), exist_ok=True)
+    json.dump(res, open(os.path.join(ROOT, "gpurun_out", "r03", f"pmc_{workload}.json"), "w"), indent=1)
     print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "counters"} for k, v in res["kernels"].items()}, indent=1))
 
 
