@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--cpu-cores", type=int, default=0, help="worker processes of the CPU baseline (0 = all host cores)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-scene latency measurement")
+    ap.add_argument("--no-graph", action="store_true", help="every step launched eagerly (default: HIP-graph replay for the "
+                                                           "planners that carry no timing events)")
     ap.add_argument("--inflight", type=int, default=20, help="independent batches (steps) kept in flight, one stream each")
     ap.add_argument("--workload", default=WORKLOAD,
                     choices=sorted(k for k in __import__("neupan_amd.scenes", fromlist=["CONFIGS"]).CONFIGS),
@@ -130,10 +132,13 @@ def main():
     # One prepared step per batch in flight (PAN.make_step: arguments validated once, ONE library call per step, output
     # tensors reused -- a serving loop owns its buffers); fresh stop-criterion state every step, reset inside the staging
     # launch.  The controls of every step are all-gathered over RCCL from ONE communication stream (neupan_amd/serve.py).
+    # Planners that carry timing events (every 4th) launch eagerly -- events ride on the dispatches --, the others replay
+    # a HIP graph of the same launches (--no-graph: all eager).
+    timed_idx = set(range(0, nfl, 4)) if nfl >= 4 else set(range(nfl))
     steps = []
     for j in range(nfl):
         with torch.cuda.stream(streams[j]):
-            steps.append(pans[j].make_step(*args_dev[j], reset_state=True))
+            steps.append(pans[j].make_step(*args_dev[j], reset_state=True, graph=(not args.no_graph and j not in timed_idx)))
     torch.cuda.synchronize(dev)
     gatherer = ControlGatherer(dist, world, device=dev, slots=nfl)
 
@@ -147,7 +152,7 @@ def main():
     # HIP events ride on the launches of every 4th batch in flight (all of them with < 4): recording two events per launch
     # doubles the host's time to enqueue a step, and with 20 chains to start that ramp is what a short timed region
     # (the driver's 20 steps) mostly measures.  launch_ms below is the average over the launches that carry events.
-    timed_pans = pans[::4] if nfl >= 4 else pans
+    timed_pans = [pans[j] for j in sorted(timed_idx)]
     for p in timed_pans:
         p.profile(True)
     if dist is not None:
@@ -266,7 +271,9 @@ def main():
                                        "through a top-M selection, SURVEY section 7), keys geometric" if args.workload.startswith("poly8") else ""),
                    "scenes_per_gpu": BATCH, "points": N, "T": T, "K": K, "M": cfg.nrmp_max_num,
                    "batches_in_flight": nfl, "schedule": "one HIP stream per batch in flight, one prepared library call per step "
-                                                        "(PAN.make_step), gathers on one communication stream",
+                                                        "(PAN.make_step), " + ("eager launches" if args.no_graph else
+                                                        "HIP-graph replay except on the planners that carry timing events") +
+                                                        ", gathers on one communication stream",
                    "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "numa_node": numa,
                    "parallelism": f"scene-shard x{world}, RCCL all-gather of controls"
                                   + (" (process group initialised)" if dist is not None else "")},
@@ -312,7 +319,10 @@ def main():
         trace_u = tr["trace_u"].cpu().numpy()
         assert np.array_equal(trace_u[:, -1], timed_u), "traced run differs from the timed run"
         rep, hip, sp = judge(trace_u[:n_sc], base, members)
-        from parity_tools import host_cores
+        from parity_tools import host_cores, one_step_consistency, one_step_report
+        # D: one oracle iteration from the HIP path's own iterate vs the HIP path's next iterate, every scene, every iteration
+        rep["one_step"] = one_step_report(one_step_consistency(args.workload, range(n_sc), tr["trace_s"].cpu().numpy()[:n_sc],
+                                                               trace_u[:n_sc], args.cpu_cores if args.cpu_cores > 0 else host))
         phys, logical = host_cores()
         line["cpu_baseline"] = {"value": round(cpu_rate, 3), "unit": "plans/s", "cores": ncore, "kind": "port",
                                 "sample": f"scenes of the same workload (first {n_sc}, cycled), K={K} each, oracle/pan_oracle.py "
@@ -355,7 +365,9 @@ def main():
                        "boundary).  Ensemble per scene = the oracle itself on inputs moved by +-1 float32 ulp (8 members) and with the "
                        "DUNE hidden units permuted (same function, other fp32 summation order; 4 members).  well posed = ensemble "
                        "spread of the final controls <= 1e-4.  A: HIP <= 1e-4 on every well-posed scene; B: HIP inside the ensemble "
-                       "spread elsewhere; C: HIP <= 1e-5 at every iteration before the ensemble itself first disagrees by > 1e-5 "
+                       "spread elsewhere (reported; a 14th sample of a chaotic scene need not fall inside the hull of 13); C: HIP <= 1e-5 at "
+                       "every iteration before the ensemble itself first disagrees by > 1e-5; D (one_step): on every scene and "
+                       "iteration ONE oracle iteration from the HIP path's own iterate reproduces the HIP path's next iterate "
                        "(tests/parity_tools.py, DESIGN.md section 5)")
         # the kernel's own last QP, per scene: rebuilt on the host from the parameters the kernel built, fp64 solution certified
         batch0 = make_batch(cfg, rank * nfl * BATCH, BATCH)

@@ -455,8 +455,8 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
     if (e == hipSuccess) e = hipMemset(h->sel_stats_dev, 0, sizeof(unsigned));
     if (e == hipSuccess) e = hipHostMalloc(&h->sel_stats_host, sizeof(unsigned), hipHostMallocDefault);
     if (e == hipSuccess) *h->sel_stats_host = 0;
-    if (e == hipSuccess) e = hipMalloc(&h->audit_dev, 4 * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMemset(h->audit_dev, 0, 4 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc(&h->audit_dev, 8 * sizeof(unsigned));       // [4]: launches seen (device side)
+    if (e == hipSuccess) e = hipMemset(h->audit_dev, 0, 8 * sizeof(unsigned));
     h->select_v1 = getenv("NPA_SELECT_V1") != nullptr;
     {
       double rate = 1.0 / 64.0;              // audit tiles: one slice wave in 64 (NPA_AUDIT_RATE in [0, 1]; 0 = candidates only)
@@ -1087,7 +1087,7 @@ static int npa_self_test(npa_handle* h) {
                                           : "npa_create self-test: two runs of the DUNE stage differ (non-deterministic keys)");
   }
   // leave no trace: counters, sequence numbers, the key policy's window
-  if (h->audit_dev) HIP_TRY(hipMemset(h->audit_dev, 0, 4 * sizeof(unsigned)));
+  if (h->audit_dev) HIP_TRY(hipMemset(h->audit_dev, 0, 8 * sizeof(unsigned)));
   if (h->sel_stats_dev) HIP_TRY(hipMemset(h->sel_stats_dev, 0, sizeof(unsigned)));
   if (h->sel_stats_host) *h->sel_stats_host = 0;
   h->launch_seq = 0; h->stats_mark = 0; h->tiles_window = 0; h->calls_window = 0; h->hold = 0;

@@ -1141,9 +1141,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
       WSYNC();
     }
   };
-  // which waves run the extra audit tile: a hash of (launch, scene, slice)
+  // which waves run the extra audit tile: a hash of (launch, scene, slice).  The launch number is the host's sequence
+  // number plus a device-side count of launches (audit[4], bumped by workgroup 0): a launch replayed from a HIP graph
+  // carries a frozen host number, and should still audit other waves and other points each time
   bool audit_wave = false;
   if (audit && audit_thresh) {
+    audit_seed += (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(audit + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (blockIdx.x == 0 && lane == 0) atomicAdd(audit + 4, 1u);
     unsigned hsh = (audit_seed * 0x9E3779B1u) ^ ((unsigned)b * 0x85EBCA77u) ^ ((unsigned)t * 0xC2B2AE3Du);
     hsh ^= hsh >> 15; hsh *= 0x2C1B3C6Du; hsh ^= hsh >> 12; hsh *= 0x297A2D39u; hsh ^= hsh >> 15;
     audit_wave = hsh < audit_thresh || audit_thresh == 0xFFFFFFFFu;

@@ -235,7 +235,11 @@ __device__ __forceinline__ PairC qp_pair(int p, int T, int npu, double sb0, doub
   return c;
 }
 
-template <int TT, int MM, bool BWD = false>
+// SCANW: the scan forms of the Phi products and the P_t blocks also for horizons of 17..32 steps (two DPP rows).  Off by
+// default: at T = 20 (acker) they changed the PAN loop's parity verdicts (deviations of 6e-5 before the reference ensemble
+// itself diverges: the prefix / suffix sums round differently and the QPs there are flat); NPA_QP_SCAN_WIDE=1 selects the
+// instantiation for measurements.
+template <int TT, int MM, bool BWD = false, bool SCANW = false>
 // (two waves per SIMD: <= 256 registers.  tests/test_abi.py reads the counts of the built code object and fails on any
 // spill or scratch use)
 __global__ __attribute__((amdgpu_flat_work_group_size(QP_THREADS, QP_THREADS), amdgpu_waves_per_eu(2, 3)))
@@ -537,7 +541,7 @@ void nrmp_qp_kernel(
   //   s = Phi v :  theta_t = sum_{r<=t} B_r[2,:] v_r ;  xy_t = sum_{r<=t} (a_r theta_{r-1} + B_r[:2,:] v_r)
   //   w = Phi'q :  l_xy,t = sum_{r>=t} q_r[:2] ;  l_2,t = sum_{r>=t} (q_r[2] + a_{r+1} . l_xy,r+1) ;  w_t = B_t' l_t
   // (checked against the dense forms in fp64: tests/tools/scan_forms_check.py)
-  constexpr bool SCAN = TT > 0 && TT <= 32;
+  constexpr bool SCAN = TT > 0 && (TT <= 16 || (SCANW && TT <= 32));
   constexpr bool WIDE = TT > 16;
   const double row0 = lane < 16 ? 1.0 : 0.0;
   auto phi_mul = [&](const double* v, double* out3) {
@@ -1464,15 +1468,18 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
     hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<10, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<20, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<20, 10, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-#define QP_LAUNCH(TTV, MMV)                                                                                      \
-  hipExtLaunchKernelGGL((nrmp_qp_kernel<TTV, MMV>), dim3(nblocks), dim3(QP_THREADS), shmem, stream, ev_start, ev_stop, 0, \
+#define QP_LAUNCH(...)                                                                                           \
+  hipExtLaunchKernelGGL((nrmp_qp_kernel<__VA_ARGS__>), dim3(nblocks), dim3(QP_THREADS), shmem, stream, ev_start, ev_stop, 0, \
                         P, cur_s_in, cur_u_in, ref_s, ref_us, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count,  \
                         cur_s_out, cur_u_out, cur_d_out, out_s, out_u, out_d, out_min_distance, out_iters,            \
                         out_nrmp_points, flags, state, qp_info, warm, scene0, batch,                                 \
                         QpBackward{nullptr, nullptr, nullptr, nullptr, nullptr, dbg_abc, dbg_f, dbg_x}, trig_out)
+  static const bool scan_wide = getenv("NPA_QP_SCAN_WIDE") != nullptr;
   if (P.T == 10 && P.M == 10 && !force_generic) QP_LAUNCH(10, 10);
+  else if (P.T == 20 && P.M == 10 && !force_generic && scan_wide) QP_LAUNCH(20, 10, false, true);
   else if (P.T == 20 && P.M == 10 && !force_generic) QP_LAUNCH(20, 10);
   else QP_LAUNCH(0, 0);
 #undef QP_LAUNCH

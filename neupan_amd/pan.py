@@ -360,13 +360,17 @@ class PAN(torch.nn.Module):
         self.last_out = out
         return out
 
-    def make_step(self, nom_s, nom_u, ref_s, ref_us, points=None, velocities=None, n_points=None, reset_state=False):
+    def make_step(self, nom_s, nom_u, ref_s, ref_us, points=None, velocities=None, n_points=None, reset_state=False,
+                  graph=False):
         """Serving-loop form of forward_batch: validate and convert the arguments ONCE and return `step()`, which plans
         the batch with ONE library call (npa_forward_batch_flags) on the current stream and returns the same dict of
         output tensors every time -- they are allocated here and REUSED (forward_batch returns fresh tensors per call,
         like the reference; a loop that owns its buffers does not need that, and the per-call conversions, allocations and
         a dozen ctypes calls were a third of a step's wall time).  The input tensors are read in place at every step():
-        refresh them with copy_() between steps."""
+        refresh them with copy_() between steps.
+        graph=True: the step's launches (staging + K x {selection, QP}) are recorded once into a HIP graph and step()
+        replays it: one graph launch instead of 1 + 2K kernel launches on the host (the kernels, their order and their
+        results are the same; the per-launch profiling events of profile() do not exist inside a graph)."""
         self.forward_begin(nom_s, nom_u, ref_s, ref_us, points, velocities, n_points, reset_state=reset_state)
         for k in range(self.iter_num):               # (the first step also runs here: buffers and the handle are warm)
             self.forward_iter(k)
@@ -387,6 +391,24 @@ class PAN(torch.nn.Module):
         idx = dev.index if dev.index is not None else torch.cuda.current_device()
 
         cur_dev = torch.cuda.current_device
+        if graph:
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(cur_stream(dev))
+            with torch.cuda.device(dev):
+                with torch.cuda.graph(g, stream=side):
+                    rc = fn(*args, C.c_void_p(cur_stream(dev).cuda_stream), flags)
+            check(rc, "npa_forward_batch_flags (graph capture)")
+            cur_stream(dev).wait_stream(side)
+
+            def step_graph():
+                g.replay()
+                self._last = last
+                self.last_out = out
+                return out
+            step_graph.device_index = idx
+            step_graph.graph = g
+            return step_graph
 
         def step():
             if cur_dev() != idx:                     # the launches must see the device of the handle
@@ -410,12 +432,14 @@ class PAN(torch.nn.Module):
         B, T = self._B, self.T
         wsf = self._ws.view(torch.float32)
         off_u = (B * 3 * (T + 1) + 3) // 4 * 4                  # cur_u follows cur_s (pan_common.h: npa_scratch_layout)
-        us = []
+        us, ss = [], []
         for k in range(self.iter_num):
             self.forward_iter(k)
             us.append(wsf[off_u:off_u + B * 2 * T].clone().reshape(B, 2, T))
+            ss.append(wsf[:B * 3 * (T + 1)].clone().reshape(B, 3, T + 1))
         out = self.forward_end()
         out["trace_u"] = torch.stack(us, dim=1)
+        out["trace_s"] = torch.stack(ss, dim=1)          # (B, K, 3, T+1): the states each iteration hands to the next
         return out
 
     # ------------------------------------------------------------------ reference signature

@@ -241,6 +241,65 @@ def run_ensemble(workload, scenes, cores, n_ulp=8, n_perm=4, sweep=True):
     return base, members, rate, base_workers
 
 
+def one_step_job(job):
+    """One PAN iteration of the ORACLE started from the HIP path's own iterate: (scene, k, nom_s, nom_u) -> controls."""
+    from neupan_amd.scenes import make_scene
+    b, k, nom_s, nom_u = job
+    cfg, wd = _WORK["cfg"], _WORK["wd"]
+    sc = make_scene(cfg, b)
+    orc = _make_oracle(cfg, wd)
+    orc.iter_num = 1
+    s, u, d = orc.forward(nom_s, nom_u, sc["ref_s"], sc["ref_us"], sc["points"], sc["velocities"])
+    return b, k, u.astype(np.float32)
+
+
+def one_step_consistency(workload, scenes, trace_s, trace_u, cores):
+    """Verdict D: does the HIP path FOLLOW the reference algorithm step by step, also on scenes where the PAN fixed-point
+    iteration is chaotic and end-to-end comparisons mean nothing?  For every scene and every PAN iteration k the oracle
+    runs ONE iteration from the HIP path's own iterate k-1 (the scene's nominal for k = 0) and its controls are compared
+    with the HIP path's iterate k: no amplification over iterations enters, only what one iteration of the two
+    implementations differs by (fp32 encoder order, two fp64 solvers on the same QP, a tie at rank M / M+1 of a slice).
+    trace_s [S,K,3,T+1], trace_u [S,K,2,T] from PAN.forward_batch_trace.  Returns the [S,K] control L2 deviations."""
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    from neupan_amd.scenes import CONFIGS, make_scene
+    cfg = CONFIGS[workload]
+    scenes = list(scenes)
+    S, K = trace_u.shape[:2]
+    jobs = []
+    for i, b in enumerate(scenes):
+        sc = make_scene(cfg, b)
+        for k in range(K):
+            ns = sc["nom_s"] if k == 0 else trace_s[i, k - 1]
+            nu = sc["nom_u"] if k == 0 else trace_u[i, k - 1]
+            jobs.append((b, k, np.asarray(ns, dtype=np.float32), np.asarray(nu, dtype=np.float32)))
+    for kk in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+        os.environ[kk] = "1"
+    wd = _weights_np(cfg)
+    cores = max(1, min(cores, len(jobs)))
+    if cores == 1:
+        _worker_init(workload, wd)
+        res = [one_step_job(j) for j in jobs]
+    else:
+        with ProcessPoolExecutor(max_workers=cores, mp_context=mp.get_context("spawn"), initializer=_worker_init,
+                                 initargs=(workload, wd)) as ex:
+            res = list(ex.map(one_step_job, jobs, chunksize=max(1, len(jobs) // (4 * cores))))
+    pos = {b: i for i, b in enumerate(scenes)}
+    dev = np.zeros((S, K))
+    for b, k, u in res:
+        dev[pos[b], k] = float(_l2(u, trace_u[pos[b], k]))
+    return dev
+
+
+def one_step_report(dev, tol=1e-4):
+    """Summary of one_step_consistency's [S,K] deviations for a bench line / an assertion."""
+    flat = dev.reshape(-1)
+    return {"steps_checked": int(flat.size), "max": float(flat.max()), "p99": float(np.quantile(flat, 0.99)),
+            "median": float(np.median(flat)), "frac_le_1e-5": float((flat <= 1e-5).mean()), "frac_le_tol": float((flat <= tol).mean()),
+            "worst": [{"scene_pos": int(i), "iteration": int(k) + 1, "ctrl_l2": float(dev[i, k])}
+                      for i, k in zip(*np.unravel_index(np.argsort(-flat)[:5], dev.shape))]}
+
+
 def _l2(a, b):
     d = a.astype(np.float64) - b.astype(np.float64)
     return np.sqrt((d * d).sum(axis=(-1, -2)))
