@@ -75,8 +75,9 @@ def main():
     ap.add_argument("--cpu-cores", type=int, default=0, help="worker processes of the CPU baseline (0 = all host cores)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-scene latency measurement")
-    ap.add_argument("--no-graph", action="store_true", help="every step launched eagerly (default: HIP-graph replay for the "
-                                                           "planners that carry no timing events)")
+    ap.add_argument("--graph", action="store_true", help="HIP-graph replay of a step's 21 launches for the planners that carry no "
+                                                        "timing events (measured: SLOWER than eager launches with 20 chains in "
+                                                        "flight, 513 k vs 656 k plans/s, DESIGN.md section 3.4; default: eager)")
     ap.add_argument("--inflight", type=int, default=20, help="independent batches (steps) kept in flight, one stream each")
     ap.add_argument("--workload", default=WORKLOAD,
                     choices=sorted(k for k in __import__("neupan_amd.scenes", fromlist=["CONFIGS"]).CONFIGS),
@@ -132,13 +133,13 @@ def main():
     # One prepared step per batch in flight (PAN.make_step: arguments validated once, ONE library call per step, output
     # tensors reused -- a serving loop owns its buffers); fresh stop-criterion state every step, reset inside the staging
     # launch.  The controls of every step are all-gathered over RCCL from ONE communication stream (neupan_amd/serve.py).
-    # Planners that carry timing events (every 4th) launch eagerly -- events ride on the dispatches --, the others replay
-    # a HIP graph of the same launches (--no-graph: all eager).
+    # Planners that carry timing events: every 4th (events ride on the dispatches).  --graph: the others replay a HIP graph
+    # of the same launches (measured slower, kept for the record).
     timed_idx = set(range(0, nfl, 4)) if nfl >= 4 else set(range(nfl))
     steps = []
     for j in range(nfl):
         with torch.cuda.stream(streams[j]):
-            steps.append(pans[j].make_step(*args_dev[j], reset_state=True, graph=(not args.no_graph and j not in timed_idx)))
+            steps.append(pans[j].make_step(*args_dev[j], reset_state=True, graph=(args.graph and j not in timed_idx)))
     torch.cuda.synchronize(dev)
     gatherer = ControlGatherer(dist, world, device=dev, slots=nfl)
 
@@ -271,7 +272,7 @@ def main():
                                        "through a top-M selection, SURVEY section 7), keys geometric" if args.workload.startswith("poly8") else ""),
                    "scenes_per_gpu": BATCH, "points": N, "T": T, "K": K, "M": cfg.nrmp_max_num,
                    "batches_in_flight": nfl, "schedule": "one HIP stream per batch in flight, one prepared library call per step "
-                                                        "(PAN.make_step), " + ("eager launches" if args.no_graph else
+                                                        "(PAN.make_step), " + ("eager launches" if not args.graph else
                                                         "HIP-graph replay except on the planners that carry timing events") +
                                                         ", gathers on one communication stream",
                    "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "numa_node": numa,
@@ -307,6 +308,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from parity_tools import gpu_last_qp_certificates, judge, run_ensemble
+        try:                                    # the CPU baseline gets the whole host, not the GPU's NUMA node
+            os.sched_setaffinity(0, range(os.cpu_count() or 1))
+        except Exception:
+            pass
         host = os.cpu_count() or 1
         n_sc = args.cpu_scenes if args.cpu_scenes > 0 else (BATCH if host >= 64 else min(96, BATCH))
         n_sc = min(n_sc, BATCH)
@@ -351,8 +356,8 @@ def main():
                 with torch.cuda.stream(streams[j]):
                     st_w.append(pans[j].make_step(*a_w, reset_state=True))
             torch.cuda.synchronize(dev)
-            nw = max(2 * nfl, 40)
-            serve_steps(nfl, st_w, streams, None, cur)
+            nw = args.steps
+            serve_steps(args.warmup, st_w, streams, None, cur)
             torch.cuda.synchronize(dev)
             tw = time.perf_counter()
             serve_steps(nw, st_w, streams, None, cur)

@@ -34,6 +34,9 @@
 #include <cstdlib>
 
 #define QP_THREADS 64          // lanes cooperating on one scene (one wavefront)
+#ifndef NPA_QP_WAVES
+#define NPA_QP_WAVES 2          // waves per SIMD the register allocation aims at
+#endif
 #define QP_MAX_IT 40
 // per-step records in LDS, one lane per horizon step: strides chosen so that ten (twenty) lanes hit distinct banks.  With
 // the natural strides -- 12 doubles for the linearisation, 8 for the step sums -- steps 0 / 8 (and 0 / 4 / 8) shared a bank on
@@ -235,14 +238,13 @@ __device__ __forceinline__ PairC qp_pair(int p, int T, int npu, double sb0, doub
   return c;
 }
 
-// SCANW: the scan forms of the Phi products and the P_t blocks also for horizons of 17..32 steps (two DPP rows).  Off by
-// default: at T = 20 (acker) they changed the PAN loop's parity verdicts (deviations of 6e-5 before the reference ensemble
-// itself diverges: the prefix / suffix sums round differently and the QPs there are flat); NPA_QP_SCAN_WIDE=1 selects the
-// instantiation for measurements.
+// SCANW: the scan forms of the Phi products and the P_t blocks also for horizons of 17..32 steps (two DPP rows); the
+// launcher's default at T = 20 (acker: 69 k -> 79 k plans/s; the parity verdicts of tests/test_gpu_parity.py are the
+// same with and without them).  NPA_QP_NOSCAN_WIDE=1 selects the dense-product instantiation for A/B measurements.
 template <int TT, int MM, bool BWD = false, bool SCANW = false>
 // (two waves per SIMD: <= 256 registers.  tests/test_abi.py reads the counts of the built code object and fails on any
 // spill or scratch use)
-__global__ __attribute__((amdgpu_flat_work_group_size(QP_THREADS, QP_THREADS), amdgpu_waves_per_eu(2, 3)))
+__global__ __attribute__((amdgpu_flat_work_group_size(QP_THREADS, QP_THREADS), amdgpu_waves_per_eu(NPA_QP_WAVES, 3)))
 void nrmp_qp_kernel(
     DevParams P, const float* cur_s_in, const float* cur_u_in, const float* __restrict__ ref_s,
     const float* __restrict__ ref_us, const float* __restrict__ mu_sorted, const float* __restrict__ lam_sorted,
@@ -283,6 +285,11 @@ void nrmp_qp_kernel(
   // directions, the hinge offsets -- live in registers, not in LDS (7 arrays, 5.5 KB of the scene's 26 KB: the LDS
   // block is what limits how many scenes a CU holds).  Arrays other lanes read (multipliers, 1/w, rhs weights) stay.
   constexpr bool REGROWS = TT > 0 && MM > 0 && (MM % 2) == 0 && TT * MM / 2 <= QP_THREADS && 5 * TT - 2 <= QP_THREADS;
+  // SCAN: the products with Phi, the blocks of P_t and the rows of K' are built from per-step sums over the horizon (lane =
+  // t, DPP row scans) -- Phi itself is never stored (5 KB of the scene's LDS block at T = 10, 20 KB at T = 20)
+  constexpr bool SCAN = TT > 0 && (TT <= 16 || (SCANW && TT <= 32));
+  constexpr bool WIDE = TT > 16;
+  const double row0 = lane < 16 ? 1.0 : 0.0;
 
   // ---- LDS carve (doubles) -----------------------------------------------------------
   // Rows of the interior-point method first, at even offsets (they are read and written two at a time).  The rows on u
@@ -316,7 +323,7 @@ void nrmp_qp_kernel(
   // a(a+1)/2), Km = L as a full [nu][nu+1] matrix whose diagonal and upper triangle stay ZERO: the substitutions read
   // row `lane` (forward) and column `lane` (backward) of it with no lane predicates and no copy of L in registers
   // (fast path: the P_t staging is the [T][6] block s3 | q3 -- both are dead between the residual phase and the passes)
-  double* Ytg = Phi + (size_t)T * 3 * ldp;
+  double* Ytg = Phi + (SCAN ? 0 : (size_t)T * 3 * ldp);
   double* Hm = Ytg + (TT > 0 ? 0 : (size_t)T * 2 * ldp);
   double* Km = Hm + (TT > 0 ? (size_t)nu * (nu + 1) / 2 : (size_t)nu * ldk);
   double* cv = Km + (size_t)nu * ldk;         // [T][3]
@@ -332,6 +339,7 @@ void nrmp_qp_kernel(
   double* dxu = xbest + nu + T;               // [nu]    (dxu, dxd contiguous)
   double* dxd = dxu + nu;                     // [T]
   double* invd = dxd + T;                     // [nu]   1/L_kk
+  double* cpre = invd + nu;                   // [T][2] (SCAN) prefix sums of (A02, A12): A_i ... A_(r+1) = I + (cpre_i - cpre_r) e_2'
   // pair table of the H build: the fast path needs it during the set-up only and parks it in the block of L (zeroed
   // after the H build, below)
   unsigned char* pa = reinterpret_cast<unsigned char*>(TT > 0 ? Km : invd + nu);      // [npair]
@@ -390,7 +398,7 @@ void nrmp_qp_kernel(
     o[8] = C0; o[9] = C1; o[10] = C2;
   }
   // pair table (a >= c), activity of the u rows, their bounds
-  for (int p = lane; p < npair; p += QP_THREADS) {
+  for (int p = lane; p < (SCAN ? 0 : npair); p += QP_THREADS) {
     int a = (int)((sqrtf(8.0f * (float)p + 1.0f) - 1.0f) * 0.5f);
     while ((a + 1) * (a + 2) / 2 <= p) ++a;
     while (a * (a + 1) / 2 > p) --a;
@@ -403,12 +411,33 @@ void nrmp_qp_kernel(
   const double sf0 = isfinite(P.speed_bound[0]) ? 1.0 : 0.0, sf1 = isfinite(P.speed_bound[1]) ? 1.0 : 0.0;
   const double af0 = isfinite(P.acce_bound[0]) ? 1.0 : 0.0, af1 = isfinite(P.acce_bound[1]) ? 1.0 : 0.0;
   const int npu = mcu >> 1, npc = npu + (obs ? T : 0);
-#define PAIR_C(p) qp_pair((p), T, npu, sb0, sb1, ab0, ab1, sf0, sf1, af0, af1, dmaxv, dmin0)
+#define PAIR_C0(p) qp_pair((p), T, npu, sb0, sb1, ab0, ab1, sf0, sf1, af0, af1, dmaxv, dmin0)
+  // REGROWS: a lane owns ONE pair (p = lane) in every pass, so its constants are six registers computed once -- not ten
+  // wave-uniform doubles kept alive through the whole solve and ~25 instructions of selection at each of the six uses
+  const PairC my_pair = PAIR_C0(REGROWS && lane < npc ? lane : 0);
+#define PAIR_C(p) (REGROWS ? my_pair : PAIR_C0(p))
   // hinge rows two at a time (rows 2l, 2l + 1 of step t = 2l / M) when M is even
   constexpr bool HPAIR = TT > 0 && MM > 0 && (MM % 2) == 0;
   LSYNC();
 
   // ---- Phi recursion: Phi[t] = A_t Phi[t-1] + [B_t at cols 2t,2t+1]; A = I + e0 A02 e2' + e1 A12 e2'
+  if constexpr (SCAN) {
+    // no Phi: the free response c_t by scans (theta is a prefix sum of C2, x / y of a_t theta_t + C_t), and the prefix sums
+    // of a that every later use of Phi is rebuilt from
+    const bool on = lane < TT;
+    const double* o = Abc + (on ? lane : 0) * QP_ABC_LD;
+    const double a0 = on ? o[0] : 0.0, a1 = on ? o[1] : 0.0, c0 = on ? o[8] : 0.0, c1 = on ? o[9] : 0.0, c2 = on ? o[10] : 0.0;
+    const double th0 = s_in[2 * (T + 1)];
+    const double thi = scan_prefix<WIDE>(c2), the = th0 + (thi - c2);          // theta before step t
+    const double x = (double)s_in[0] + scan_prefix<WIDE>(fma(a0, the, c0));
+    const double y = (double)s_in[T + 1] + scan_prefix<WIDE>(fma(a1, the, c1));
+    const double p0 = scan_prefix<WIDE>(a0), p1 = scan_prefix<WIDE>(a1);
+    if (on) {
+      cv[lane * 3 + 0] = x; cv[lane * 3 + 1] = y; cv[lane * 3 + 2] = th0 + thi;
+      st2(cpre + 2 * lane, p0, p1);
+    }
+    LSYNC();
+  } else
   for (int t = 0; t < T; ++t) {
     const double* o = Abc + t * QP_ABC_LD;
     double* Pt = Phi + (size_t)t * 3 * ldp;
@@ -438,6 +467,11 @@ void nrmp_qp_kernel(
   const double W1 = 2.0 * (double)P.q_s[1] * (double)P.q_s[1] + P.bk;
   const double W2 = 2.0 * m2 * (double)P.q_s[2] * (double)P.q_s[2] + P.bk;
   const double pu = P.p_u;
+  if constexpr (SCAN) {
+    // the state cost's Hessian Phi' W Phi is not formed: W joins S'_t in the P_t blocks of every iteration (K' build), and the
+    // packed triangle only carries the band terms of C_u' D C_u (+ 2 p_u^2 on the speed diagonal), zero elsewhere
+    for (int q = lane; q < npair; q += QP_THREADS) Hm[q] = 0.0;
+  } else
   for (int p = lane; p < npair; p += QP_THREADS) {
     int a = pa[p], c = pc[p];
     double acc = 0;
@@ -510,6 +544,22 @@ void nrmp_qp_kernel(
   QP_COLD_INIT();
   double gmax = obs ? (double)P.eta : 0.0;
   // g_u = Phi' lin - 2 p_u gamma_b on the speed entries
+  if constexpr (SCAN) {
+    // Phi' lin by the suffix-sum form (phi_tmul below, written out here: lin itself must survive)
+    const bool on = lane < TT;
+    const int t = on ? lane : 0;
+    const double q0 = on ? lin[3 * t] : 0.0, q1 = on ? lin[3 * t + 1] : 0.0, q2 = on ? lin[3 * t + 2] : 0.0;
+    const double l0 = scan_suffix<WIDE>(q0, row0), l1 = scan_suffix<WIDE>(q1, row0);
+    const double2 an = ld2(Abc + (t + 1 < TT ? t + 1 : t) * QP_ABC_LD);
+    const double l2 = scan_suffix<WIDE>(on ? q2 + an.x * scan_next<WIDE>(l0, lane) + an.y * scan_next<WIDE>(l1, lane) : 0.0, row0);
+    const double* o = Abc + t * QP_ABC_LD;
+    const double2 b0 = ld2(o + 2), b1 = ld2(o + 4), b2 = ld2(o + 6);
+    if (on) {
+      const double g0 = b0.x * l0 + b1.x * l1 + b2.x * l2 - 2.0 * pu * (double)__fmul_rn(P.p_u, rus[t]);
+      const double g1 = b0.y * l0 + b1.y * l1 + b2.y * l2;
+      gmax = fmax(gmax, fmax(fabs(g0), fabs(g1)));
+    }
+  } else
   for (int a = lane; a < nu; a += QP_THREADS) {
     double acc = 0;
     for (int t = a >> 1; t < T; ++t) {
@@ -525,7 +575,9 @@ void nrmp_qp_kernel(
   const double inv_m = 1.0 / m_tot;
   const double pub = (lane < nu && !(lane & 1)) ? -2.0 * pu * (double)__fmul_rn(P.p_u, rus[lane >> 1]) : 0.0;
   LSYNC();
-  if constexpr (TT > 0) {
+  if constexpr (SCAN) {
+    hdiag = (lane < NU && !(lane & 1)) ? 2.0 * pu * pu : 0.0;
+  } else if constexpr (TT > 0) {
     if (lane < NU) {
       hdiag = Hm[lane * (lane + 1) / 2 + lane];
       hoff = lane >= 2 ? Hm[lane * (lane + 1) / 2 + lane - 2] : 0.0;
@@ -541,9 +593,6 @@ void nrmp_qp_kernel(
   //   s = Phi v :  theta_t = sum_{r<=t} B_r[2,:] v_r ;  xy_t = sum_{r<=t} (a_r theta_{r-1} + B_r[:2,:] v_r)
   //   w = Phi'q :  l_xy,t = sum_{r>=t} q_r[:2] ;  l_2,t = sum_{r>=t} (q_r[2] + a_{r+1} . l_xy,r+1) ;  w_t = B_t' l_t
   // (checked against the dense forms in fp64: tests/tools/scan_forms_check.py)
-  constexpr bool SCAN = TT > 0 && (TT <= 16 || (SCANW && TT <= 32));
-  constexpr bool WIDE = TT > 16;
-  const double row0 = lane < 16 ? 1.0 : 0.0;
   auto phi_mul = [&](const double* v, double* out3) {
     if constexpr (SCAN) {
       const bool on = lane < TT;
@@ -855,10 +904,13 @@ void nrmp_qp_kernel(
           // A(t+1)...A(s) = I + (c_s - c_t) e_2' with c the prefix sum of a, so the blocks of P_t are suffix sums over
           // s >= t of S_s, S_s c_s and c_s'S_s c_s (lane = t; no serial recursion, no broadcast of S'):
           //   P_xy,xy = sS ;  P_xy,2 = sSc - sS c_t ;  P_22 = scSc - 2 c_t . sSc + c_t' sS c_t
+          // The state cost's weights W = diag(W0, W1, W2) enter here as well (S_s -> S_s + diag(W0, W1); W2 sits on the
+          // theta entry only and reaches P_22 as W2 x the number of steps s >= t): K' = band + sum_t Phi_t' (S'_t + W) Phi_t
+          // with no precomputed Phi' W Phi.
           const bool on = lane < TT;
-          const double2 a01 = ld2(Abc + (on ? lane : 0) * QP_ABC_LD);
-          const double c0 = scan_prefix<WIDE>(on ? a01.x : 0.0), c1 = scan_prefix<WIDE>(on ? a01.y : 0.0);
-          const double s00 = on ? S0r : 0.0, s01 = on ? S1r : 0.0, s11 = on ? S2r : 0.0;
+          const double2 cp = ld2(cpre + 2 * (on ? lane : 0));
+          const double c0 = on ? cp.x : 0.0, c1 = on ? cp.y : 0.0;
+          const double s00 = on ? S0r + W0 : 0.0, s01 = on ? S1r : 0.0, s11 = on ? S2r + W1 : 0.0;
           const double sc0 = s00 * c0 + s01 * c1, sc1 = s01 * c0 + s11 * c1;
           const double p00 = scan_suffix<WIDE>(s00, row0), p01 = scan_suffix<WIDE>(s01, row0), p11 = scan_suffix<WIDE>(s11, row0);
           const double t0 = scan_suffix<WIDE>(sc0, row0), t1 = scan_suffix<WIDE>(sc1, row0), t2 = scan_suffix<WIDE>(c0 * sc0 + c1 * sc1, row0);
@@ -866,7 +918,7 @@ void nrmp_qp_kernel(
           if (on) {
             st2(Pst + lane * 6, p00, p01);
             st2(Pst + lane * 6 + 2, t0 - u0, p11);
-            st2(Pst + lane * 6 + 4, t1 - u1, t2 - 2.0 * (c0 * t0 + c1 * t1) + (c0 * u0 + c1 * u1));
+            st2(Pst + lane * 6 + 4, t1 - u1, t2 - 2.0 * (c0 * t0 + c1 * t1) + (c0 * u0 + c1 * u1) + W2 * (double)(TT - lane));
           }
         } else {
         double p00 = 0, p01 = 0, p02 = 0, p11 = 0, p12 = 0, p22 = 0;
@@ -908,6 +960,23 @@ void nrmp_qp_kernel(
         const double g0 = Pi[0] * b0 + Pi[1] * b1 + Pi[2] * b2;
         const double g1 = Pi[1] * b0 + Pi[3] * b1 + Pi[4] * b2;
         const double g2 = Pi[2] * b0 + Pi[4] * b1 + Pi[5] * b2;
+        if constexpr (SCAN) {
+          // Phi_i[:, 2r + k] = (I + (c_i - c_r) e_2') B_r[:, k] for r <= i, so with G2 = g2 + g . c_i the entry is
+          //   g0 B_r[0,k] + g1 B_r[1,k] + (G2 - g . c_r) B_r[2,k]
+          // from wave-uniform loads of step r's B and c (two columns per step); columns beyond the row's own are garbage
+          // that nobody reads, as before
+          const double2 ci = ld2(cpre + 2 * i);
+          const double G2 = g2 + g0 * ci.x + g1 * ci.y;
+#pragma unroll
+          for (int r = 0; r < TT; ++r) {
+            const double* o = Abc + r * QP_ABC_LD;
+            const double2 bb0 = ld2(o + 2), bb1 = ld2(o + 4), bb2 = ld2(o + 6), cr = ld2(cpre + 2 * r);
+            const double e = G2 - (g0 * cr.x + g1 * cr.y);
+            arow[2 * r] = fma(g0, bb0.x, fma(g1, bb1.x, fma(e, bb2.x, Hm[ar * (ar + 1) / 2 + 2 * r])));
+            arow[2 * r + 1] = fma(g0, bb0.y, fma(g1, bb1.y, fma(e, bb2.y, Hm[ar * (ar + 1) / 2 + 2 * r + 1])));
+            if ((r & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
         const double* Ph = Phi + (size_t)i * 3 * ldp;  // Phi_i rows (zero beyond column 2i+1)
 #pragma unroll
         for (int c = 0; c < NU; ++c) {
@@ -916,6 +985,7 @@ void nrmp_qp_kernel(
           // (keep the scheduler from issuing all 4 NU loads ahead of the arithmetic: that is where the register
           // demand of this kernel peaked, above the 256 a wave may hold at two waves per SIMD)
           if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
         }
       }
       PROF(3);
@@ -1122,6 +1192,26 @@ void nrmp_qp_kernel(
         const int lr = lane < NU ? lane : 0;
         rr *= myinv;                         // b_i / L_ii
         if constexpr (NU <= 20) {
+#if NPA_QP_WAVES >= 3
+          // (three waves per SIMD: row and column of L one after the other through the same registers)
+          {
+            double Lrow[NU];
+#pragma unroll
+            for (int k = 0; k < NU; ++k) Lrow[k] = Km[lr * ldk + k];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < NU; ++k) rr = fma(-Lrow[k], readlane_f64(rr, k), rr);          // -> y
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          {
+            double Lcol[NU];
+#pragma unroll
+            for (int k = 0; k < NU; ++k) Lcol[k] = Km[k * ldk + lr];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = NU - 1; k >= 0; --k) rr = fma(-Lcol[k], readlane_f64(rr, k), rr);     // -> z
+          }
+#else
           double Lrow[NU], Lcol[NU];
 #pragma unroll
           for (int k = 0; k < NU; ++k) Lrow[k] = Km[lr * ldk + k];
@@ -1132,6 +1222,7 @@ void nrmp_qp_kernel(
           for (int k = 0; k < NU; ++k) rr = fma(-Lrow[k], readlane_f64(rr, k), rr);          // -> y
 #pragma unroll
           for (int k = NU - 1; k >= 0; --k) rr = fma(-Lcol[k], readlane_f64(rr, k), rr);     // -> z
+#endif
         } else {                             // (T = 20: 2 x 40 doubles ahead of the chains do not fit the register file)
 #pragma unroll
           for (int k = 0; k < NU; ++k) rr = fma(-Km[lr * ldk + k], readlane_f64(rr, k), rr);
@@ -1435,7 +1526,13 @@ void nrmp_qp_kernel(
 static bool qp_fast_path(int T, int M) { return (T == 10 || T == 20) && M == 10; }
 
 // LDS bytes of one scene; `fast` = the register-resident instantiation (packed H, L and P staging)
-extern "C" size_t npa_qp_shmem_bytes_path(int T, int M, int fast) {
+static bool qp_scan_wide() {
+  static const bool v = getenv("NPA_QP_NOSCAN_WIDE") == nullptr;
+  return v;
+}
+// LDS bytes of one scene; fast = the register-resident instantiation (packed H, L and P staging); scan = its form
+// without a stored Phi (T <= 16, or T <= 32 with the wide scans)
+extern "C" size_t npa_qp_shmem_bytes_path2(int T, int M, int fast, int scan) {
   const bool obs = M > 0;
   size_t nu = 2 * T, ldp = nu + 1, mcd = 8 * T - 4 + 2 * T, mf = obs ? (size_t)T * M : 0, npair = nu * (nu + 1) / 2;
   const size_t mfe = (mf + 1) & ~(size_t)1;
@@ -1443,9 +1540,15 @@ extern "C" size_t npa_qp_shmem_bytes_path(int T, int M, int fast) {
   const bool regrows = fast && M > 0 && M % 2 == 0 && T * M / 2 <= QP_THREADS && 5 * T - 2 <= QP_THREADS;
   const size_t rows = (regrows ? 3 : 6) * mcd + (regrows ? 5 : 9) * mfe;
   const size_t mats = fast ? nu * (nu + 1) / 2 + nu * ldp : (size_t)T * 2 * ldp + 2 * nu * ldp;
-  size_t d = rows + (size_t)T * 3 * ldp + mats + 4 * (T * 3) + T * QP_ABC_LD + (((size_t)T * QP_ST_LD + 1) & ~(size_t)1) + nu + T + (nu + T) + nu + T + nu;
+  const size_t phi = (fast && scan) ? 0 : (size_t)T * 3 * ldp;
+  size_t d = rows + phi + mats + 4 * (T * 3) + T * QP_ABC_LD + (((size_t)T * QP_ST_LD + 1) & ~(size_t)1) + nu + T + (nu + T) + nu + T + nu +
+             ((fast && scan) ? 2 * (size_t)T : 0);
   size_t bytes = d * sizeof(double) + (fast ? 0 : 2 * ((npair + 7) & ~(size_t)7));
   return (bytes + 15) & ~(size_t)15;
+}
+extern "C" size_t npa_qp_shmem_bytes_path(int T, int M, int fast) {
+  const bool scan = fast && (T <= 16 || (T <= 32 && qp_scan_wide()));
+  return npa_qp_shmem_bytes_path2(T, M, fast, scan ? 1 : 0);
 }
 
 extern "C" size_t npa_qp_shmem_bytes(int T, int M) { return npa_qp_shmem_bytes_path(T, M, 0); }
@@ -1462,6 +1565,7 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
   static const bool force_generic = getenv("NPA_QP_GENERIC") != nullptr;     // tests: the generic (LDS) instantiation for every (T, M)
   const bool fast = qp_fast_path(P.T, P.M) && !force_generic;
   const size_t shmem = npa_qp_shmem_bytes_path(P.T, P.M, fast ? 1 : 0);      // one scene (wave) per workgroup, see the kernel
+  // (T = 20 without the wide scans keeps Phi: npa_qp_shmem_bytes_path follows the same switch)
   const int nblocks = batch;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1477,7 +1581,7 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
                         cur_s_out, cur_u_out, cur_d_out, out_s, out_u, out_d, out_min_distance, out_iters,            \
                         out_nrmp_points, flags, state, qp_info, warm, scene0, batch,                                 \
                         QpBackward{nullptr, nullptr, nullptr, nullptr, nullptr, dbg_abc, dbg_f, dbg_x}, trig_out)
-  static const bool scan_wide = getenv("NPA_QP_SCAN_WIDE") != nullptr;
+  const bool scan_wide = qp_scan_wide();
   if (P.T == 10 && P.M == 10 && !force_generic) QP_LAUNCH(10, 10);
   else if (P.T == 20 && P.M == 10 && !force_generic && scan_wide) QP_LAUNCH(20, 10, false, true);
   else if (P.T == 20 && P.M == 10 && !force_generic) QP_LAUNCH(20, 10);
