@@ -79,6 +79,7 @@ def main():
                                                         "timing events (measured: SLOWER than eager launches with 20 chains in "
                                                         "flight, 513 k vs 656 k plans/s, DESIGN.md section 3.4; default: eager)")
     ap.add_argument("--inflight", type=int, default=20, help="independent batches (steps) kept in flight, one stream each")
+    ap.add_argument("--issue-threads", type=int, default=4, help="host threads issuing the steps' launches (0: the main thread alone)")
     ap.add_argument("--workload", default=WORKLOAD,
                     choices=sorted(k for k in __import__("neupan_amd.scenes", fromlist=["CONFIGS"]).CONFIGS),
                     help="scene configuration (default: the one BASELINE.json's metric is quoted on)")
@@ -101,7 +102,7 @@ def main():
 
     # the measured leg imports the product only; tests/ (and with it oracle/) is touched by the cpu_baseline leg alone
     from neupan_amd.pan import PAN
-    from neupan_amd.serve import ControlGatherer, bind_to_gpu_numa_node, run_steps as serve_steps
+    from neupan_amd.serve import ControlGatherer, StepLoop, bind_to_gpu_numa_node, run_steps as serve_steps
     numa = bind_to_gpu_numa_node(local_rank)            # launch thread next to its GPU (one process per GPU)
     from neupan_amd.robot import Robot
     from neupan_amd.scenes import CONFIGS, make_batch
@@ -143,10 +144,12 @@ def main():
     torch.cuda.synchronize(dev)
     gatherer = ControlGatherer(dist, world, device=dev, slots=nfl)
 
+    loop = StepLoop(steps, streams, gatherer, cur, threads=args.issue_threads)
+
     def run_steps(n):
         """n steps (= n forward calls over batches of 256 scenes), `nfl` of them in flight, one stream each: step i is
-        planned by planner i % nfl."""
-        return serve_steps(n, steps, streams, gatherer, cur)
+        planned by planner i % nfl; the launches are issued by --issue-threads host threads (0: this thread alone)."""
+        return loop.run(n)
 
     run_steps(args.warmup)
     torch.cuda.synchronize(dev)
@@ -275,7 +278,7 @@ def main():
                                                         "(PAN.make_step), " + ("eager launches" if not args.graph else
                                                         "HIP-graph replay except on the planners that carry timing events") +
                                                         ", gathers on one communication stream",
-                   "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "numa_node": numa,
+                   "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "numa_node": numa, "issue_threads": loop.threads,
                    "parallelism": f"scene-shard x{world}, RCCL all-gather of controls"
                                   + (" (process group initialised)" if dist is not None else "")},
         "roofline": roof,

@@ -122,6 +122,11 @@ int npa_set_adjust(npa_handle *h, const float q_s[3], float p_u, float eta, floa
  * previous iterate, pan.py:100-105 / 215-243; zero it to reset a scene). */
 size_t npa_workspace_bytes(const npa_handle *h, int batch);
 size_t npa_state_bytes(const npa_handle *h, int batch);
+/* Byte offsets inside the workspace of the arrays a caller may look at BETWEEN npa_forward_iter calls (stream-ordered),
+ * out[0..n), n <= 8: the working nominal cur_s [B][3][T+1], cur_u [B][2][T], cur_d [B][T], and the sorted rows the last
+ * selection launch emitted -- mu [B][T+1][M][E], lam [B][T+1][M][2], pts [B][T+1][M][2], dist [B][T+1][M], count [B][T+1]
+ * (int32): the layout of npa_dune_stage's outputs, so a gradient pass can reuse them instead of re-running the stage. */
+int npa_workspace_layout(const npa_handle *h, int batch, size_t *out, int n);
 /* Byte offset inside the workspace of the per-scene QP diagnostics written by the last NRMP launch
  * of npa_forward_batch: [B][16] doubles (best iteration, merit, mu, status, iterations run, ...). */
 size_t npa_workspace_qp_info_offset(const npa_handle *h, int batch);

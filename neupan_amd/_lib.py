@@ -45,6 +45,7 @@ SYMBOLS = {
     "npa_workspace_bytes": (_SZ, [_P, _I]),
     "npa_state_bytes": (_SZ, [_P, _I]),
     "npa_workspace_qp_info_offset": (_SZ, [_P, _I]),
+    "npa_workspace_layout": (_I, [_P, _I, C.POINTER(C.c_size_t), _I]),
     "npa_forward_batch": (_I, [_P, _I, _I] + [_P] * 13 + [_P, _SZ, _P, _SZ, _P]),
     "npa_forward_begin": (_I, [_P, _I, _I] + [_P] * 13 + [_P, _SZ, _P, _SZ, _P, _I]),
     "npa_forward_batch_flags": (_I, [_P, _I, _I] + [_P] * 13 + [_P, _SZ, _P, _SZ, _P, _I]),

@@ -63,7 +63,24 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 struct EventPair { hipEvent_t a, b; };
 
+// state of a forward call between npa_forward_begin and npa_forward_end (one per handle: a handle plans one batch at a
+// time; different handles are independent and may be driven from different host threads)
+struct PendingCall {
+  bool active = false;
+  int batch = 0, n_stride = 0;
+  const float *ref_s = nullptr, *ref_us = nullptr, *points = nullptr, *velocities = nullptr;
+  const int32_t* n_points = nullptr;
+  float *out_s = nullptr, *out_u = nullptr, *out_d = nullptr, *out_md = nullptr, *out_np = nullptr;
+  int32_t* out_iters = nullptr;
+  float* ws = nullptr;
+  float* state = nullptr;
+  hipStream_t stream = nullptr;
+  bool dune = false;
+};
+
 struct npa_handle {
+  PendingCall pc;
+  std::mutex mu;              // guards pc (two threads on ONE handle are a caller's bug; this makes it an error, not a race)
   DevParams P;
   float* wpack = nullptr;     // device
   int device = 0;
@@ -558,6 +575,13 @@ extern "C" size_t npa_workspace_qp_info_offset(const npa_handle* h, int batch) {
   if (!h || batch < 1) return 0;
   return npa_scratch_layout(batch, h->P.T, mdim(h->P), h->P.E, kstride(h)).qp_info * sizeof(float);
 }
+extern "C" int npa_workspace_layout(const npa_handle* h, int batch, size_t* out, int n) {
+  if (!h || batch < 1 || !out || n < 1) return fail(NPA_E_ARG, "npa_workspace_layout: bad argument");
+  const ScratchLayout L = npa_scratch_layout(batch, h->P.T, mdim(h->P), h->P.E, kstride(h));
+  const size_t v[8] = {L.cur_s * 4, L.cur_u * 4, L.cur_d * 4, L.mu * 4, L.lam * 4, L.pts * 4, L.dist * 4, L.count * 4};
+  for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
+  return NPA_OK;
+}
 extern "C" size_t npa_state_bytes(const npa_handle* h, int batch) {
   if (!h || batch < 1) return 0;
   return (size_t)batch * npa_state_floats(h->P.T, mdim(h->P), h->P.E) * sizeof(float);
@@ -723,27 +747,6 @@ __global__ void stage_kernel(float* __restrict__ cur_s, const float* __restrict_
 // streams (one handle each; neupan_amd.pan.forward_interleaved, bench.py): every kernel here is latency bound, and
 // the waves of one batch fill the SIMDs the others leave idle.  The split into begin / iter / end exists for the
 // callers that look at the working nominal between iterations (PAN.forward_batch_trace, the gradient chain).
-struct PendingCall {
-  bool active = false;
-  int batch = 0, n_stride = 0;
-  const float *ref_s = nullptr, *ref_us = nullptr, *points = nullptr, *velocities = nullptr;
-  const int32_t* n_points = nullptr;
-  float *out_s = nullptr, *out_u = nullptr, *out_d = nullptr, *out_md = nullptr, *out_np = nullptr;
-  int32_t* out_iters = nullptr;
-  float* ws = nullptr;
-  float* state = nullptr;
-  hipStream_t stream = nullptr;
-  bool dune = false;
-};
-static std::mutex g_pending_mu;
-static std::vector<std::pair<npa_handle*, PendingCall>> g_pending;
-static PendingCall* pending_of(npa_handle* h, bool create) {
-  for (auto& p : g_pending) if (p.first == h) return &p.second;
-  if (!create) return nullptr;
-  g_pending.emplace_back(h, PendingCall());
-  return &g_pending.back().second;
-}
-
 // Network keys only.  Single fp16 products make the key launch ~25 % cheaper but put more points inside
 // select_kernel's margin; when they do not fit the final ranking the slice re-encodes them exactly, ~3 key-tile units
 // per tile.  Every 8 forward calls compare the two: if the re-encoded tiles cost more than the saving, use the split
@@ -785,8 +788,8 @@ extern "C" int npa_forward_begin(npa_handle* h, int batch, int n_stride, const f
   if (points && n_stride < 1) return fail(NPA_E_ARG, "n_stride < 1");
   if (points && (n_stride < P.dune_max_num ? n_stride : P.dune_max_num) > P.key_stride)
     return fail(NPA_E_UNSUPPORTED, "more than 32768 points per scene after decimation");
-  std::lock_guard<std::mutex> lock(g_pending_mu);
-  PendingCall* pc = pending_of(h, true);
+  std::lock_guard<std::mutex> lock(h->mu);
+  PendingCall* pc = &h->pc;
   if (pc->active) return fail(NPA_E_ARG, "npa_forward_begin: previous forward on this handle not ended");
   hipStream_t stream = (hipStream_t)stream_;
   const int T = P.T;
@@ -817,9 +820,9 @@ extern "C" int npa_forward_begin(npa_handle* h, int batch, int n_stride, const f
 
 extern "C" int npa_forward_iter(npa_handle* h, int k) {
   if (!h) return fail(NPA_E_ARG, "npa_forward_iter: null handle");
-  std::lock_guard<std::mutex> lock(g_pending_mu);
-  PendingCall* pc = pending_of(h, false);
-  if (!pc || !pc->active) return fail(NPA_E_ARG, "npa_forward_iter: no forward in progress on this handle");
+  std::lock_guard<std::mutex> lock(h->mu);
+  PendingCall* pc = &h->pc;
+  if (!pc->active) return fail(NPA_E_ARG, "npa_forward_iter: no forward in progress on this handle");
   const DevParams& P = h->P;
   if (k < 0 || k >= P.K) return fail(NPA_E_ARG, "npa_forward_iter: iteration index out of range");
   const int T = P.T, batch = pc->batch;
@@ -867,9 +870,9 @@ extern "C" int npa_forward_iter(npa_handle* h, int k) {
 
 extern "C" int npa_forward_end(npa_handle* h) {
   if (!h) return fail(NPA_E_ARG, "npa_forward_end: null handle");
-  std::lock_guard<std::mutex> lock(g_pending_mu);
-  PendingCall* pc = pending_of(h, false);
-  if (!pc || !pc->active) return fail(NPA_E_ARG, "npa_forward_end: no forward in progress on this handle");
+  std::lock_guard<std::mutex> lock(h->mu);
+  PendingCall* pc = &h->pc;
+  if (!pc->active) return fail(NPA_E_ARG, "npa_forward_end: no forward in progress on this handle");
   pc->active = false;
   return NPA_OK;
 }
@@ -1095,8 +1098,4 @@ static int npa_self_test(npa_handle* h) {
   return NPA_OK;
 }
 
-static void drop_pending(npa_handle* h) {
-  std::lock_guard<std::mutex> lock(g_pending_mu);
-  for (size_t i = 0; i < g_pending.size(); ++i)
-    if (g_pending[i].first == h) { g_pending.erase(g_pending.begin() + i); break; }
-}
+static void drop_pending(npa_handle* h) { (void)h; }

@@ -323,6 +323,22 @@ class PAN(torch.nn.Module):
                           nrmp_points=out_np, used_points=use_pts, hold=(nom_s, nom_u, ref_s, ref_us))
         self._pending = dict(opt_s=out_s, opt_u=out_u, opt_d=out_d, min_distance=out_md, iters=out_it, nrmp_points=out_np)
 
+    def _workspace_views(self):
+        """Views into the workspace of the batch in progress: dict(cur_s, cur_u, mu, lam, pts, dist, count) (stream-ordered)."""
+        B, T, M, E = self._B, self.T, max(self.nrmp_max_num, 1), self.E
+        off = (C.c_size_t * 8)()
+        check(self._lib.npa_workspace_layout(self._h, B, off, 8), "npa_workspace_layout")
+        ws = self._ws
+
+        def view(i, n, dtype, shape):
+            return ws[off[i]:off[i] + 4 * n].view(dtype).reshape(shape)
+        return dict(cur_s=view(0, B * 3 * (T + 1), torch.float32, (B, 3, T + 1)), cur_u=view(1, B * 2 * T, torch.float32, (B, 2, T)),
+                    mu=view(3, B * (T + 1) * M * E, torch.float32, (B, T + 1, M, E)),
+                    lam=view(4, B * (T + 1) * M * 2, torch.float32, (B, T + 1, M, 2)),
+                    pts=view(5, B * (T + 1) * M * 2, torch.float32, (B, T + 1, M, 2)),
+                    dist=view(6, B * (T + 1) * M, torch.float32, (B, T + 1, M)),
+                    count=view(7, B * (T + 1), torch.int32, (B, T + 1)))
+
     def forward_iter(self, k):
         """Enqueue PAN iteration k (selection + QP launches) of the forward started by forward_begin."""
         with torch.cuda.device(self.device):       # the launches must see the device of the handle
@@ -657,10 +673,16 @@ class _PanGrad(torch.autograd.Function):
         off_u = (n_s + 3) // 4 * 4
         first = 0 if getattr(pan, "recurrent", True) else pan.iter_num - 1
         snaps = []
+        use_rows = (not pan.no_obs) and points is not None
+        vw = pan._workspace_views() if use_rows else None
         for k in range(pan.iter_num):
             if k >= first:
-                snaps.append((k, wsf[:n_s].clone().reshape(B, 3, T + 1), wsf[off_u:off_u + B * 2 * T].clone().reshape(B, 2, T)))
+                snaps.append([k, wsf[:n_s].clone().reshape(B, 3, T + 1), wsf[off_u:off_u + B * 2 * T].clone().reshape(B, 2, T), None])
             pan.forward_iter(k)
+            if k >= first and use_rows:
+                # the sorted rows THIS iteration's QP was built from: the backward pass re-solves it from them instead of
+                # re-running the DUNE stage (slice 0 is only refreshed in iteration 0 and stays valid: the QP never reads it)
+                snaps[-1][3] = {key: vw[key].clone() for key in ("mu", "lam", "pts", "count")}
         out = pan.forward_end()
         ctx.pan = pan
         ctx.snaps = snaps
@@ -680,13 +702,10 @@ class _PanGrad(torch.autograd.Function):
         gu = torch.zeros((B, 2, T), device=dev) if gu is None else gu.contiguous()
         gd = None if (gd is None or ctx.no_obs) else gd.contiguous()
         tot = torch.zeros((B, 7), dtype=torch.float64, device=dev)
-        for k, snap_s, snap_u in reversed(ctx.snaps):
+        for k, snap_s, snap_u, stage in reversed(ctx.snaps):
             ran = ctx.iters > k                        # scenes whose stop test ended the loop earlier skip this solve
             if not bool(ran.any()):
                 continue
-            stage = None
-            if not pan.no_obs and points is not None:
-                stage = pan.dune_stage(snap_s, points, velocities, n_points)
             r = pan.nrmp_backward(snap_s, snap_u, ref_s, ref_us, stage, gs, gu, gd)
             tot += torch.where(ran[:, None], r["grad"][:, :7].double(), torch.zeros_like(tot))
             m = ran[:, None, None]

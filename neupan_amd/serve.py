@@ -76,6 +76,78 @@ def run_steps(n: int, steps, streams=None, gatherer: ControlGatherer | None = No
     return last
 
 
+class StepLoop:
+    """run_steps with the launches issued from several host threads: slot j (one planner, one stream) belongs to thread
+    j % threads, which issues that slot's steps in order (a handle plans one batch at a time); the main thread hands every
+    step's controls to the gatherer in step order.  One Python thread needs ~5 us per kernel launch -- 0.11 ms for the 21
+    launches of a step -- which is what a short timed region mostly measures; the library call releases the GIL, so the
+    launches of different planners proceed in parallel.  threads = 0: plain run_steps."""
+
+    def __init__(self, steps, streams, gatherer=None, cur=None, threads=0):
+        import queue
+        import threading
+        self.steps, self.streams, self.gatherer, self.cur = steps, streams, gatherer, cur
+        self.nfl = len(steps)
+        self.threads = min(int(threads), self.nfl) if streams is not None else 0
+        self._q = [queue.Queue() for _ in range(self.threads)]
+        self._workers = []
+        self._err = None
+        for w in range(self.threads):
+            t = threading.Thread(target=self._work, args=(w,), daemon=True)
+            t.start()
+            self._workers.append(t)
+
+    def _work(self, w):
+        while True:
+            cmd = self._q[w].get()
+            if cmd is None:
+                return
+            n, outs, evs = cmd
+            try:
+                for i in range(n):
+                    j = i % self.nfl
+                    if j % self.threads != w:
+                        continue
+                    with torch.cuda.stream(self.streams[j]):
+                        outs[i] = self.steps[j]()
+                    evs[i].set()
+            except BaseException as e:      # surface it in run(); unblock the main thread
+                self._err = e
+                for ev in evs:
+                    ev.set()
+
+    def run(self, n):
+        if self.threads == 0:
+            return run_steps(n, self.steps, self.streams, self.gatherer, self.cur)
+        import threading
+        last = [None] * self.nfl
+        for st in self.streams:
+            st.wait_stream(self.cur)
+        outs, evs = [None] * n, [threading.Event() for _ in range(n)]
+        for q in self._q:
+            q.put((n, outs, evs))
+        for i in range(n):
+            evs[i].wait()
+            if self._err is not None:
+                raise self._err
+            j = i % self.nfl
+            o = outs[i]
+            g = self.gatherer.gather(o["opt_u"], j, self.streams[j]) if self.gatherer is not None else o["opt_u"]
+            last[j] = (o, g)
+        for st in self.streams:
+            self.cur.wait_stream(st)
+        if self.gatherer is not None:
+            self.gatherer.join(self.cur)
+        return last
+
+    def close(self):
+        for q in self._q:
+            q.put(None)
+        for t in self._workers:
+            t.join(timeout=5)
+        self._workers = []
+
+
 def bind_to_gpu_numa_node(device_index: int):
     """Pin this process to the CPUs of the NUMA node its GPU hangs off (one process per GPU: the launch thread and the
     pinned buffers should not sit across the socket).  Best effort: returns the node or None."""

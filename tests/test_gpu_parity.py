@@ -701,3 +701,43 @@ def test_coarse_calibration_grids(grid):
         if a["violations"] > 0 or km["key_terms"] != 4:
             assert np.array_equal(second[k], e[k]), (k, km, rep, a)
     print("coarse grid", grid, km, rep, a, "first launch equals exact:", all(np.array_equal(first[k], e[k]) for k in ("mu", "lam", "pts", "dist")))
+
+
+def test_prepared_step_and_threaded_issue_equal_forward_batch():
+    """PAN.make_step (arguments converted once, ONE library call per step, reused output tensors; optionally a HIP-graph
+    replay) and neupan_amd.serve.StepLoop (the steps' launches issued by several host threads, one stream per planner)
+    plan exactly what forward_batch plans: bitwise equal controls, on every repetition."""
+    import torch
+    from gpu_helpers import make_gpu_pan
+    from neupan_amd.serve import StepLoop
+    cfg = CONFIGS["diff_1k_T10_K10"]
+    nfl, B = 6, 32
+    batches = [make_batch(cfg, 8000 + 100 * j, B) for j in range(nfl)]
+    keys = ("nom_s", "nom_u", "ref_s", "ref_us", "points")
+    ref = []
+    for bt in batches:
+        p = make_gpu_pan(cfg)
+        ref.append(p.forward_batch(*[bt[k] for k in keys])["opt_u"].cpu().numpy())
+    dev = torch.device("cuda", 0)
+    pans = [make_gpu_pan(cfg) for _ in range(nfl)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
+    args = [[torch.from_numpy(bt[k]).to(dev) for k in keys] for bt in batches]
+    torch.cuda.synchronize()
+    steps = []
+    for j in range(nfl):
+        with torch.cuda.stream(streams[j]):
+            steps.append(pans[j].make_step(*args[j], reset_state=True, graph=(j == 1)))
+    torch.cuda.synchronize()
+    cur = torch.cuda.current_stream(dev)
+    for threads in (0, 3):
+        loop = StepLoop(steps, streams, None, cur, threads=threads)
+        for n in (nfl, 3 * nfl + 2):
+            last = loop.run(n)
+            torch.cuda.synchronize()
+            for j in range(nfl):
+                o, g = last[j]
+                assert np.array_equal(o["opt_u"].cpu().numpy(), ref[j]), (threads, n, j)
+                assert (o["iters"].cpu().numpy() == cfg.iter_num).all()
+        loop.close()
+    # the attributes of the planner follow the prepared step as they follow forward_batch
+    assert np.isfinite(float(pans[0].min_distance[0])) and pans[0].audit()["violations"] == 0
