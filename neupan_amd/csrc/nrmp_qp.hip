@@ -153,6 +153,12 @@ __device__ __forceinline__ double scan_next(double v, int lane) {
   }
   return x;
 }
+// a wave-uniform double made provably uniform (both halves through v_readfirstlane): the compiler may then keep it in a
+// scalar register pair -- and, when it runs short of those, park it in a lane of a spill VGPR (v_readlane to fetch it)
+// instead of sending a whole vector register to scratch memory
+__device__ __forceinline__ double uni64(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 struct OpSum { __device__ static double f(double a, double b) { return a + b; } };
 struct OpMax { __device__ static double f(double a, double b) { return fmax(a, b); } };
 struct OpMin { __device__ static double f(double a, double b) { return fmin(a, b); } };
@@ -278,8 +284,8 @@ void nrmp_qp_kernel(
   const int mf = obs ? T * M : 0;
   const int ldp = nu + 1, ldk = nu + 1;       // odd leading dimensions
   const int npair = nu * (nu + 1) / 2;
-  const double ro = P.ro_obs, iro = 1.0 / ro;
-  const double dmin0 = fmax((double)P.d_min, 0.0), dmaxv = (double)P.d_max;
+  const double ro = P.ro_obs, iro = uni64(1.0 / ro);
+  const double dmin0 = uni64(fmax((double)P.d_min, 0.0)), dmaxv = uni64((double)P.d_max);
   // T = 10, M = 10: each lane owns ONE pair of hinge rows (lanes < T M / 2 = 50) and ONE pair of u / d rows (lanes <
   // 5T - 2 = 48) in every phase, so the per-row arrays that only their owner touches -- slacks, residuals, multiplier
   // directions, the hinge offsets -- live in registers, not in LDS (7 arrays, 5.5 KB of the scene's 26 KB: the LDS
@@ -463,10 +469,10 @@ void nrmp_qp_kernel(
 
   // ---- cost: H (constant block), state-cost gradient at u=0 ---------------------------------
   const double m2 = (P.kin == 2) ? 0.0 : 1.0;            // omni: theta row not in the state cost
-  const double W0 = 2.0 * (double)P.q_s[0] * (double)P.q_s[0] + P.bk;
-  const double W1 = 2.0 * (double)P.q_s[1] * (double)P.q_s[1] + P.bk;
-  const double W2 = 2.0 * m2 * (double)P.q_s[2] * (double)P.q_s[2] + P.bk;
-  const double pu = P.p_u;
+  const double W0 = uni64(2.0 * (double)P.q_s[0] * (double)P.q_s[0] + P.bk);
+  const double W1 = uni64(2.0 * (double)P.q_s[1] * (double)P.q_s[1] + P.bk);
+  const double W2 = uni64(2.0 * m2 * (double)P.q_s[2] * (double)P.q_s[2] + P.bk);
+  const double pu = uni64((double)P.p_u);
   if constexpr (SCAN) {
     // the state cost's Hessian Phi' W Phi is not formed: W joins S'_t in the P_t blocks of every iteration (K' build), and the
     // packed triangle only carries the band terms of C_u' D C_u (+ 2 p_u^2 on the speed diagonal), zero elsewhere
@@ -534,7 +540,7 @@ void nrmp_qp_kernel(
   }
 
   // ---- starting point: u = 0, d mid-range, unit multipliers, slacks >= 1 --------------------
-  const double d0 = 0.5 * (dmin0 + dmaxv);
+  const double d0 = uni64(0.5 * (dmin0 + dmaxv));
   double cmax = fmax(fabs(dmaxv), fabs(dmin0));
   double m_act = 0;
   for (int p = lane; p < npu; p += QP_THREADS) {
@@ -570,9 +576,9 @@ void nrmp_qp_kernel(
     gmax = fmax(gmax, fabs(acc));
   }
   // (the merit divides the residuals by these scales: reciprocals once, no fp64 division inside the loop)
-  const double iscale_d = 1.0 / (1.0 + wave_reduce<OpMax>(gmax)), iscale_p = 1.0 / (1.0 + wave_reduce<OpMax>(cmax));
+  const double iscale_d = uni64(1.0 / (1.0 + wave_reduce<OpMax>(gmax))), iscale_p = uni64(1.0 / (1.0 + wave_reduce<OpMax>(cmax)));
   const double m_tot = fmax(wave_reduce<OpSum>(m_act) + (double)mf + (obs ? 2.0 * T : 0.0), 1.0);
-  const double inv_m = 1.0 / m_tot;
+  const double inv_m = uni64(1.0 / m_tot);
   const double pub = (lane < nu && !(lane & 1)) ? -2.0 * pu * (double)__fmul_rn(P.p_u, rus[lane >> 1]) : 0.0;
   LSYNC();
   if constexpr (SCAN) {
@@ -801,15 +807,22 @@ void nrmp_qp_kernel(
       if constexpr (HPAIR) {
         // all 4 M values of the step on their way (128-bit loads) before the sums start: the lanes that do this are few
         // and the loop was a chain of load -> wait -> 12 flops per row
-        double2 l2[MM / 2], p0[MM / 2], p1[MM / 2], iw2[MM / 2];
+        // (NPA_QP_WAVES >= 3: in batches of two pairs -- 32 registers in flight instead of 80)
+        constexpr int HB = NPA_QP_WAVES >= 3 ? 2 : MM / 2;
 #pragma unroll
-        for (int j = 0; j < MM / 2; ++j) {
-          const int i = t * MM + 2 * j;
-          l2[j] = ld2(lf + i); p0[j] = ld2(fa0 + i); p1[j] = ld2(fa1 + i); iw2[j] = ld2(iwf + i);
+        for (int j0 = 0; j0 < MM / 2; j0 += HB) {
+          double2 l2[HB], p0[HB], p1[HB], iw2[HB];
+#pragma unroll
+          for (int j = 0; j < HB; ++j) {
+            const int i = t * MM + 2 * (j0 + j < MM / 2 ? j0 + j : 0);
+            l2[j] = ld2(lf + i); p0[j] = ld2(fa0 + i); p1[j] = ld2(fa1 + i); iw2[j] = ld2(iwf + i);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < HB; ++j)
+            if (j0 + j < MM / 2) { acc(l2[j].x, p0[j].x, p1[j].x, iw2[j].x); acc(l2[j].y, p0[j].y, p1[j].y, iw2[j].y); }
+          if constexpr (HB < MM / 2) __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < MM / 2; ++j) { acc(l2[j].x, p0[j].x, p1[j].x, iw2[j].x); acc(l2[j].y, p0[j].y, p1[j].y, iw2[j].y); }
       } else {
 #pragma unroll 5
         for (int j = 0; j < M; ++j) { const int i = t * M + j; acc(lf[i], fa0[i], fa1[i], iwf[i]); }
@@ -1023,6 +1036,9 @@ void nrmp_qp_kernel(
             const double2 lj = ld2(dxu + j0);
             if (j0 >= k + 2) arow[j0] = fma(-l, lj.x, arow[j0]);
             if (j0 + 1 < NU) arow[j0 + 1] = fma(-l, lj.y, arow[j0 + 1]);
+#if NPA_QP_WAVES >= 3
+            if ((j0 & 7) == 6) __builtin_amdgcn_sched_barrier(0);        // at most four 128-bit loads in flight
+#endif
           }
         }
       }
@@ -1157,14 +1173,23 @@ void nrmp_qp_kernel(
       for (int t = lane; t < T; t += QP_THREADS) {
         double z0 = 0, z1 = 0, zs = 0;
         if constexpr (HPAIR) {
-          double2 w2[MM / 2], p0[MM / 2], p1[MM / 2];
+          constexpr int HB = NPA_QP_WAVES >= 3 ? 2 : MM / 2;
 #pragma unroll
-          for (int j = 0; j < MM / 2; ++j) { const int i = t * MM + 2 * j; w2[j] = ld2(dwf + i); p0[j] = ld2(fa0 + i); p1[j] = ld2(fa1 + i); }
-          __builtin_amdgcn_sched_barrier(0);
+          for (int j0 = 0; j0 < MM / 2; j0 += HB) {
+            double2 w2[HB], p0[HB], p1[HB];
 #pragma unroll
-          for (int j = 0; j < MM / 2; ++j) {
-            z0 += w2[j].x * p0[j].x; z1 += w2[j].x * p1[j].x; zs += w2[j].x;
-            z0 += w2[j].y * p0[j].y; z1 += w2[j].y * p1[j].y; zs += w2[j].y;
+            for (int j = 0; j < HB; ++j) {
+              const int i = t * MM + 2 * (j0 + j < MM / 2 ? j0 + j : 0);
+              w2[j] = ld2(dwf + i); p0[j] = ld2(fa0 + i); p1[j] = ld2(fa1 + i);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < HB; ++j)
+              if (j0 + j < MM / 2) {
+                z0 += w2[j].x * p0[j].x; z1 += w2[j].x * p1[j].x; zs += w2[j].x;
+                z0 += w2[j].y * p0[j].y; z1 += w2[j].y * p1[j].y; zs += w2[j].y;
+              }
+            if constexpr (HB < MM / 2) __builtin_amdgcn_sched_barrier(0);
           }
         } else {
 #pragma unroll 5
