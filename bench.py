@@ -137,12 +137,13 @@ def main():
     # Planners that carry timing events: every 4th (events ride on the dispatches).  --graph: the others replay a HIP graph
     # of the same launches (measured slower, kept for the record).
     timed_idx = set(range(0, nfl, 4)) if nfl >= 4 else set(range(nfl))
+    gatherer = ControlGatherer(dist, world, device=dev, slots=nfl, shape=(BATCH, 2, T))
     steps = []
     for j in range(nfl):
         with torch.cuda.stream(streams[j]):
-            steps.append(pans[j].make_step(*args_dev[j], reset_state=True, graph=(args.graph and j not in timed_idx)))
+            steps.append(pans[j].make_step(*args_dev[j], reset_state=True, graph=(args.graph and j not in timed_idx),
+                                           out_u=gatherer.buffer(j)))
     torch.cuda.synchronize(dev)
-    gatherer = ControlGatherer(dist, world, device=dev, slots=nfl)
 
     loop = StepLoop(steps, streams, gatherer, cur, threads=args.issue_threads)
 
@@ -183,7 +184,7 @@ def main():
     out, gathered = last[0]
     for o, g in (x for x in last if x is not None):
         assert (o["iters"].cpu().numpy() == K).all(), "every scene must run exactly K PAN iterations inside the timed region"
-        assert g.shape[0] == world * BATCH
+        assert g.numel() == world * BATCH * 2 * T
 
     plans = BATCH * world * args.steps
     value = plans / elapsed
@@ -280,7 +281,8 @@ def main():
                                                         ", gathers on one communication stream",
                    "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "numa_node": numa, "issue_threads": loop.threads,
                    "parallelism": f"scene-shard x{world}, RCCL all-gather of controls"
-                                  + (" (process group initialised)" if dist is not None else "")},
+                                  + (f" (process group initialised; {gatherer.collectives} collectives for {gatherer.issued} steps: "
+                                     f"one per {nfl} steps, all inside the timed loop)" if dist is not None else "")},
         "roofline": roof,
         # host time to enqueue a step (one library call = 21 launches, one Python thread) next to the step's wall time: when
         # the two are close the step is bound by the host's launch rate, not by the kernels

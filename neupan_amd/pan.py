@@ -270,7 +270,8 @@ class PAN(torch.nn.Module):
         return t
 
     # ------------------------------------------------------------------ batched entry
-    def forward_begin(self, nom_s, nom_u, ref_s, ref_us, points=None, velocities=None, n_points=None, reset_state=False):
+    def forward_begin(self, nom_s, nom_u, ref_s, ref_us, points=None, velocities=None, n_points=None, reset_state=False,
+                      out_u=None):
         """Stage one batch (see forward_batch for shapes) and start a forward on the current stream: follow with
         forward_iter(k) for k in range(iter_num) and forward_end()."""
         if self._untrained:
@@ -303,7 +304,10 @@ class PAN(torch.nn.Module):
         ws, state = self._get_buffers(B)
         dev = self.device
         out_s = torch.empty((B, 3, T + 1), dtype=torch.float32, device=dev)
-        out_u = torch.empty((B, 2, T), dtype=torch.float32, device=dev)
+        if out_u is None:
+            out_u = torch.empty((B, 2, T), dtype=torch.float32, device=dev)
+        elif tuple(out_u.shape) != (B, 2, T) or out_u.dtype != torch.float32 or not out_u.is_contiguous() or out_u.device != dev:
+            raise ValueError("out_u must be a contiguous float32 tensor of shape (B, 2, T) on the planner's device")
         out_d = torch.empty((B, 1, max(T, 1)), dtype=torch.float32, device=dev) if M > 0 and self.dune_max_num > 0 else None
         out_md = torch.empty((B,), dtype=torch.float32, device=dev)
         # every scene's QP writes these in PAN iteration 0 at the latest: no fill kernels needed
@@ -377,17 +381,18 @@ class PAN(torch.nn.Module):
         return out
 
     def make_step(self, nom_s, nom_u, ref_s, ref_us, points=None, velocities=None, n_points=None, reset_state=False,
-                  graph=False):
+                  graph=False, out_u=None):
         """Serving-loop form of forward_batch: validate and convert the arguments ONCE and return `step()`, which plans
         the batch with ONE library call (npa_forward_batch_flags) on the current stream and returns the same dict of
         output tensors every time -- they are allocated here and REUSED (forward_batch returns fresh tensors per call,
         like the reference; a loop that owns its buffers does not need that, and the per-call conversions, allocations and
         a dozen ctypes calls were a third of a step's wall time).  The input tensors are read in place at every step():
-        refresh them with copy_() between steps.
+        refresh them with copy_() between steps.  out_u: a caller-owned (B, 2, T) tensor the controls are written to (e.g. a
+        slot of a gather staging buffer, neupan_amd.serve.ControlGatherer).
         graph=True: the step's launches (staging + K x {selection, QP}) are recorded once into a HIP graph and step()
         replays it: one graph launch instead of 1 + 2K kernel launches on the host (the kernels, their order and their
         results are the same; the per-launch profiling events of profile() do not exist inside a graph)."""
-        self.forward_begin(nom_s, nom_u, ref_s, ref_us, points, velocities, n_points, reset_state=reset_state)
+        self.forward_begin(nom_s, nom_u, ref_s, ref_us, points, velocities, n_points, reset_state=reset_state, out_u=out_u)
         for k in range(self.iter_num):               # (the first step also runs here: buffers and the handle are warm)
             self.forward_iter(k)
         out = self.forward_end()

@@ -143,3 +143,40 @@ def test_serving_loop_schedule_with_two_ranks(inflight, n_steps):
         shape, firsts = row
         assert shape == (2 * 4, 2, 10)
         assert firsts == [float(1000 * r + 10 * j + ran) for r in range(2)]
+
+
+@pytest.mark.gpu
+def test_coalesced_gather_over_rccl_on_one_gpu():
+    """ControlGatherer on the GPU: the slots' controls sit in one staging buffer and cross the fabric with ONE
+    all_gather_into_tensor per `slots` steps (plus one for a trailing partial group at join()).  A process group of one
+    rank over RCCL exercises the production branch; the gathered rows must be the latest controls of every slot."""
+    import torch.distributed as dist
+    from neupan_amd.serve import ControlGatherer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        slots, B, T = 3, 8, 10
+        g = ControlGatherer(dist, 1, device=dev, slots=slots, shape=(B, 2, T))
+        streams = [torch.cuda.Stream(device=dev) for _ in range(slots)]
+        views = [None] * slots
+        for i in range(7):                       # 2 full groups + 1 trailing step
+            j = i % slots
+            with torch.cuda.stream(streams[j]):
+                g.buffer(j).fill_(float(100 * i + j))       # "the planner" writes its controls into its staging row
+            views[j] = g.gather(g.buffer(j), j, streams[j])
+        g.join()
+        torch.cuda.synchronize()
+        assert g.issued == 7 and g.collectives == 3
+        want = [600.0, 401.0, 502.0]             # the last step of every slot
+        for j in range(slots):
+            assert tuple(views[j].shape) == (1, B, 2, T)
+            assert torch.all(views[j] == want[j]), (j, float(views[j].flatten()[0]))
+        # a tensor that does not live in the staging buffer is copied in behind its producer
+        other = torch.full((B, 2, T), 7.0, device=dev)
+        v = g.gather(other, 1, torch.cuda.current_stream(dev))
+        g.join(); torch.cuda.synchronize()
+        assert torch.all(v == 7.0)
+    finally:
+        dist.destroy_process_group()
