@@ -141,8 +141,7 @@ def main():
     steps = []
     for j in range(nfl):
         with torch.cuda.stream(streams[j]):
-            steps.append(pans[j].make_step(*args_dev[j], reset_state=True, graph=(args.graph and j not in timed_idx),
-                                           out_u=gatherer.buffer(j)))
+            steps.append(pans[j].make_step(*args_dev[j], reset_state=True, graph=(args.graph and j not in timed_idx)))
     torch.cuda.synchronize(dev)
 
     loop = StepLoop(steps, streams, gatherer, cur, threads=args.issue_threads)

@@ -20,68 +20,98 @@ from .dist import gather_controls
 class ControlGatherer:
     """All-gather of the steps' controls behind their work, on a stream of its own (or inline on CPU).
 
-    On a GPU the gathers are COALESCED: every slot (batch in flight) writes its controls into its row of one staging
-    buffer [slots][B][2][T] (hand `buffer(slot)` to PAN.make_step(out_u=...)), and one all_gather_into_tensor moves the
-    whole buffer once per `slots` steps -- every step's controls still cross the fabric inside the loop, in 1/slots as many
-    collectives (a collective per step from 20 chains cost 25 % of the throughput with ONE rank: 504 k vs 668 k plans/s)."""
+    On a GPU the gathers are COALESCED: behind every step its controls are copied (on the step's own stream, so the next
+    step of that planner cannot overtake the copy) into that slot's row of a staging buffer [slots][B][2][T], and ONE
+    all_gather_into_tensor per `slots` steps moves the buffer -- every step's controls still cross the fabric inside the
+    loop, in 1/slots as many collectives (a collective per step from 20 chains cost 25 % of the throughput with ONE rank:
+    504 k vs 668 k plans/s).  Two staging / result buffers alternate by group, and a row is rewritten only after the
+    gather that read it two groups earlier has completed (an event wait that has practically always passed).
+    after_step() is called by whoever issues the step (possibly a worker thread), gather() by one thread in step order:
+    the collectives are issued in the same order on every rank."""
 
     def __init__(self, dist=None, world: int = 1, device=None, slots: int = 1, shape=None):
         self.dist, self.world, self.slots = dist, world, slots
         self.active = dist is not None and dist.is_initialized()
         self.cuda = device is not None and torch.device(device).type == "cuda"
         self.comm = torch.cuda.Stream(device=device) if (self.active and self.cuda) else None
-        self.events = [torch.cuda.Event() for _ in range(slots)] if self.comm is not None else None
         self.issued = 0              # gather() calls
         self.collectives = 0         # collectives actually issued
-        self.pending = 0
-        self.stage = self.out = None
-        if self.comm is not None and shape is not None:
-            self.stage = torch.empty((slots,) + tuple(shape), dtype=torch.float32, device=device)
-            self.out = torch.empty((world, slots) + tuple(shape), dtype=torch.float32, device=device)
+        self.coalesce = self.comm is not None and shape is not None
+        if self.coalesce:
+            self.stage = [torch.empty((slots,) + tuple(shape), dtype=torch.float32, device=device) for _ in range(2)]
+            self.out = [torch.empty((world, slots) + tuple(shape), dtype=torch.float32, device=device) for _ in range(2)]
+            self.copied = [[torch.cuda.Event() for _ in range(slots)] for _ in range(2)]
+            self.flushed = [None, None]          # event behind the last all-gather that read stage[parity]
+            self.group_of = [0] * slots          # how many steps each slot has staged
+            self.gathered_of = [0] * slots
+            self.pending = [0, 0]
+        elif self.comm is not None:
+            self.events = [torch.cuda.Event() for _ in range(slots)]
 
-    def buffer(self, slot: int):
-        """Row `slot` of the staging buffer (None when the gathers are not coalesced): where that slot's planner should
-        write its controls."""
-        return None if self.stage is None else self.stage[slot]
-
-    def _flush(self):
-        with torch.cuda.stream(self.comm):
-            self.dist.all_gather_into_tensor(self.out.view(-1), self.stage.view(-1))
-        self.collectives += 1
-        self.pending = 0
+    def after_step(self, opt_u: torch.Tensor, slot: int, stream=None):
+        """Stage a finished step's controls (call right after issuing the step, on the thread that issued it; `stream` = the
+        step's stream, default the current one)."""
+        if not self.coalesce:
+            return
+        st = stream if stream is not None else torch.cuda.current_stream(opt_u.device)
+        par = self.group_of[slot] & 1
+        # (an issuing thread that runs ahead: the row's previous occupant -- two steps of this slot ago -- must have been
+        # handed to the gather, or its flush event does not exist yet)
+        while self.gathered_of[slot] < self.group_of[slot] - 1:
+            import time
+            time.sleep(0)
+        fl = self.flushed[par]
+        with torch.cuda.stream(st):
+            if fl is not None:
+                st.wait_event(fl)                # the gather that read this row two groups ago
+            self.stage[par][slot].copy_(opt_u, non_blocking=True)
+            self.copied[par][slot].record(st)
+        self.group_of[slot] += 1
 
     def gather(self, opt_u: torch.Tensor, slot: int = 0, producer=None):
-        """`opt_u` was produced on stream `producer` (None: the current stream / CPU).  Returns the gathered controls of
-        that step, (world x B, 2, T) or a (world, B, 2, T) view of the coalesced buffer -- valid on the comm stream once the
-        slot's group has been gathered (join() makes everything valid on the current stream)."""
+        """Hand a step's controls to the gather (one thread, step order).  Returns the gathered controls of that step:
+        (world x B, 2, T), or a (world, B, 2, T) view of the coalesced result -- valid once the slot's group has been gathered
+        (join() makes everything valid on the current stream)."""
         if not self.active:
             return opt_u
         self.issued += 1
         if self.comm is None:
             self.collectives += 1
             return gather_controls(opt_u, self.dist, self.world, equal_shards=True)
-        ev = self.events[slot]
-        ev.record(producer if producer is not None else torch.cuda.current_stream(opt_u.device))
-        self.comm.wait_event(ev)
-        if self.stage is None:
+        if not self.coalesce:
+            ev = self.events[slot]
+            ev.record(producer if producer is not None else torch.cuda.current_stream(opt_u.device))
+            self.comm.wait_event(ev)
             with torch.cuda.stream(self.comm):
                 out = gather_controls(opt_u, self.dist, self.world, equal_shards=True)
             opt_u.record_stream(self.comm)
             self.collectives += 1
             return out
-        if opt_u.data_ptr() != self.stage[slot].data_ptr():
-            with torch.cuda.stream(self.comm):
-                self.stage[slot].copy_(opt_u, non_blocking=True)
-            opt_u.record_stream(self.comm)
-        self.pending += 1
-        if self.pending >= self.slots:
-            self._flush()
-        return self.out[:, slot]
+        if self.group_of[slot] == self.gathered_of[slot]:     # the caller did not stage it: do it here, on the producer's stream
+            self.after_step(opt_u, slot, producer)
+        par = self.gathered_of[slot] & 1
+        self.gathered_of[slot] += 1
+        self.comm.wait_event(self.copied[par][slot])
+        self.pending[par] += 1
+        if self.pending[par] >= self.slots:
+            self._flush(par)
+        return self.out[par][:, slot]
+
+    def _flush(self, par):
+        with torch.cuda.stream(self.comm):
+            self.dist.all_gather_into_tensor(self.out[par].view(-1), self.stage[par].view(-1))
+            ev = torch.cuda.Event()
+            ev.record(self.comm)
+        self.flushed[par] = ev
+        self.collectives += 1
+        self.pending[par] = 0
 
     def join(self, stream=None):
         if self.comm is not None:
-            if self.stage is not None and self.pending > 0:
-                self._flush()
+            if self.coalesce:
+                for par in (0, 1):
+                    if self.pending[par] > 0:
+                        self._flush(par)
             (stream if stream is not None else torch.cuda.current_stream(self.comm.device)).wait_stream(self.comm)
 
 
@@ -99,6 +129,8 @@ def run_steps(n: int, steps, streams=None, gatherer: ControlGatherer | None = No
         if streams is not None:
             with torch.cuda.stream(streams[j]):
                 o = steps[j]()
+            if gatherer is not None:
+                gatherer.after_step(o["opt_u"], j, streams[j])
             g = gatherer.gather(o["opt_u"], j, streams[j]) if gatherer is not None else o["opt_u"]
         else:
             o = steps[j]()
@@ -146,6 +178,8 @@ class StepLoop:
                         continue
                     with torch.cuda.stream(self.streams[j]):
                         outs[i] = self.steps[j]()
+                    if self.gatherer is not None:
+                        self.gatherer.after_step(outs[i]["opt_u"], j, self.streams[j])
                     evs[i].set()
             except BaseException as e:      # surface it in run(); unblock the main thread
                 self._err = e

@@ -160,12 +160,14 @@ def test_coalesced_gather_over_rccl_on_one_gpu():
         slots, B, T = 3, 8, 10
         g = ControlGatherer(dist, 1, device=dev, slots=slots, shape=(B, 2, T))
         streams = [torch.cuda.Stream(device=dev) for _ in range(slots)]
+        outs = [torch.empty((B, 2, T), device=dev) for _ in range(slots)]       # "the planners'" reused output tensors
         views = [None] * slots
         for i in range(7):                       # 2 full groups + 1 trailing step
             j = i % slots
             with torch.cuda.stream(streams[j]):
-                g.buffer(j).fill_(float(100 * i + j))       # "the planner" writes its controls into its staging row
-            views[j] = g.gather(g.buffer(j), j, streams[j])
+                outs[j].fill_(float(100 * i + j))
+            g.after_step(outs[j], j, streams[j])
+            views[j] = g.gather(outs[j], j, streams[j])
         g.join()
         torch.cuda.synchronize()
         assert g.issued == 7 and g.collectives == 3
@@ -173,9 +175,9 @@ def test_coalesced_gather_over_rccl_on_one_gpu():
         for j in range(slots):
             assert tuple(views[j].shape) == (1, B, 2, T)
             assert torch.all(views[j] == want[j]), (j, float(views[j].flatten()[0]))
-        # a tensor that does not live in the staging buffer is copied in behind its producer
-        other = torch.full((B, 2, T), 7.0, device=dev)
-        v = g.gather(other, 1, torch.cuda.current_stream(dev))
+        # a step whose issuer did not stage it is staged by gather() itself, behind its producer
+        outs[1].fill_(7.0)
+        v = g.gather(outs[1], 1, torch.cuda.current_stream(dev))
         g.join(); torch.cuda.synchronize()
         assert torch.all(v == 7.0)
     finally:
