@@ -1084,7 +1084,16 @@ static int npa_self_test(npa_handle* h) {
     std::vector<float> s0(n_stage), s1(n_stage);
     HIP_TRY(hipMemcpy(s0.data(), d_stage[0], n_stage * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(s1.data(), d_stage[1], n_stage * 4, hipMemcpyDeviceToHost));
-    if (memcmp(s0.data(), s1.data(), n_stage * 4) != 0)
+    // (rows only, and the number of rows: with NPA_SEL_DEBUG the upper bits of count[] carry candidate statistics, which
+    // differ between the two runs by design)
+    const size_t n_rows = (size_t)B * (T + 1) * M * (E + 5);
+    bool same = memcmp(s0.data(), s1.data(), n_rows * 4) == 0;
+    for (size_t i = n_rows; i < n_stage && same; ++i) {
+      int c0, c1;
+      memcpy(&c0, &s0[i], 4); memcpy(&c1, &s1[i], 4);
+      same = (c0 & 0xFF) == (c1 & 0xFF);
+    }
+    if (!same)
       return fail(NPA_E_UNSUPPORTED, geo2 ? "npa_create self-test: the geometric-key selection differs from the exact whole-slice "
                                             "selection on the test cloud (margin or kernel broken on this build / runtime)"
                                           : "npa_create self-test: two runs of the DUNE stage differ (non-deterministic keys)");

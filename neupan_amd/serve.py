@@ -45,6 +45,8 @@ class ControlGatherer:
             self.group_of = [0] * slots          # how many steps each slot has staged
             self.gathered_of = [0] * slots
             self.pending = [0, 0]
+            self.flush_gen = [0, 0]              # all-gathers issued per staging buffer
+            self.gen_at = [[-1] * slots for _ in range(2)]   # flush_gen when a slot last contributed to that buffer
         elif self.comm is not None:
             self.events = [torch.cuda.Event() for _ in range(slots)]
 
@@ -57,8 +59,9 @@ class ControlGatherer:
         par = self.group_of[slot] & 1
         # (an issuing thread that runs ahead: the row's previous occupant -- two steps of this slot ago -- must have been
         # handed to the gather, or its flush event does not exist yet)
-        while self.gathered_of[slot] < self.group_of[slot] - 1:
-            import time
+        import time
+        while self.gathered_of[slot] < self.group_of[slot] - 1 or \
+                (self.group_of[slot] >= 2 and self.flush_gen[par] <= self.gen_at[par][slot]):
             time.sleep(0)
         fl = self.flushed[par]
         with torch.cuda.stream(st):
@@ -92,6 +95,7 @@ class ControlGatherer:
         par = self.gathered_of[slot] & 1
         self.gathered_of[slot] += 1
         self.comm.wait_event(self.copied[par][slot])
+        self.gen_at[par][slot] = self.flush_gen[par]
         self.pending[par] += 1
         if self.pending[par] >= self.slots:
             self._flush(par)
@@ -103,6 +107,7 @@ class ControlGatherer:
             ev = torch.cuda.Event()
             ev.record(self.comm)
         self.flushed[par] = ev
+        self.flush_gen[par] += 1
         self.collectives += 1
         self.pending[par] = 0
 
