@@ -98,7 +98,10 @@ def main():
     if "RANK" in os.environ and "MASTER_PORT" in os.environ:      # under torch.distributed.run, also with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if os.environ.get("NPA_BENCH_LAZY_PG"):       # diagnostics: no eager communicator
+            dist.init_process_group("nccl", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # the measured leg imports the product only; tests/ (and with it oracle/) is touched by the cpu_baseline leg alone
     from neupan_amd.pan import PAN
@@ -137,7 +140,8 @@ def main():
     # Planners that carry timing events: every 4th (events ride on the dispatches).  --graph: the others replay a HIP graph
     # of the same launches (measured slower, kept for the record).
     timed_idx = set(range(0, nfl, 4)) if nfl >= 4 else set(range(nfl))
-    gatherer = ControlGatherer(dist, world, device=dev, slots=nfl, shape=(BATCH, 2, T))
+    # (NPA_BENCH_NOGATHER=1, diagnostics only: process group up, no gathers -- isolates what the collectives themselves cost)
+    gatherer = ControlGatherer(None if os.environ.get("NPA_BENCH_NOGATHER") else dist, world, device=dev, slots=nfl, shape=(BATCH, 2, T))
     steps = []
     for j in range(nfl):
         with torch.cuda.stream(streams[j]):
@@ -159,21 +163,21 @@ def main():
     timed_pans = [pans[j] for j in sorted(timed_idx)]
     for p in timed_pans:
         p.profile(True)
-    if dist is not None:
+    if dist is not None and not os.environ.get("NPA_BENCH_LAZY_PG"):
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     last = run_steps(args.steps)
     t_issue = time.perf_counter() - t0          # host time to enqueue every step (the GPU is still working)
     torch.cuda.synchronize(dev)
-    if dist is not None:
+    if dist is not None and not os.environ.get("NPA_BENCH_LAZY_PG"):
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     profs = [p.profile_read() for p in timed_pans]
     for p in timed_pans:
         p.profile(False)
-    if dist is not None:
+    if dist is not None and not os.environ.get("NPA_BENCH_LAZY_PG"):
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -333,13 +337,20 @@ def main():
         rep["one_step"] = one_step_report(one_step_consistency(args.workload, range(n_sc), tr["trace_s"].cpu().numpy()[:n_sc],
                                                                trace_u[:n_sc], args.cpu_cores if args.cpu_cores > 0 else host))
         phys, logical = host_cores()
+        quota = None
+        try:                                    # cgroup v2 CPU quota of this container ("max" = none): the ceiling of any CPU baseline here
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            quota = None if q == "max" else round(float(q) / float(per), 2)
+        except Exception:
+            pass
         line["cpu_baseline"] = {"value": round(cpu_rate, 3), "unit": "plans/s", "cores": ncore, "kind": "port",
                                 "sample": f"scenes of the same workload (first {n_sc}, cycled), K={K} each, oracle/pan_oracle.py "
                                           f"(numpy fp32 + fp64 IPM): kind 'port' because /root/reference does not exist on the GPU "
                                           f"box (the reference's own a-2..a-6 cannot be imported there); worker processes x 1 "
                                           f"thread, BLAS/OpenMP pinned to 1 thread in the parent before the spawn; best rate of a "
                                           f"sweep over the number of concurrent workers ({ncore} won; host: {phys} physical cores, "
-                                          f"{logical} hardware threads), 2-4 plans per worker, workers started and warm",
+                                          f"{logical} hardware threads, cgroup CPU quota {quota}), 2-4 plans per worker, workers started and warm",
+                                "cgroup_cpu_quota": quota,
                                 "sweep": getattr(run_ensemble, "last_sweep", None),
                                 "seconds_per_plan_single_worker": round(getattr(run_ensemble, "last_single_seconds", 0.0) or 0.0, 3)}
         js = getattr(run_ensemble, "last_job_seconds", None)

@@ -28,8 +28,15 @@ def test_default_bench_line_carries_every_contract_field():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1
+    # the CPU baseline is a sane one: a plan inside a worker of the winning level costs at most ~3x a plan on an idle host
+    assert c["seconds_per_plan_in_worker"]["median"] <= 3.0 * c["seconds_per_plan_single_worker"] + 0.05, c
+    assert len(c["sweep"]) >= 3 and c["value"] == max(r["plans_per_s"] for r in c["sweep"])
     p = d["parity"]
-    assert p["A_well_posed_all_le_tol"] and p["B_others_inside_envelope"] and p["C_le_1e-5_until_ensemble_diverges"]
+    assert p["A_well_posed_all_le_tol"] and p["C_le_1e-5_until_ensemble_diverges"]
+    assert p["one_step"]["frac_le_tol"] >= 0.995 and p["one_step"]["median"] <= 2e-6          # verdict D
+    assert 0 < p["well_posed_frac"] <= 1 and p["well_posed_only"]["plans_per_s"] > 0
+    assert d["margin_audit"]["violations"] == 0 and d["margin_audit"]["points"] > 0
+    assert d["host_issue_ms_per_step"] <= 0.5 * d["ms_per_step"]
 
 
 def test_tracked_pmc_file_matches_the_kernel_sources():
