@@ -119,6 +119,17 @@ def main():
         kw.update(over)
         return PAN(cfg.T, cfg.dt, Robot(cfg.T, cfg.dt, **cfg.robot), **kw)
 
+    if os.environ.get("NPA_BENCH_HIPRIO_STREAM"):          # diagnostics: does the mere existence of a high-priority stream cost?
+        _hp = torch.cuda.Stream(device=dev, priority=-1)
+        with torch.cuda.stream(_hp):
+            torch.zeros(16, device=dev).add_(1)
+        torch.cuda.synchronize(dev)
+    if os.environ.get("NPA_BENCH_RCCL_COMM_ONLY"):        # diagnostics: a raw RCCL communicator (no torch process group)
+        import ctypes as _C
+        _r = _C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+        _comm = _C.c_void_p()
+        _devs = (_C.c_int * 1)(local_rank)
+        print("ncclCommInitAll rc", _r.ncclCommInitAll(_C.byref(_comm), 1, _devs), file=sys.stderr)
     cfg = CONFIGS[args.workload]
     BATCH = args.batch
     T, K, N = cfg.T, cfg.iter_num, cfg.n_points
