@@ -35,7 +35,8 @@
 
 #define QP_THREADS 64          // lanes cooperating on one scene (one wavefront)
 #ifndef NPA_QP_WAVES
-#define NPA_QP_WAVES 2          // waves per SIMD the register allocation aims at
+#define NPA_QP_WAVES 2          // waves per SIMD the register allocation aims at (3: the 168-register experiment of DESIGN.md 3.3:
+                               // 35 registers spill, +3 % throughput, -8 % sequential -- measured, not shipped)
 #endif
 #define QP_MAX_IT 40
 // per-step records in LDS, one lane per horizon step: strides chosen so that ten (twenty) lanes hit distinct banks.  With
@@ -247,10 +248,10 @@ __device__ __forceinline__ PairC qp_pair(int p, int T, int npu, double sb0, doub
 // SCANW: the scan forms of the Phi products and the P_t blocks also for horizons of 17..32 steps (two DPP rows); the
 // launcher's default at T = 20 (acker: 69 k -> 79 k plans/s; the parity verdicts of tests/test_gpu_parity.py are the
 // same with and without them).  NPA_QP_NOSCAN_WIDE=1 selects the dense-product instantiation for A/B measurements.
-template <int TT, int MM, bool BWD = false, bool SCANW = false>
+template <int TT, int MM, bool BWD = false, bool SCANW = false, int WV = NPA_QP_WAVES>
 // (two waves per SIMD: <= 256 registers.  tests/test_abi.py reads the counts of the built code object and fails on any
 // spill or scratch use)
-__global__ __attribute__((amdgpu_flat_work_group_size(QP_THREADS, QP_THREADS), amdgpu_waves_per_eu(NPA_QP_WAVES, 3)))
+__global__ __attribute__((amdgpu_flat_work_group_size(QP_THREADS, QP_THREADS), amdgpu_waves_per_eu(WV, 3)))
 void nrmp_qp_kernel(
     DevParams P, const float* cur_s_in, const float* cur_u_in, const float* __restrict__ ref_s,
     const float* __restrict__ ref_us, const float* __restrict__ mu_sorted, const float* __restrict__ lam_sorted,
@@ -807,8 +808,8 @@ void nrmp_qp_kernel(
       if constexpr (HPAIR) {
         // all 4 M values of the step on their way (128-bit loads) before the sums start: the lanes that do this are few
         // and the loop was a chain of load -> wait -> 12 flops per row
-        // (NPA_QP_WAVES >= 3: in batches of two pairs -- 32 registers in flight instead of 80)
-        constexpr int HB = NPA_QP_WAVES >= 3 ? 2 : MM / 2;
+        // (WV >= 3: in batches of two pairs -- 32 registers in flight instead of 80)
+        constexpr int HB = WV >= 3 ? 2 : MM / 2;
 #pragma unroll
         for (int j0 = 0; j0 < MM / 2; j0 += HB) {
           double2 l2[HB], p0[HB], p1[HB], iw2[HB];
@@ -1036,9 +1037,8 @@ void nrmp_qp_kernel(
             const double2 lj = ld2(dxu + j0);
             if (j0 >= k + 2) arow[j0] = fma(-l, lj.x, arow[j0]);
             if (j0 + 1 < NU) arow[j0 + 1] = fma(-l, lj.y, arow[j0 + 1]);
-#if NPA_QP_WAVES >= 3
-            if ((j0 & 7) == 6) __builtin_amdgcn_sched_barrier(0);        // at most four 128-bit loads in flight
-#endif
+            if constexpr (WV >= 3)
+              if ((j0 & 7) == 6) __builtin_amdgcn_sched_barrier(0);      // at most four 128-bit loads in flight
           }
         }
       }
@@ -1123,6 +1123,10 @@ void nrmp_qp_kernel(
         // right-hand side: r1 := -dL/dx with dL/du collecting Phi' dL/ds (s_0 is pinned); every other
         // residual is zero.  s - ref of the final iterate is parked in `lin` for the q_s gradient.
         const float* gs = bw.grad_s + (size_t)b * 3 * (T + 1);
+        if constexpr (TT > 0) {            // (the P_t staging of the K' build took over s3 | q3: Phi x once more)
+          phi_mul(xu, s3);
+          LSYNC();
+        }
         for (int q = lane; q < 3 * T; q += QP_THREADS) {
           int t = q / 3, k = q - 3 * t;
           const float qsk = k == 0 ? P.q_s[0] : (k == 1 ? P.q_s[1] : P.q_s[2]);
@@ -1173,7 +1177,7 @@ void nrmp_qp_kernel(
       for (int t = lane; t < T; t += QP_THREADS) {
         double z0 = 0, z1 = 0, zs = 0;
         if constexpr (HPAIR) {
-          constexpr int HB = NPA_QP_WAVES >= 3 ? 2 : MM / 2;
+          constexpr int HB = WV >= 3 ? 2 : MM / 2;
 #pragma unroll
           for (int j0 = 0; j0 < MM / 2; j0 += HB) {
             double2 w2[HB], p0[HB], p1[HB];
@@ -1217,37 +1221,37 @@ void nrmp_qp_kernel(
         const int lr = lane < NU ? lane : 0;
         rr *= myinv;                         // b_i / L_ii
         if constexpr (NU <= 20) {
-#if NPA_QP_WAVES >= 3
-          // (three waves per SIMD: row and column of L one after the other through the same registers)
-          {
-            double Lrow[NU];
+          if constexpr (WV >= 3) {
+            // (three waves per SIMD: row and column of L one after the other through the same registers)
+            {
+              double Lrow[NU];
+#pragma unroll
+              for (int k = 0; k < NU; ++k) Lrow[k] = Km[lr * ldk + k];
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int k = 0; k < NU; ++k) rr = fma(-Lrow[k], readlane_f64(rr, k), rr);          // -> y
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+              double Lcol[NU];
+#pragma unroll
+              for (int k = 0; k < NU; ++k) Lcol[k] = Km[k * ldk + lr];
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int k = NU - 1; k >= 0; --k) rr = fma(-Lcol[k], readlane_f64(rr, k), rr);     // -> z
+            }
+          } else {
+            double Lrow[NU], Lcol[NU];
 #pragma unroll
             for (int k = 0; k < NU; ++k) Lrow[k] = Km[lr * ldk + k];
-            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);         // all of row `lane` is on its way before the chain starts
+#pragma unroll
+            for (int k = 0; k < NU; ++k) Lcol[k] = Km[k * ldk + lr];   // (free to overlap the forward chain)
 #pragma unroll
             for (int k = 0; k < NU; ++k) rr = fma(-Lrow[k], readlane_f64(rr, k), rr);          // -> y
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          {
-            double Lcol[NU];
-#pragma unroll
-            for (int k = 0; k < NU; ++k) Lcol[k] = Km[k * ldk + lr];
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = NU - 1; k >= 0; --k) rr = fma(-Lcol[k], readlane_f64(rr, k), rr);     // -> z
           }
-#else
-          double Lrow[NU], Lcol[NU];
-#pragma unroll
-          for (int k = 0; k < NU; ++k) Lrow[k] = Km[lr * ldk + k];
-          __builtin_amdgcn_sched_barrier(0);         // all of row `lane` is on its way before the chain starts
-#pragma unroll
-          for (int k = 0; k < NU; ++k) Lcol[k] = Km[k * ldk + lr];   // (free to overlap the forward chain)
-#pragma unroll
-          for (int k = 0; k < NU; ++k) rr = fma(-Lrow[k], readlane_f64(rr, k), rr);          // -> y
-#pragma unroll
-          for (int k = NU - 1; k >= 0; --k) rr = fma(-Lcol[k], readlane_f64(rr, k), rr);     // -> z
-#endif
         } else {                             // (T = 20: 2 x 40 doubles ahead of the chains do not fit the register file)
 #pragma unroll
           for (int k = 0; k < NU; ++k) rr = fma(-Km[lr * ldk + k], readlane_f64(rr, k), rr);
@@ -1351,7 +1355,13 @@ void nrmp_qp_kernel(
         for (int t = lane; t < T; t += QP_THREADS) {
           double refu = (double)__fmul_rn(P.p_u, rus[t]) / (P.p_u != 0.f ? (double)P.p_u : 1.0);
           gp += dxu[2 * t] * (xu[2 * t] - refu);
-          if (obs) { ge += dxd[t]; gmx += dld[2 * t]; gmn += dld[2 * t + 1]; }
+          if (obs) {
+            ge += dxd[t];
+            if constexpr (!REGROWS) { gmx += dld[2 * t]; gmn += dld[2 * t + 1]; }
+          }
+        }
+        if constexpr (REGROWS) {           // the d rows' multiplier directions sit in their owner lanes' registers (pair npu + t)
+          if (obs && lane >= npu && lane < npc) { gmx = Rdlc.x; gmn = Rdlc.y; }
         }
         if (bw.grad_nom_s) {
           // the only input of this solve that the reference keeps on its autograd graph besides theta:
@@ -1622,15 +1632,27 @@ extern "C" hipError_t npa_launch_qp_backward(const DevParams& P, int batch, cons
                                              float* out_s, float* out_u, float* out_d, const float* grad_s,
                                              const float* grad_u, const float* grad_d, float* grad_theta,
                                              float* grad_nom_s, double* qp_info, hipStream_t stream) {
-  const size_t wave_bytes = npa_qp_shmem_bytes(P.T, P.M);
+  static const bool force_generic = getenv("NPA_QP_GENERIC") != nullptr;
+  const bool fast = qp_fast_path(P.T, P.M) && !force_generic && (P.T <= 16 || qp_scan_wide());
+  const size_t wave_bytes = npa_qp_shmem_bytes_path(P.T, P.M, fast ? 1 : 0);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<10, 10, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<20, 10, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((nrmp_qp_kernel<0, 0, true>), dim3(batch), dim3(QP_THREADS), wave_bytes, stream, P, nom_s, nom_u, ref_s,
-                     ref_us, mu_sorted, lam_sorted, pts_sorted, (const float*)nullptr, count, out_s, out_u, out_d,
-                     (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int*)nullptr, (float*)nullptr,
-                     (int*)nullptr, (float*)nullptr, qp_info, (double*)nullptr, 0, batch, QpBackward{grad_s, grad_u, grad_d, grad_theta, grad_nom_s, nullptr, nullptr, nullptr}, (float*)nullptr);
+  // (the register-resident instantiations since round 3: the gradient pass reads the multiplier directions of the d rows
+  // from their owner lanes; NPA_QP_GENERIC=1 keeps the LDS kernel)
+#define QPB_LAUNCH(...)                                                                                                \
+  hipLaunchKernelGGL((nrmp_qp_kernel<__VA_ARGS__>), dim3(batch), dim3(QP_THREADS), wave_bytes, stream, P, nom_s, nom_u, ref_s, \
+                     ref_us, mu_sorted, lam_sorted, pts_sorted, (const float*)nullptr, count, out_s, out_u, out_d,        \
+                     (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int*)nullptr, (float*)nullptr,  \
+                     (int*)nullptr, (float*)nullptr, qp_info, (double*)nullptr, 0, batch,                                 \
+                     QpBackward{grad_s, grad_u, grad_d, grad_theta, grad_nom_s, nullptr, nullptr, nullptr}, (float*)nullptr)
+  if (fast && P.T == 10) QPB_LAUNCH(10, 10, true);
+  else if (fast && P.T == 20) QPB_LAUNCH(20, 10, true, true);
+  else QPB_LAUNCH(0, 0, true);
+#undef QPB_LAUNCH
   return hipGetLastError();
 }

@@ -161,3 +161,20 @@ def test_hip_recurrent_gradient_vs_oracle():
     worst = np.sort(worst)
     assert worst[len(worst) // 2] <= 1e-3 and worst[-1] <= 5e-2, worst
     assert max(rec) > 1e-3                       # the chained terms are there
+
+
+@pytest.mark.gpu
+def test_gradient_tests_on_the_generic_instantiation():
+    """The backward solve runs on the register-resident QP instantiations (T = 10 / 20, M = 10) since round 3; the generic
+    (LDS) instantiation still serves every other shape.  NPA_QP_GENERIC=1 is read once per process, so the two GPU gradient
+    tests above are run once more in a child process with it set."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NPA_QP_GENERIC="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_nrmp_backward.py"), "-m", "gpu", "-q", "-x",
+                        "-p", "no:cacheprovider", "-k", "hip_gradient_vs_oracle or hip_recurrent_gradient_vs_oracle"],
+                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "2 passed" in r.stdout, r.stdout[-500:]
