@@ -44,9 +44,16 @@
 // every 64-bit access (bank = dword address mod 64 for reads, mod 32 for writes)
 #define QP_ABC_LD 14           // [T][14]: A02 A12 B00 B01 B10 B11 B20 B21 C0 C1 C2 (even: read two at a time)
 #define QP_ST_LD 9             // [T][9]:  S'00 S'01 S'11 v0 v1 sigma 1/kappa r1_d
-#define QP_WARM_DELTA 0.01     // floor of the multipliers / slacks taken over from the previous solve
+#define QP_WARM_DELTA 0.003    // floor of the multipliers / slacks taken over from the previous solve
+// Interior-point heuristics (tuned on the QPs of the four benchmark workloads with the CPU transliteration of this method,
+// tests/tools/qp_step_study.py -> profiles/r03_qp_step_study.txt; oracle/condensed_ipm.py carries the same constants):
+#define QP_STEP_ETA 0.995      // fraction of the step to the boundary, RAISED towards 1 as the gap closes: eta = max(0.995, 1 - mu),
+#define QP_STEP_CAP 1e-6       //   never above 1 - 1e-6.  The fixed 0.995 made the end game linear (x 0.005 per iteration)
+#define QP_START_MU 3.0        // cold start: multipliers = 3 / slack (every row starts on the central path of mu = 3)
+#define QP_SIGMA_MU_MIN 1e-15  // floor of the centring target: a gap driven to 1e-20 leaves the Newton matrix too ill
+                               //   conditioned for the residuals to follow (solves that ended at 1e-11: 8 -> 1 of 640)
 #define QP_WARM_STEP 0.1       // largest control change of the previous solve after which its result is reused
-// the cold starting point: u = 0, d mid-range, unit multipliers, slacks >= 1 (a macro: used before the loop and, in the
+// the cold starting point: u = 0, d mid-range, slacks >= 1, multipliers QP_START_MU / slack (a macro: used before the loop and, in the
 // instantiations with warm start, again at the loop top when a warm attempt is dropped)
 #define QP_COLD_INIT()                                                                            \
   do {                                                                                            \
@@ -56,20 +63,26 @@
       const PairC c = PAIR_C(p);                                                                  \
       const double cx = p >= npu ? d0 : 0.0;      /* c'x at the cold point */                     \
       const bool on = c.actf != 0.0;                                                              \
-      st2(lc + 2 * p, c.actf, c.actf);                                                            \
-      ST_ROW(Rwc, wc, p, on ? fmax(c.bp - cx, 1.0) : 1.0, on ? fmax(c.bm + cx, 1.0) : 1.0);       \
+      const double w0p = on ? fmax(c.bp - cx, 1.0) : 1.0, w0m = on ? fmax(c.bm + cx, 1.0) : 1.0;  \
+      st2(lc + 2 * p, c.actf * QP_START_MU * fast_rcp(w0p), c.actf * QP_START_MU * fast_rcp(w0m)); \
+      ST_ROW(Rwc, wc, p, w0p, w0m);                                                               \
       ST_ROW(Rdlc, dlc, p, 0.0, 0.0); st2(dwc + 2 * p, 0.0, 0.0);                                 \
     }                                                                                             \
     LSYNC();                                                                                      \
     if constexpr (REGROWS) {                                                                      \
       if (lane < mf / 2) {                                                                        \
-        st2(lf + 2 * lane, 1.0, 1.0);                                                             \
-        Rwf = make_double2(fmax(-d0 - Rff.x + iro, 1.0), fmax(-d0 - Rff.y + iro, 1.0));           \
+        /* the hinge slack contains its own multiplier (w = F x - f + l/ro): one fixed-point round */ \
+        const double hx = -d0 - Rff.x, hy = -d0 - Rff.y;                                          \
+        const double l0x = QP_START_MU * fast_rcp(fmax(hx + iro, 1.0)), l0y = QP_START_MU * fast_rcp(fmax(hy + iro, 1.0)); \
+        Rwf = make_double2(fmax(hx + l0x * iro, 1.0), fmax(hy + l0y * iro, 1.0));                 \
+        st2(lf + 2 * lane, QP_START_MU * fast_rcp(Rwf.x), QP_START_MU * fast_rcp(Rwf.y));         \
       }                                                                                           \
     } else {                                                                                      \
       for (int i = lane; i < mf; i += QP_THREADS) {                                               \
-        lf[i] = 1.0;                                                                              \
-        wf[i] = fmax(-d0 - ff[i] + iro, 1.0); /* F x - f + lf/ro at u = 0 */                      \
+        const double hx = -d0 - ff[i];        /* F x - f at u = 0 */                              \
+        const double l0x = QP_START_MU * fast_rcp(fmax(hx + iro, 1.0));                           \
+        wf[i] = fmax(hx + l0x * iro, 1.0);                                                        \
+        lf[i] = QP_START_MU * fast_rcp(wf[i]);                                                    \
       }                                                                                           \
     }                                                                                             \
     LSYNC();                                                                                      \
@@ -179,7 +192,7 @@ __device__ __forceinline__ double fast_rcp(double x) {      // ~1 ulp; x finite,
   r = fma(fma(-x, r, 1.0), r, r);
   return r;
 }
-// step-to-the-boundary ratios only need a few digits (the step is scaled by 0.995 anyway)
+// step-to-the-boundary ratios only need a few digits (v_rcp_f64: ~1e-8 relative; the step keeps >= 1e-6 of the distance)
 __device__ __forceinline__ double rough_rcp(double x) { return __builtin_amdgcn_rcp(x); }
 // 1/sqrt(pivot) of the Cholesky: v_rsq_f64 (about 2^-26 relative) and ONE Newton step (-> ~1e-15); L L' then differs from
 // K' by a few ulp -- an inexact Newton matrix at that level costs nothing, and the step is on the serial path of every pivot
@@ -540,7 +553,7 @@ void nrmp_qp_kernel(
     return;
   }
 
-  // ---- starting point: u = 0, d mid-range, unit multipliers, slacks >= 1 --------------------
+  // ---- starting point: u = 0, d mid-range, slacks >= 1, multipliers QP_START_MU / slack --------
   const double d0 = uni64(0.5 * (dmin0 + dmaxv));
   double cmax = fmax(fabs(dmaxv), fabs(dmin0));
   double m_act = 0;
@@ -708,7 +721,7 @@ void nrmp_qp_kernel(
   const bool can_warm = WARM && wrm && flags && flags[b * 4 + 2];
   PROF(0);
   bool adj = false;                      // BWD: the pass below is the adjoint solve
-  int it_total = 0, warm_code = 0;       // diagnostics: iterations over both attempts; 1 warm start used, 2 / 3 dropped at it 0 / 3, 4 not converged
+  int it_total = 0, warm_code = 0;       // diagnostics: iterations over both attempts; 1 warm start used, 2 / 3 dropped at it 0 / 6, 4 not converged
   bool warm_now = can_warm;              // the solve in progress started from the previous solution
   bool need_cold = false;                // re-initialise at the top of the next iteration (a dropped warm attempt)
   if (WARM && warm_now) {
@@ -862,12 +875,13 @@ void nrmp_qp_kernel(
     if (qp_info && lane == 0 && it < 4) { double* qq = qp_info + (size_t)b * QP_INFO_STRIDE; qq[5 + 2 * it] = merit; qq[6 + 2 * it] = mu; }
 #endif
     if (!(merit == merit) || !(merit < 1e300)) { status = 2; break; }
-    // a warm start that is not paying off is dropped at once: a good one starts at merit ~2e-2 (the floor QP_WARM_DELTA
-    // of its multipliers) and gains two digits per iteration; one that starts far from feasibility, or has not
-    // reached 1e-4 after three iterations (1e-8 after seven), is heading for the cold start's iteration count or worse
-    // (rule tuned on 960 QPs of 96 scenes, tests/tools: mean 13.3 -> 10.0 iterations, the per-iteration maximum unchanged)
+    // a warm start that is not paying off is dropped at once: a good one starts at merit <= 1.2e-2 and needs 3 - 5
+    // iterations with the adaptive step; one that starts far from feasibility is dropped before its first iteration, one
+    // that has not reached 1e-4 after six is stuck (the one case in 1360 QPs went on for 27).  Round 2's checkpoints at
+    // iterations 3 and 7 dropped attempts that the adaptive step finishes in fewer iterations than the cold start they
+    // fell back to (tests/tools/qp_step_study.py)
     if constexpr (WARM) {
-      if (warm_now && ((it == 0 && merit > 0.05) || (it == 3 && merit > 1e-4) || (it == 7 && merit > 1e-8))) {
+      if (warm_now && ((it == 0 && merit > 0.05) || (it == 6 && merit > 1e-4))) {
         warm_code = it == 0 ? 2 : 3;
         it_total += it; warm_now = false; need_cold = true;
         it = -1;
@@ -1336,9 +1350,9 @@ void nrmp_qp_kernel(
         }
         double mu_aff = wave_reduce<OpSum>(gap_aff) * inv_m;
         double sg = mu_aff * fast_rcp(mu);
-        sigma_mu = sg * sg * sg * mu;
+        sigma_mu = fmax(sg * sg * sg * mu, QP_SIGMA_MU_MIN);
       } else {
-        alpha = fmin(1.0, 0.995 * amax);
+        alpha = fmin(1.0, fmin(fmax(QP_STEP_ETA, 1.0 - mu), 1.0 - QP_STEP_CAP) * amax);
       }
       LSYNC();
       PROF(7); PROF_C(7);

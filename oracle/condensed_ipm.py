@@ -74,18 +74,23 @@ def condense(pb: NrmpProblem):
     return H, g, F, f, C, c, Phi, cv
 
 
-WARM_DELTA = 0.01       # QP_WARM_DELTA in nrmp_qp.hip
-# a warm attempt is dropped (the solve restarts cold) when its merit exceeds these at iteration 0 / 3 / 7, and repeated
+WARM_DELTA = 0.003      # QP_WARM_DELTA in nrmp_qp.hip
+# a warm attempt is dropped (the solve restarts cold) when its merit exceeds these at iteration 0 / 6, and repeated
 # cold when it ends above WARM_ACCEPT -- the kernel's rules (nrmp_qp.hip, "a warm start that is not paying off").  The
 # gate on the PREVIOUS solve (converged, controls moved < QP_WARM_STEP) is the caller's: pass warm=None when it fails.
-WARM_DROP = {0: 0.05, 3: 1e-4, 7: 1e-8}
+WARM_DROP = {0: 0.05, 6: 1e-4}
 WARM_ACCEPT = 1e-10
+# the kernel's interior-point heuristics (same names without the QP_ prefix; tests/tools/qp_step_study.py tuned them)
+STEP_ETA = 0.995        # fraction of the step to the boundary: max(STEP_ETA, 1 - mu), capped at 1 - STEP_CAP
+STEP_CAP = 1e-6
+START_MU = 3.0          # cold start: multipliers = START_MU / slack
+SIGMA_MU_MIN = 1e-15    # floor of the centring target sigma * mu
 
 
 def solve_condensed(pb: NrmpProblem, tol=1e-14, max_iter=40, trace=None, warm=None):
     """warm = (x, lc, lf) of a previous, similar solve: the kernel's warm start across the PAN
     iterations of one forward call (multipliers and slacks floored at WARM_DELTA), with the kernel's drop rules: the
-    attempt is abandoned for a cold start at iteration 0 / 3 / 7 when its merit is above WARM_DROP, and a warm-started
+    attempt is abandoned for a cold start at iteration 0 / 6 when its merit is above WARM_DROP, and a warm-started
     solve that ends above WARM_ACCEPT is repeated cold.  info["warm_code"]: 0 cold, 1 warm start used, 2 / 3 dropped at
     iteration 0 / later, 4 not converged (qp_info[15] of the kernel)."""
     H, g, F, f, C, c, Phi, cv = condense(pb)
@@ -97,8 +102,17 @@ def solve_condensed(pb: NrmpProblem, tol=1e-14, max_iter=40, trace=None, warm=No
     x = np.zeros(n)
     if not pb.no_obs:
         x[nu:] = 0.5 * (max(pb.d_min, 0.0) + pb.d_max)
-    lc = np.ones(mc); wc = np.maximum(c - C @ x, 1.0)
-    lf = np.ones(mf); wf = np.maximum(F @ x - f + lf / ro, 1.0)
+    # slacks >= 1, multipliers on the central path of mu = START_MU (the hinge slack contains its own multiplier,
+    # w = F x - f + l/ro: one fixed-point round, as QP_COLD_INIT does it)
+    wc = np.maximum(c - C @ x, 1.0)
+    hx = F @ x - f
+    wf = np.maximum(hx + 1.0 / ro, 1.0)
+    if START_MU is None:                # (round 2's start, unit multipliers: only tests/tools/qp_step_study.py sets this)
+        lc = np.ones(mc); lf = np.ones(mf)
+    else:
+        lc = START_MU / wc
+        lf = START_MU / wf
+        wf = np.maximum(hx + lf / ro, 1.0); lf = START_MU / wf
     if warm is not None:
         x = np.array(warm[0], dtype=float)
         if not pb.no_obs:
@@ -130,7 +144,7 @@ def solve_condensed(pb: NrmpProblem, tol=1e-14, max_iter=40, trace=None, warm=No
             best = (merit, x.copy(), it); stall = 0
         else:
             stall += 1
-        if merit <= tol or stall >= 3 or it == max_iter or mu < 1e-15:
+        if merit <= tol or stall >= 3 or it == max_iter or mu < 1e-17:
             break
         Dc = lc / wc
         Df = lf / (wf + lf / ro)
@@ -156,9 +170,10 @@ def solve_condensed(pb: NrmpProblem, tol=1e-14, max_iter=40, trace=None, warm=No
         dx, dwc, dlc, dwf, dlf = solve(lc * wc, lf * wf)
         a_aff = min(max_step(wc, dwc), max_step(lc, dlc), max_step(wf, dwf), max_step(lf, dlf))
         mu_aff = ((lc + a_aff * dlc) @ (wc + a_aff * dwc) + (lf + a_aff * dlf) @ (wf + a_aff * dwf)) / max(m, 1)
-        sigma = (mu_aff / mu) ** 3
-        dx, dwc, dlc, dwf, dlf = solve(lc * wc + dwc * dlc - sigma * mu, lf * wf + dwf * dlf - sigma * mu)
-        a = min(1.0, 0.995 * min(max_step(wc, dwc), max_step(lc, dlc), max_step(wf, dwf), max_step(lf, dlf)))
+        sigma_mu = max((mu_aff / mu) ** 3 * mu, SIGMA_MU_MIN)
+        dx, dwc, dlc, dwf, dlf = solve(lc * wc + dwc * dlc - sigma_mu, lf * wf + dwf * dlf - sigma_mu)
+        eta = min(max(STEP_ETA, 1.0 - mu), 1.0 - STEP_CAP)
+        a = min(1.0, eta * min(max_step(wc, dwc), max_step(lc, dlc), max_step(wf, dwf), max_step(lf, dlf)))
         x = x + a * dx; wc = wc + a * dwc; lc = lc + a * dlc; wf = wf + a * dwf; lf = lf + a * dlf
         lam_out = (lc, lf)
     if warm is not None and not best[0] <= WARM_ACCEPT:

@@ -209,8 +209,8 @@ def test_qp_oracle_vs_highs_on_benchmark_problems(cfgname, scene, kw):
 
 
 def test_condensed_solver_warm_start_rules():
-    """oracle/condensed_ipm.py carries the kernel's warm start (nrmp_qp.hip): floor QP_WARM_DELTA = 0.01, drop rules at
-    iteration 0 / 3 / 7, cold retry.  (1) a solve started from its own solution is accepted, takes fewer iterations and
+    """oracle/condensed_ipm.py carries the kernel's warm start (nrmp_qp.hip): floor QP_WARM_DELTA = 0.003, drop rules at
+    iteration 0 / 6, cold retry.  (1) a solve started from its own solution is accepted, takes fewer iterations and
     lands on the same point; (2) a start from an unrelated problem's solution is dropped or converges -- either way the
     point is the cold solve's."""
     g = golden("qp_cases")

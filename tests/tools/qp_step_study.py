@@ -1,0 +1,92 @@
+"""CPU study behind the interior-point heuristics of the QP kernel (nrmp_qp.hip: QP_STEP_ETA / QP_STEP_CAP, QP_START_MU,
+QP_SIGMA_MU_MIN, QP_WARM_DELTA, the warm-start drop rules).  oracle/condensed_ipm.py is the kernel's method in numpy and
+carries the same constants; this tool replays it over EVERY QP the oracle's PAN loop produces on scenes of the four
+benchmark workloads -- warm-started along the loop under the kernel's gate (previous solve converged to 1e-12 and moved
+the controls by < 0.1) -- once per rule set, and counts interior-point iterations.
+
+    python tests/tools/qp_step_study.py [scenes per workload] [procs]     -> profiles/r03_qp_step_study.txt
+
+The kernel's time is proportional to these counts (one wave per scene, ~2 900 VALU instructions per iteration)."""
+import os, sys
+for _k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+    os.environ.setdefault(_k, "1")
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+WORK = ("diff_1k_T10_K10", "acker_2k_T20_K15", "dyna_4k_T10_K10", "poly8_5k_T10_K10")
+ROUND2 = dict(STEP_CAP=0.005, START_MU=None, SIGMA_MU_MIN=0.0, WARM_DELTA=0.01, WARM_DROP={0: 0.05, 3: 1e-4, 7: 1e-8})
+SHIPPED = {}
+RULES = [("round 2 (eta = 0.995, unit multipliers, floor 0.01, drops at 0 / 3 / 7)", ROUND2),
+         ("+ centring target >= 1e-15", {**ROUND2, "SIGMA_MU_MIN": 1e-15}),
+         ("+ eta = max(0.995, 1 - mu) <= 1 - 1e-6", {**ROUND2, "SIGMA_MU_MIN": 1e-15, "STEP_CAP": 1e-6}),
+         ("+ multipliers 3 / slack at the cold start", {**ROUND2, "SIGMA_MU_MIN": 1e-15, "STEP_CAP": 1e-6, "START_MU": 3.0}),
+         ("+ warm floor 0.003", {**ROUND2, "SIGMA_MU_MIN": 1e-15, "STEP_CAP": 1e-6, "START_MU": 3.0, "WARM_DELTA": 0.003}),
+         ("+ drops at 0 / 6 only  = SHIPPED", SHIPPED),
+         ("shipped, but no cap on eta", {"STEP_CAP": 0.0}),
+         ("shipped, but warm floor 0.001", {"WARM_DELTA": 0.001}),
+         ("shipped, but warm floor 0.01", {"WARM_DELTA": 0.01}),
+         ("shipped, but no drop after iteration 0", {"WARM_DROP": {0: 0.05}}),
+         ("shipped, but no floor on the centring target", {"SIGMA_MU_MIN": 0.0})]
+
+
+def job(arg):
+    name, b = arg
+    from helpers import CONFIGS, make_oracle
+    from neupan_amd.scenes import make_scene
+    from oracle import condensed_ipm as ci
+    cfg = CONFIGS[name]
+    sc = make_scene(cfg, b)
+    orc = make_oracle(cfg)
+    pbs = []
+    orig = orc.nrmp
+
+    def hook(*a):
+        r = orig(*a)
+        pbs.append(orc.last_problem)
+        return r
+    orc.nrmp = hook
+    orc.forward(sc["nom_s"], sc["nom_u"], sc["ref_s"], sc["ref_us"], sc["points"], sc["velocities"])
+    shipped = {k: getattr(ci, k) for k in ("STEP_ETA", "STEP_CAP", "START_MU", "SIGMA_MU_MIN", "WARM_DELTA", "WARM_DROP")}
+    out = []
+    for _, rules in RULES:
+        for k, v in {**shipped, **rules}.items():
+            setattr(ci, k, v)
+        rows = []; prev = None; prev_u = None
+        for pb in pbs:
+            warm = prev["warm"] if prev is not None and prev["merit"] <= 1e-12 and prev["step"] < 0.1 else None
+            s, u, d, info = ci.solve_condensed(pb, warm=warm)
+            info["step"] = float(np.abs(u - prev_u).max()) if prev_u is not None else 9.0     # (first nominal: not a solve's output)
+            rows.append((info["iters_total"], info["warm_code"], float(info["merit"])))
+            prev, prev_u = info, u
+        out.append(rows)
+    for k, v in shipped.items():
+        setattr(ci, k, v)
+    return name, out
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    procs = int(sys.argv[2]) if len(sys.argv) > 2 else (os.cpu_count() or 1)
+    from concurrent.futures import ProcessPoolExecutor
+    import multiprocessing as mp
+    with ProcessPoolExecutor(procs, mp_context=mp.get_context("spawn")) as ex:
+        res = list(ex.map(job, [(w, b) for w in WORK for b in range(n)]))
+    lines = [f"interior-point iterations per QP over the oracle's PAN loop, {n} scenes per workload, every QP of every scene (tests/tools/qp_step_study.py)",
+             "columns: mean / max over all QPs | mean / max over the LAST QP of a call | solves by warm code (0 cold, 1 warm used, 2 / 3 dropped at the first / a later checkpoint, 4 repeated cold) | solves that end above 1e-12"]
+    for w in WORK:
+        lines.append(w)
+        for i, (label, _) in enumerate(RULES):
+            rows = [r for name, out in res if name == w for r in out[i]]
+            last = [out[i][-1][0] for name, out in res if name == w]
+            it = np.array([r[0] for r in rows]); code = np.array([r[1] for r in rows]); bad = sum(r[2] > 1e-12 for r in rows)
+            by = " ".join(f"{c}:{(code == c).sum()}x{it[code == c].mean():.1f}" for c in range(5) if (code == c).any())
+            lines.append(f"  {label:82s} {it.mean():6.2f} /{it.max():3d} | {np.mean(last):6.2f} /{max(last):3d} | {by} | {bad}")
+    txt = "\n".join(lines)
+    print(txt)
+    with open(os.path.join(ROOT, "profiles", "r03_qp_step_study.txt"), "w") as f:
+        f.write(txt + "\n")
+
+
+if __name__ == "__main__":
+    main()
