@@ -50,6 +50,9 @@
 #define QP_STEP_ETA 0.995      // fraction of the step to the boundary, RAISED towards 1 as the gap closes: eta = max(0.995, 1 - mu),
 #define QP_STEP_CAP 1e-6       //   never above 1 - 1e-6.  The fixed 0.995 made the end game linear (x 0.005 per iteration)
 #define QP_START_MU 3.0        // cold start: multipliers = 3 / slack (every row starts on the central path of mu = 3)
+#ifndef QP_CHOL_LOOK
+#define QP_CHOL_LOOK 3         // columns behind the pivot whose trailing update is broadcast with v_readlane (the rest: LDS, one pivot late)
+#endif
 #define QP_SIGMA_MU_MIN 1e-15  // floor of the centring target: a gap driven to 1e-20 leaves the Newton matrix too ill
                                //   conditioned for the residuals to follow (solves that ended at 1e-11: 8 -> 1 of 640)
 #define QP_WARM_STEP 0.1       // largest control change of the previous solve after which its result is reused
@@ -1024,8 +1027,25 @@ void nrmp_qp_kernel(
       double piv = readlane_f64(arow[0], 0);
       if (!(piv > 0.0)) chol_ok = false;
       double rinv = fast_rsqrt(piv);
+      // The trailing update of pivot k splits three ways.  Column k + 1 is on the pivot chain (two v_readlane).  Columns up
+      // to k + QP_CHOL_LOOK take the v_readlane route as well: they are read by the chains of the next pivots, and an LDS
+      // round trip (store of the column, uniform-address loads: > 100 cycles) would sit on every one of them.  The rest --
+      // most of the instructions -- is broadcast through LDS with 128-bit loads of two l_j each (a third of the VALU
+      // instructions two v_readlane per value would cost), and APPLIED ONE PIVOT LATE: pivot k loads the column pivot
+      // k - 1 stored, so that neither the store nor the loads wait on this pivot's chain.  (LDS operations of a wave
+      // execute in order: pivot k's loads come before its own store into the same slot.)
+      constexpr int LOOK = NU > 20 ? NU : QP_CHOL_LOOK;      // (T = 20: the loaded values do not fit beside the 40-entry row)
+      double lprev = 0.0;
 #pragma unroll
       for (int k = 0; k < NU; ++k) {
+        constexpr int JN = NU <= 20 ? NU / 2 : 1;
+        double2 lj[JN];
+        const int jf = k + LOOK;                 // first column of pivot k - 1's deferred update
+        if (k >= 1 && jf < NU) {
+#pragma unroll
+          for (int j0 = jf & ~1; j0 < NU; j0 += 2) lj[(j0 >> 1) % JN] = ld2(dxu + j0);
+        }
+        if constexpr (NU <= 20) __builtin_amdgcn_sched_barrier(0);     // the loads go out before the chain, their use comes after it
         const double l = arow[k] * rinv;
         invd[k] = rinv;                      // uniform value, every lane stores it
         arow[k] = l;
@@ -1035,26 +1055,21 @@ void nrmp_qp_kernel(
           if (!(piv > 0.0)) chol_ok = false;
           rinv = fast_rsqrt(piv);
         }
-        // The rest of the trailing update is not on the pivot chain: its broadcasts of l_j go through LDS (one store of the
-        // column, uniform-address 128-bit loads of two l_j each) instead of two v_readlane per value -- a third of the
-        // VALU instructions of the factorisation.  (LDS operations of a wave execute in order: the loads see the store,
-        // and the next column's store comes after this column's loads.)
-        if constexpr (NU > 20) {              // (T = 20: the 2 x 19 values a step loads do not fit beside the 40-entry row)
 #pragma unroll
-          for (int j = k + 2; j < NU; ++j) arow[j] = fma(-l, readlane_f64(l, j), arow[j]);
-        } else if (k + 2 < NU) {
-          // (dxu and dxd are dead between `update` and the substitution; lanes >= NU dump their copy into dxd[0]: no
-          // predicate, the factorisation stays one basic block)
-          dxu[lane < NU ? lane : NU] = l;
+        for (int j = k + 2; j < NU && j <= k + LOOK; ++j) arow[j] = fma(-l, readlane_f64(l, j), arow[j]);
+        // (dxu and dxd are dead between `update` and the substitution; lanes >= NU dump their copy into dxd[0]: no
+        // predicate, the factorisation stays one basic block)
+        if (k + 1 + LOOK < NU) dxu[lane < NU ? lane : NU] = l;
+        if constexpr (NU <= 20) __builtin_amdgcn_sched_barrier(0);
+        if (k >= 1 && jf < NU) {
 #pragma unroll
-          for (int j0 = (k + 2) & ~1; j0 < NU; j0 += 2) {
-            const double2 lj = ld2(dxu + j0);
-            if (j0 >= k + 2) arow[j0] = fma(-l, lj.x, arow[j0]);
-            if (j0 + 1 < NU) arow[j0 + 1] = fma(-l, lj.y, arow[j0 + 1]);
-            if constexpr (WV >= 3)
-              if ((j0 & 7) == 6) __builtin_amdgcn_sched_barrier(0);      // at most four 128-bit loads in flight
+          for (int j0 = jf & ~1; j0 < NU; j0 += 2) {
+            const double2 v = lj[(j0 >> 1) % JN];
+            if (j0 >= jf) arow[j0] = fma(-lprev, v.x, arow[j0]);
+            if (j0 + 1 < NU) arow[j0 + 1] = fma(-lprev, v.y, arow[j0 + 1]);
           }
         }
+        lprev = l;
       }
       // Park the strictly lower part of row `lane`, SCALED BY 1/L_ii, in the zero-padded LDS matrix: Lf[i][k] = L[i][k]/L[i][i].
       // Both substitutions then run without a multiplication on their serial chain:
