@@ -1077,10 +1077,18 @@ void nrmp_qp_kernel(
       //   L'x = y :  z_i = y_i      - sum_{k>i} Lf[k][i] z_k,  z = diag(L) x,  x_i = z_i/L_ii   (column i of Lf)
       LSYNC();
       myinv = invd[ar];
+      // (every lane of the matrix stores its whole row, zeros on and above the diagonal: one exec region and selects.  The
+      // predicated form -- `if (c < lane) store` -- compiled to a branch per column with a wait for the previous store
+      // ahead of each: 19 serialised LDS round trips, ~1 300 cycles per factorisation)
       if (lane < NU) {
+        double* Lr = Km + lane * ldk;
+        int lo = lane;
+        asm volatile("" : "+v"(lo));       // (opaque: else the 19 lane masks are hoisted out of the solver loop, spilled, and reloaded)
 #pragma unroll
-        for (int c = 0; c < NU - 1; ++c)
-          if (c < lane) Km[lane * ldk + c] = arow[c] * myinv;
+        for (int c = 0; c < NU - 1; ++c) {
+          const double v = arow[c] * myinv;
+          Lr[c] = c < lo ? v : 0.0;
+        }
       }
       LSYNC();
     } else {
