@@ -170,6 +170,33 @@ __device__ __forceinline__ double scan_next(double v, int lane) {
   }
   return x;
 }
+// Two / three scans at once, step-major.  A wave alone on its SIMD issues one instruction per four cycles whatever its kind,
+// and between a step's v_add_f64 and the next step's DPP read of the same register the hardware wants two wait states: a
+// single scan pays an s_nop per step for them, interleaved scans fill the slots with each other's instructions.
+#define QP_SCAN_STEP2(CT) do { a += dpp0_f64<CT>(a); __builtin_amdgcn_sched_barrier(0); b += dpp0_f64<CT>(b); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define QP_SCAN_STEP3(CT) do { a += dpp0_f64<CT>(a); __builtin_amdgcn_sched_barrier(0); b += dpp0_f64<CT>(b); __builtin_amdgcn_sched_barrier(0); \
+                               c += dpp0_f64<CT>(c); __builtin_amdgcn_sched_barrier(0); } while (0)
+template <bool WIDE>
+__device__ __forceinline__ void scan_prefix2(double& a, double& b) {
+  __builtin_amdgcn_sched_barrier(0);
+  QP_SCAN_STEP2(0x111); QP_SCAN_STEP2(0x112); QP_SCAN_STEP2(0x114); QP_SCAN_STEP2(0x118);
+  if constexpr (WIDE) {
+    a += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(a), 0x142, 0xA, 0xF, false), __builtin_amdgcn_update_dpp(0, __double2loint(a), 0x142, 0xA, 0xF, false));
+    b += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(b), 0x142, 0xA, 0xF, false), __builtin_amdgcn_update_dpp(0, __double2loint(b), 0x142, 0xA, 0xF, false));
+  }
+}
+template <bool WIDE>
+__device__ __forceinline__ void scan_suffix2(double& a, double& b, double row0) {
+  __builtin_amdgcn_sched_barrier(0);
+  QP_SCAN_STEP2(0x101); QP_SCAN_STEP2(0x102); QP_SCAN_STEP2(0x104); QP_SCAN_STEP2(0x108);
+  if constexpr (WIDE) { a = fma(row0, readlane_f64(a, 16), a); b = fma(row0, readlane_f64(b, 16), b); }
+}
+template <bool WIDE>
+__device__ __forceinline__ void scan_suffix3(double& a, double& b, double& c, double row0) {
+  __builtin_amdgcn_sched_barrier(0);
+  QP_SCAN_STEP3(0x101); QP_SCAN_STEP3(0x102); QP_SCAN_STEP3(0x104); QP_SCAN_STEP3(0x108);
+  if constexpr (WIDE) { a = fma(row0, readlane_f64(a, 16), a); b = fma(row0, readlane_f64(b, 16), b); c = fma(row0, readlane_f64(c, 16), c); }
+}
 // a wave-uniform double made provably uniform (both halves through v_readfirstlane): the compiler may then keep it in a
 // scalar register pair -- and, when it runs short of those, park it in a lane of a spill VGPR (v_readlane to fetch it)
 // instead of sending a whole vector register to scratch memory
@@ -179,15 +206,28 @@ __device__ __forceinline__ double uni64(double v) {
 struct OpSum { __device__ static double f(double a, double b) { return a + b; } };
 struct OpMax { __device__ static double f(double a, double b) { return fmax(a, b); } };
 struct OpMin { __device__ static double f(double a, double b) { return fmin(a, b); } };
-// full-wave reduction; every lane returns the same bits (the combination tree is symmetric)
+// full-wave reduction, the same bits in every lane: four butterfly steps inside the 16-lane rows (every lane is a valid
+// source: bound_ctrl spares the compiler the zero-initialised destination it otherwise builds per step), then the row
+// totals travel up with row_bcast:15 (lane 15 of a row -> the next row) and row_bcast:31 (lane 31 -> rows 2, 3): LANE 63
+// ends up with all four, and only lane 63 is read (what the two steps leave in rows 0 - 2 is not a total and is not used)
 template <class Op>
 __device__ __forceinline__ double wave_reduce(double v) {
-  v = Op::f(v, dpp_f64<0xB1>(v));     // quad_perm [1,0,3,2]
-  v = Op::f(v, dpp_f64<0x4E>(v));     // quad_perm [2,3,0,1]
-  v = Op::f(v, dpp_f64<0x141>(v));    // row_half_mirror
-  v = Op::f(v, dpp_f64<0x140>(v));    // row_mirror -> every lane holds its 16-lane row total
-  double a = readlane_f64(v, 0), b = readlane_f64(v, 16), c = readlane_f64(v, 32), d = readlane_f64(v, 48);
-  return Op::f(Op::f(a, b), Op::f(c, d));
+  v = Op::f(v, dpp0_f64<0xB1>(v));     // quad_perm [1,0,3,2]
+  v = Op::f(v, dpp0_f64<0x4E>(v));     // quad_perm [2,3,0,1]
+  v = Op::f(v, dpp0_f64<0x141>(v));    // row_half_mirror
+  v = Op::f(v, dpp0_f64<0x140>(v));    // row_mirror -> every lane holds its 16-lane row total
+  v = Op::f(v, dpp0_f64<0x142>(v));    // row 3: r3 + r2   (row 1: r1 + r0)
+  v = Op::f(v, dpp0_f64<0x143>(v));    // row 3: + (r1 + r0)
+  return readlane_f64(v, 63);
+}
+// two independent reductions, step-major (see QP_SCAN_STEP2: each fills the other's wait states)
+template <class OpA, class OpB>
+__device__ __forceinline__ void wave_reduce2(double& a, double& b) {
+#define QP_RED_STEP2(CT) do { a = OpA::f(a, dpp0_f64<CT>(a)); __builtin_amdgcn_sched_barrier(0); b = OpB::f(b, dpp0_f64<CT>(b)); __builtin_amdgcn_sched_barrier(0); } while (0)
+  __builtin_amdgcn_sched_barrier(0);
+  QP_RED_STEP2(0xB1); QP_RED_STEP2(0x4E); QP_RED_STEP2(0x141); QP_RED_STEP2(0x140); QP_RED_STEP2(0x142); QP_RED_STEP2(0x143);
+#undef QP_RED_STEP2
+  a = readlane_f64(a, 63); b = readlane_f64(b, 63);
 }
 __device__ __forceinline__ double fast_rcp(double x) {      // ~1 ulp; x finite, nonzero
   double r = __builtin_amdgcn_rcp(x);
@@ -627,7 +667,8 @@ void nrmp_qp_kernel(
       const double th = scan_prefix<WIDE>(bu2), thx = th - bu2;               // theta_{t+1}, theta_t
       const double i0 = on ? fma(a01.x, thx, b0.x * vt.x + b0.y * vt.y) : 0.0;
       const double i1 = on ? fma(a01.y, thx, b1.x * vt.x + b1.y * vt.y) : 0.0;
-      const double x = scan_prefix<WIDE>(i0), y = scan_prefix<WIDE>(i1);
+      double x = i0, y = i1;
+      scan_prefix2<WIDE>(x, y);
       if (on) { out3[3 * t] = x; out3[3 * t + 1] = y; out3[3 * t + 2] = th; }
       return;
     }
@@ -652,7 +693,8 @@ void nrmp_qp_kernel(
       const bool on = lane < TT;
       const int t = on ? lane : 0;
       const double q0 = on ? in3[3 * t] : 0.0, q1 = on ? in3[3 * t + 1] : 0.0, q2 = on ? in3[3 * t + 2] : 0.0;
-      const double l0 = scan_suffix<WIDE>(q0, row0), l1 = scan_suffix<WIDE>(q1, row0);
+      double l0 = q0, l1 = q1;
+      scan_suffix2<WIDE>(l0, l1, row0);
       const double2 an = ld2(Abc + (t + 1 < TT ? t + 1 : t) * QP_ABC_LD);         // a of step t+1 (meets l = 0 at the last step)
       const double l2 = scan_suffix<WIDE>(on ? q2 + an.x * scan_next<WIDE>(l0, lane) + an.y * scan_next<WIDE>(l1, lane) : 0.0, row0);
       const double* o = Abc + t * QP_ABC_LD;
@@ -869,9 +911,11 @@ void nrmp_qp_kernel(
       r1u += ct_mul(lc, a);
     }
     PROF_B(5);
-    const double mu = wave_reduce<OpSum>(gap) * inv_m;
-    // scaled dual and primal residuals in ONE max reduction (scaling is monotone: max of scaled = scaled max)
-    const double rmax = wave_reduce<OpMax>(fmax(fmax(lane < nu ? fabs(r1u) : 0.0, r1dmax) * iscale_d, rpmax * iscale_p));
+    // scaled dual and primal residuals in ONE max reduction (scaling is monotone: max of scaled = scaled max), side by side
+    // with the sum of the complementarity products
+    double gsum = gap, rmax = fmax(fmax(lane < nu ? fabs(r1u) : 0.0, r1dmax) * iscale_d, rpmax * iscale_p);
+    wave_reduce2<OpSum, OpMax>(gsum, rmax);
+    const double mu = gsum * inv_m;
     const double merit = fmax(rmax, mu);
     last_mu = mu;
 #ifdef NPA_QP_DBGTRACE
@@ -943,8 +987,9 @@ void nrmp_qp_kernel(
           const double c0 = on ? cp.x : 0.0, c1 = on ? cp.y : 0.0;
           const double s00 = on ? S0r + W0 : 0.0, s01 = on ? S1r : 0.0, s11 = on ? S2r + W1 : 0.0;
           const double sc0 = s00 * c0 + s01 * c1, sc1 = s01 * c0 + s11 * c1;
-          const double p00 = scan_suffix<WIDE>(s00, row0), p01 = scan_suffix<WIDE>(s01, row0), p11 = scan_suffix<WIDE>(s11, row0);
-          const double t0 = scan_suffix<WIDE>(sc0, row0), t1 = scan_suffix<WIDE>(sc1, row0), t2 = scan_suffix<WIDE>(c0 * sc0 + c1 * sc1, row0);
+          double p00 = s00, p01 = s01, p11 = s11, t0 = sc0, t1 = sc1, t2 = c0 * sc0 + c1 * sc1;
+          scan_suffix3<WIDE>(p00, p01, p11, row0);
+          scan_suffix3<WIDE>(t0, t1, t2, row0);
           const double u0 = p00 * c0 + p01 * c1, u1 = p01 * c0 + p11 * c1;
           if (on) {
             st2(Pst + lane * 6, p00, p01);
@@ -998,14 +1043,26 @@ void nrmp_qp_kernel(
           // that nobody reads, as before
           const double2 ci = ld2(cpre + 2 * i);
           const double G2 = g2 + g0 * ci.x + g1 * ci.y;
+          // (software pipeline of depth one: step r + 1's five loads go out before step r's arithmetic -- with the loads
+          // and their use in the same step every step waited a full LDS latency, ~1 000 of this phase's 1 450 cycles; a
+          // deeper prefetch does not fit the register file here, where the demand of the kernel peaks)
+          const double* hrow = Hm + ar * (ar + 1) / 2;
+          double2 nb0 = ld2(Abc + 2), nb1 = ld2(Abc + 4), nb2 = ld2(Abc + 6), ncr = ld2(cpre);
+          double nh0 = hrow[0], nh1 = hrow[1];
 #pragma unroll
           for (int r = 0; r < TT; ++r) {
-            const double* o = Abc + r * QP_ABC_LD;
-            const double2 bb0 = ld2(o + 2), bb1 = ld2(o + 4), bb2 = ld2(o + 6), cr = ld2(cpre + 2 * r);
+            const double2 bb0 = nb0, bb1 = nb1, bb2 = nb2, cr = ncr;
+            const double h0 = nh0, h1 = nh1;
+            if (r + 1 < TT) {
+              const double* o = Abc + (r + 1) * QP_ABC_LD;
+              nb0 = ld2(o + 2); nb1 = ld2(o + 4); nb2 = ld2(o + 6); ncr = ld2(cpre + 2 * (r + 1));
+              nh0 = hrow[2 * r + 2]; nh1 = hrow[2 * r + 3];
+            }
+            __builtin_amdgcn_sched_barrier(0);
             const double e = G2 - (g0 * cr.x + g1 * cr.y);
-            arow[2 * r] = fma(g0, bb0.x, fma(g1, bb1.x, fma(e, bb2.x, Hm[ar * (ar + 1) / 2 + 2 * r])));
-            arow[2 * r + 1] = fma(g0, bb0.y, fma(g1, bb1.y, fma(e, bb2.y, Hm[ar * (ar + 1) / 2 + 2 * r + 1])));
-            if ((r & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+            arow[2 * r] = fma(g0, bb0.x, fma(g1, bb1.x, fma(e, bb2.x, h0)));
+            arow[2 * r + 1] = fma(g0, bb0.y, fma(g1, bb1.y, fma(e, bb2.y, h1)));
+            __builtin_amdgcn_sched_barrier(0);
           }
         } else {
         const double* Ph = Phi + (size_t)i * 3 * ldp;  // Phi_i rows (zero beyond column 2i+1)
