@@ -53,10 +53,12 @@
 #ifndef QP_CHOL_LOOK
 #define QP_CHOL_LOOK 3         // columns behind the pivot whose trailing update is broadcast with v_readlane (the rest: LDS, one pivot late)
 #endif
+#define QP_RETRY_MERIT 1e-9    // a cold solve that ends above this is repeated once from round 2's start (unit multipliers)
 #define QP_SIGMA_MU_MIN 1e-15  // floor of the centring target: a gap driven to 1e-20 leaves the Newton matrix too ill
                                //   conditioned for the residuals to follow (solves that ended at 1e-11: 8 -> 1 of 640)
 #define QP_WARM_STEP 0.1       // largest control change of the previous solve after which its result is reused
-// the cold starting point: u = 0, d mid-range, slacks >= 1, multipliers QP_START_MU / slack (a macro: used before the loop and, in the
+// the cold starting point: u = 0, d mid-range, slacks >= 1, multipliers QP_START_MU / slack -- or, for the SECOND cold attempt
+// of a solve whose first one jammed (cold_alt), unit multipliers, round 2's start -- (a macro: used before the loop and, in the
 // instantiations with warm start, again at the loop top when a warm attempt is dropped)
 #define QP_COLD_INIT()                                                                            \
   do {                                                                                            \
@@ -67,7 +69,7 @@
       const double cx = p >= npu ? d0 : 0.0;      /* c'x at the cold point */                     \
       const bool on = c.actf != 0.0;                                                              \
       const double w0p = on ? fmax(c.bp - cx, 1.0) : 1.0, w0m = on ? fmax(c.bm + cx, 1.0) : 1.0;  \
-      st2(lc + 2 * p, c.actf * QP_START_MU * fast_rcp(w0p), c.actf * QP_START_MU * fast_rcp(w0m)); \
+      st2(lc + 2 * p, c.actf * (cold_alt ? 1.0 : QP_START_MU * fast_rcp(w0p)), c.actf * (cold_alt ? 1.0 : QP_START_MU * fast_rcp(w0m))); \
       ST_ROW(Rwc, wc, p, w0p, w0m);                                                               \
       ST_ROW(Rdlc, dlc, p, 0.0, 0.0); st2(dwc + 2 * p, 0.0, 0.0);                                 \
     }                                                                                             \
@@ -76,16 +78,17 @@
       if (lane < mf / 2) {                                                                        \
         /* the hinge slack contains its own multiplier (w = F x - f + l/ro): one fixed-point round */ \
         const double hx = -d0 - Rff.x, hy = -d0 - Rff.y;                                          \
-        const double l0x = QP_START_MU * fast_rcp(fmax(hx + iro, 1.0)), l0y = QP_START_MU * fast_rcp(fmax(hy + iro, 1.0)); \
+        const double l0x = cold_alt ? 1.0 : QP_START_MU * fast_rcp(fmax(hx + iro, 1.0));          \
+        const double l0y = cold_alt ? 1.0 : QP_START_MU * fast_rcp(fmax(hy + iro, 1.0));          \
         Rwf = make_double2(fmax(hx + l0x * iro, 1.0), fmax(hy + l0y * iro, 1.0));                 \
-        st2(lf + 2 * lane, QP_START_MU * fast_rcp(Rwf.x), QP_START_MU * fast_rcp(Rwf.y));         \
+        st2(lf + 2 * lane, cold_alt ? 1.0 : QP_START_MU * fast_rcp(Rwf.x), cold_alt ? 1.0 : QP_START_MU * fast_rcp(Rwf.y)); \
       }                                                                                           \
     } else {                                                                                      \
       for (int i = lane; i < mf; i += QP_THREADS) {                                               \
         const double hx = -d0 - ff[i];        /* F x - f at u = 0 */                              \
-        const double l0x = QP_START_MU * fast_rcp(fmax(hx + iro, 1.0));                           \
+        const double l0x = cold_alt ? 1.0 : QP_START_MU * fast_rcp(fmax(hx + iro, 1.0));          \
         wf[i] = fmax(hx + l0x * iro, 1.0);                                                        \
-        lf[i] = QP_START_MU * fast_rcp(wf[i]);                                                    \
+        lf[i] = cold_alt ? 1.0 : QP_START_MU * fast_rcp(wf[i]);                                   \
       }                                                                                           \
     }                                                                                             \
     LSYNC();                                                                                      \
@@ -604,6 +607,9 @@ void nrmp_qp_kernel(
     const PairC c = PAIR_C(p);
     if (c.actf != 0.0) { cmax = fmax(cmax, fabs(c.bp)); m_act += 2.0; }
   }
+  // the cold attempt in progress starts from unit multipliers: the second attempt of a forward solve -- and every solve of the
+  // BWD instantiations (one start, the one that never jammed; a restart path there costs registers the adjoint needs)
+  bool cold_alt = BWD;
   QP_COLD_INIT();
   double gmax = obs ? (double)P.eta : 0.0;
   // g_u = Phi' lin - 2 p_u gamma_b on the speed entries
@@ -766,7 +772,7 @@ void nrmp_qp_kernel(
   const bool can_warm = WARM && wrm && flags && flags[b * 4 + 2];
   PROF(0);
   bool adj = false;                      // BWD: the pass below is the adjoint solve
-  int it_total = 0, warm_code = 0;       // diagnostics: iterations over both attempts; 1 warm start used, 2 / 3 dropped at it 0 / 6, 4 not converged
+  int it_total = 0, warm_code = 0;       // diagnostics: iterations over all attempts; 1 warm start used, 2 / 3 dropped at it 0 / 6, 4 not converged, 5 cold retry
   bool warm_now = can_warm;              // the solve in progress started from the previous solution
   bool need_cold = false;                // re-initialise at the top of the next iteration (a dropped warm attempt)
   if (WARM && warm_now) {
@@ -805,7 +811,7 @@ void nrmp_qp_kernel(
   }
   for (it = 0; it <= QP_MAX_IT; ++it) {
     if constexpr (WARM) {
-      if (need_cold) {                     // restart of a dropped warm attempt: the cold start again
+      if (need_cold) {                     // restart of a dropped warm attempt, or of a jammed cold one: the cold start again
         need_cold = false;
         QP_COLD_INIT();
         best_merit = 1e300; last_mu = 0; best_it = 0; stall = 0; status = 0;
@@ -952,6 +958,17 @@ void nrmp_qp_kernel(
         if (warm_now && !(best_merit <= 1e-10)) {      // a warm-started solve that did not converge: once more, cold
           warm_code = 4;
           it_total += it; warm_now = false; need_cold = true;
+          it = -1;
+          continue;
+        }
+      }
+      // A cold solve that JAMMED (three non-improving iterations far from convergence: a step that landed on the boundary
+      // too early; one scene in 96 of the acker workload with the centred start, none with round 2's) gets one more
+      // attempt from the other starting point.  qp_info[15] = 5 records it.
+      if constexpr (WARM) {
+        if (!cold_alt && !(best_merit <= QP_RETRY_MERIT)) {
+          cold_alt = true; warm_code = 5;
+          it_total += it; need_cold = true;
           it = -1;
           continue;
         }
@@ -1206,6 +1223,9 @@ void nrmp_qp_kernel(
     if (!chol_ok) {
       if constexpr (WARM) {
         if (warm_now && !(best_merit <= 1e-10)) { warm_code = 4; it_total += it; warm_now = false; need_cold = true; it = -1; continue; }
+      }
+      if constexpr (WARM) {
+        if (!cold_alt && !(best_merit <= QP_RETRY_MERIT)) { cold_alt = true; warm_code = 5; it_total += it; need_cold = true; it = -1; continue; }
       }
       status = best_merit <= 1e-11 ? 0 : 3;
       break;
@@ -1503,6 +1523,7 @@ void nrmp_qp_kernel(
   LSYNC();
   it_total += it;
   if (warm_now) warm_code = 1;
+  if (status == 0 && !(best_merit <= QP_RETRY_MERIT)) status = 4;      // both cold attempts ended short of convergence
 
   if (bw.dbg_x)
     for (int a = lane; a < nu + T; a += QP_THREADS) bw.dbg_x[(size_t)b * (nu + T) + a] = (a < nu || obs) ? xbest[a] : 0.0;

@@ -85,14 +85,16 @@ STEP_ETA = 0.995        # fraction of the step to the boundary: max(STEP_ETA, 1 
 STEP_CAP = 1e-6
 START_MU = 3.0          # cold start: multipliers = START_MU / slack
 SIGMA_MU_MIN = 1e-15    # floor of the centring target sigma * mu
+RETRY_MERIT = 1e-9      # a cold solve that ends above this is repeated once with unit multipliers (round 2's start)
 
 
-def solve_condensed(pb: NrmpProblem, tol=1e-14, max_iter=40, trace=None, warm=None):
+def solve_condensed(pb: NrmpProblem, tol=1e-14, max_iter=40, trace=None, warm=None, _alt=False):
     """warm = (x, lc, lf) of a previous, similar solve: the kernel's warm start across the PAN
     iterations of one forward call (multipliers and slacks floored at WARM_DELTA), with the kernel's drop rules: the
     attempt is abandoned for a cold start at iteration 0 / 6 when its merit is above WARM_DROP, and a warm-started
     solve that ends above WARM_ACCEPT is repeated cold.  info["warm_code"]: 0 cold, 1 warm start used, 2 / 3 dropped at
-    iteration 0 / later, 4 not converged (qp_info[15] of the kernel)."""
+    iteration 0 / later, 4 not converged, 5 a cold solve that jammed and was repeated from unit multipliers (qp_info[15] of
+    the kernel)."""
     H, g, F, f, C, c, Phi, cv = condense(pb)
     n = H.shape[0]; T = pb.T; nu = 2 * T
     ro = pb.ro_obs
@@ -107,7 +109,7 @@ def solve_condensed(pb: NrmpProblem, tol=1e-14, max_iter=40, trace=None, warm=No
     wc = np.maximum(c - C @ x, 1.0)
     hx = F @ x - f
     wf = np.maximum(hx + 1.0 / ro, 1.0)
-    if START_MU is None:                # (round 2's start, unit multipliers: only tests/tools/qp_step_study.py sets this)
+    if START_MU is None or _alt:        # round 2's start, unit multipliers: the second attempt of a jammed cold solve (and the study tool)
         lc = np.ones(mc); lf = np.ones(mf)
     else:
         lc = START_MU / wc
@@ -179,6 +181,11 @@ def solve_condensed(pb: NrmpProblem, tol=1e-14, max_iter=40, trace=None, warm=No
     if warm is not None and not best[0] <= WARM_ACCEPT:
         out = solve_condensed(pb, tol=tol, max_iter=max_iter, trace=trace)
         out[3]["warm_code"] = 4
+        out[3]["iters_total"] = out[3]["iters_total"] + it
+        return out
+    if warm is None and not _alt and START_MU is not None and not best[0] <= RETRY_MERIT:      # jammed: the other start, once
+        out = solve_condensed(pb, tol=tol, max_iter=max_iter, trace=trace, _alt=True)
+        out[3]["warm_code"] = 5
         out[3]["iters_total"] = out[3]["iters_total"] + it
         return out
     merit, x, it_used = best

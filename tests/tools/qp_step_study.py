@@ -17,14 +17,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 WORK = ("diff_1k_T10_K10", "acker_2k_T20_K15", "dyna_4k_T10_K10", "poly8_5k_T10_K10")
-ROUND2 = dict(STEP_CAP=0.005, START_MU=None, SIGMA_MU_MIN=0.0, WARM_DELTA=0.01, WARM_DROP={0: 0.05, 3: 1e-4, 7: 1e-8})
+ROUND2 = dict(STEP_CAP=0.005, START_MU=None, SIGMA_MU_MIN=0.0, WARM_DELTA=0.01, WARM_DROP={0: 0.05, 3: 1e-4, 7: 1e-8}, RETRY_MERIT=float("inf"))
 SHIPPED = {}
 RULES = [("round 2 (eta = 0.995, unit multipliers, floor 0.01, drops at 0 / 3 / 7)", ROUND2),
          ("+ centring target >= 1e-15", {**ROUND2, "SIGMA_MU_MIN": 1e-15}),
          ("+ eta = max(0.995, 1 - mu) <= 1 - 1e-6", {**ROUND2, "SIGMA_MU_MIN": 1e-15, "STEP_CAP": 1e-6}),
          ("+ multipliers 3 / slack at the cold start", {**ROUND2, "SIGMA_MU_MIN": 1e-15, "STEP_CAP": 1e-6, "START_MU": 3.0}),
          ("+ warm floor 0.003", {**ROUND2, "SIGMA_MU_MIN": 1e-15, "STEP_CAP": 1e-6, "START_MU": 3.0, "WARM_DELTA": 0.003}),
-         ("+ drops at 0 / 6 only  = SHIPPED", SHIPPED),
+         ("+ drops at 0 / 6 only", {"RETRY_MERIT": float("inf")}),
+         ("+ a cold solve that ends above 1e-9 is repeated from unit multipliers  = SHIPPED", SHIPPED),
          ("shipped, but no cap on eta", {"STEP_CAP": 0.0}),
          ("shipped, but warm floor 0.001", {"WARM_DELTA": 0.001}),
          ("shipped, but warm floor 0.01", {"WARM_DELTA": 0.01}),
@@ -49,7 +50,7 @@ def job(arg):
         return r
     orc.nrmp = hook
     orc.forward(sc["nom_s"], sc["nom_u"], sc["ref_s"], sc["ref_us"], sc["points"], sc["velocities"])
-    shipped = {k: getattr(ci, k) for k in ("STEP_ETA", "STEP_CAP", "START_MU", "SIGMA_MU_MIN", "WARM_DELTA", "WARM_DROP")}
+    shipped = {k: getattr(ci, k) for k in ("STEP_ETA", "STEP_CAP", "START_MU", "SIGMA_MU_MIN", "WARM_DELTA", "WARM_DROP", "RETRY_MERIT")}
     out = []
     for _, rules in RULES:
         for k, v in {**shipped, **rules}.items():
@@ -123,15 +124,15 @@ def main():
     with ProcessPoolExecutor(procs, mp_context=mp.get_context("spawn")) as ex:
         res = list(ex.map(job, [(w, b) for w in WORK for b in range(n)]))
     lines = [f"interior-point iterations per QP over the oracle's PAN loop, {n} scenes per workload, every QP of every scene (tests/tools/qp_step_study.py)",
-             "columns: mean / max over all QPs | mean / max over the LAST QP of a call | solves by warm code (0 cold, 1 warm used, 2 / 3 dropped at the first / a later checkpoint, 4 repeated cold) | solves that end above 1e-12"]
+             "columns: mean / max over all QPs | mean / max over the LAST QP of a call | solves by warm code (0 cold, 1 warm used, 2 / 3 dropped at the first / a later checkpoint, 4 repeated cold, 5 cold retry) | solves that end above 1e-12, largest final merit"]
     for w in WORK:
         lines.append(w)
         for i, (label, _) in enumerate(RULES):
             rows = [r for name, out in res if name == w for r in out[i]]
             last = [out[i][-1][0] for name, out in res if name == w]
             it = np.array([r[0] for r in rows]); code = np.array([r[1] for r in rows]); bad = sum(r[2] > 1e-12 for r in rows)
-            by = " ".join(f"{c}:{(code == c).sum()}x{it[code == c].mean():.1f}" for c in range(5) if (code == c).any())
-            lines.append(f"  {label:82s} {it.mean():6.2f} /{it.max():3d} | {np.mean(last):6.2f} /{max(last):3d} | {by} | {bad}")
+            by = " ".join(f"{c}:{(code == c).sum()}x{it[code == c].mean():.1f}" for c in range(6) if (code == c).any())
+            lines.append(f"  {label:82s} {it.mean():6.2f} /{it.max():3d} | {np.mean(last):6.2f} /{max(last):3d} | {by} | {bad}, {max(r[2] for r in rows):.1e}")
     txt = "\n".join(lines)
     print(txt)
     with open(os.path.join(ROOT, "profiles", "r03_qp_step_study.txt"), "w") as f:
