@@ -581,7 +581,7 @@ def test_warm_started_qp_equals_cold_qp(cfgname, scenes, monkeypatch):
     cold = make_gpu_pan(cfg)
     uc = cold.forward_batch(*args)["opt_u"].cpu().numpy()
     info_c = cold.last_qp_info()
-    assert (info_c[:, 15] == 0).all(), "NPA_QP_COLD=1 must disable the warm start"
+    assert np.isin(info_c[:, 15], (0, 5)).all(), "NPA_QP_COLD=1 must disable the warm start"      # (5: a jammed cold solve, repeated)
     assert (info_w[:, 15] > 0).any(), "no scene took the warm start: the test does not exercise it"
     assert (info_w[:, 3] == 0).all() and (info_c[:, 3] == 0).all()          # solver status: converged
     err = np.linalg.norm((uw - uc).reshape(scenes, -1), axis=1)
