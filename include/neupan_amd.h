@@ -128,7 +128,15 @@ size_t npa_state_bytes(const npa_handle *h, int batch);
  * (int32): the layout of npa_dune_stage's outputs, so a gradient pass can reuse them instead of re-running the stage. */
 int npa_workspace_layout(const npa_handle *h, int batch, size_t *out, int n);
 /* Byte offset inside the workspace of the per-scene QP diagnostics written by the last NRMP launch
- * of npa_forward_batch: [B][16] doubles (best iteration, merit, mu, status, iterations run, ...). */
+ * of npa_forward_batch: [B][16] doubles per scene:
+ *   [0] iteration of the iterate that was kept   [1] its merit (max of the scaled KKT residuals and the gap)   [2] last mu
+ *   [3] solver status: 0 converged, 2 non-finite data, 3 factorisation lost positive definiteness above 1e-11,
+ *       4 ended above 1e-9 after both cold attempts
+ *   [4] interior-point iterations of the last attempt   [14] iterations over all attempts of the solve
+ *   [15] how the solve started: 0 cold, 1 from the previous PAN iteration's solution (warm), 2 / 3 a warm attempt refused at
+ *       iteration 0 / dropped at iteration 6 and restarted cold, 4 a warm attempt that ended above 1e-10 and was repeated
+ *       cold, 5 a cold attempt that jammed and was repeated from unit multipliers
+ *   [5..13] per-phase cycle counters of the -DNPA_QP_PROF builds (0 otherwise). */
 size_t npa_workspace_qp_info_offset(const npa_handle *h, int batch);
 
 /* Replaces PAN.forward (pan.py:109-147) for `batch` independent scenes:

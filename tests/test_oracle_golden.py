@@ -232,3 +232,36 @@ def test_condensed_solver_warm_start_rules():
                 s2, u2, d2, info2 = solve_condensed(pb, warm=sj)
                 np.testing.assert_allclose(u2, u0, atol=2e-6)
     assert fewer >= 6, fewer
+
+
+def test_condensed_solver_repeats_a_jammed_cold_solve():
+    """Scene 66 of the acker workload: from the centred cold start (multipliers 3 / slack) the interior-point method jams --
+    a step lands on the boundary too early, three non-improving iterations end the solve at 3e-6 -- while unit multipliers
+    go through.  oracle/condensed_ipm.py carries the kernel's rule (nrmp_qp.hip, QP_RETRY_MERIT): a cold solve that ends
+    above 1e-9 is repeated once from unit multipliers (warm_code 5).  The solution is the uncondensed oracle's."""
+    from neupan_amd.scenes import make_scene
+    from oracle import condensed_ipm as ci
+    cfg = CONFIGS["acker_2k_T20_K15"]
+    sc = make_scene(cfg, 66)
+    orc = make_oracle(cfg, iter_num=5)
+    pbs = []
+    orig = orc.nrmp
+
+    def hook(*a):
+        r = orig(*a)
+        pbs.append(orc.last_problem)
+        return r
+    orc.nrmp = hook
+    orc.forward(sc["nom_s"], sc["nom_u"], sc["ref_s"], sc["ref_us"], sc["points"], sc["velocities"])
+    pb = pbs[-1]
+    s, u, d, info = solve_condensed(pb)
+    assert info["warm_code"] == 5 and info["merit"] <= 1e-12, info
+    old = ci.RETRY_MERIT
+    try:
+        ci.RETRY_MERIT = float("inf")                     # without the rule: the jam
+        s1, u1, d1, info1 = solve_condensed(pb)
+    finally:
+        ci.RETRY_MERIT = old
+    assert info1["warm_code"] == 0 and info1["merit"] > 1e-9, info1
+    s0, u0, d0 = solve_nrmp_qp(pb)
+    np.testing.assert_allclose(u, u0, atol=5e-5)          # (acker QPs are flat in the steering direction: DESIGN.md section 5)
