@@ -1,0 +1,119 @@
+"""CPU study for the NEXT step of the QP kernel: a primal-dual active-set iteration for the warm-started solves.
+
+Once the PAN loop has settled, iteration k + 1 solves nearly the QP of iteration k; the interior-point method of
+nrmp_qp.hip then needs ~4 iterations (one factorisation and two solves each) from the previous solution.  The problem is
+a strictly convex QP with squared-hinge terms and simple linear rows (bounds on u and d, rate limits):
+
+    min 1/2 x'Hx + g'x + ro/2 |max(0, f - F x)|^2      s.t.  C x <= c .
+
+Given the previous solve's x and multipliers, guess the hinge rows that are on (f - F x > 0) and the linear rows that are
+tight (lam + (C x - c) > 0), solve the equality-constrained QP of that guess exactly -- ONE factorisation and one solve --
+and repeat until the guess reproduces itself: then the KKT conditions hold exactly.  This tool replays that on every QP
+the oracle's PAN loop produces (condensed exactly as the kernel condenses it, oracle/condensed_ipm.py), started from the
+previous PAN iteration's solution under the kernel's warm-start gate, and reports how often and how fast it converges.
+
+    python tests/tools/qp_active_set_study.py [scenes per workload] [procs]    -> profiles/r03_qp_active_set_study.txt
+
+Nothing of this is in the product; DESIGN.md section 7 lists it as the next algorithmic step."""
+import os, sys
+for _k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+    os.environ.setdefault(_k, "1")
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+WORK = ("diff_1k_T10_K10", "acker_2k_T20_K15", "dyna_4k_T10_K10", "poly8_5k_T10_K10")
+
+
+def active_set_solve(H, g, F, f, C, c, ro, x, lam, max_it=8):
+    """-> x, lam, factorisations, converged"""
+    n = H.shape[0]
+    prev = None
+    for it in range(max_it + 1):
+        on = (f - F @ x) > 0
+        tight = (lam + (C @ x - c)) > 0
+        key = (on.tobytes(), tight.tobytes())
+        if key == prev:
+            return x, lam, it, True
+        if it == max_it:
+            break
+        prev = key
+        K = H + ro * F[on].T @ F[on]
+        rhs = -g + ro * F[on].T @ f[on]
+        CA = C[tight]; m = CA.shape[0]
+        try:
+            if m:
+                sol = np.linalg.solve(np.block([[K, CA.T], [CA, np.zeros((m, m))]]), np.concatenate([rhs, c[tight]]))
+                x = sol[:n]; lam = np.zeros(C.shape[0]); lam[tight] = sol[n:]
+            else:
+                x = np.linalg.solve(K, rhs); lam = np.zeros(C.shape[0])
+        except np.linalg.LinAlgError:           # dependent tight rows
+            break
+    return x, lam, max_it, False
+
+
+def job(arg):
+    name, b = arg
+    from helpers import CONFIGS, make_oracle
+    from neupan_amd.scenes import make_scene
+    from oracle import condensed_ipm as ci
+    cfg = CONFIGS[name]
+    sc = make_scene(cfg, b)
+    orc = make_oracle(cfg)
+    pbs = []
+    orig = orc.nrmp
+
+    def hook(*a):
+        r = orig(*a)
+        pbs.append(orc.last_problem)
+        return r
+    orc.nrmp = hook
+    orc.forward(sc["nom_s"], sc["nom_u"], sc["ref_s"], sc["ref_us"], sc["points"], sc["velocities"])
+    rows = []
+    prev = None; prev_u = None
+    for k, pb in enumerate(pbs):
+        H, g, F, f, C, c, Phi, cv = ci.condense(pb)
+        s, u, d, info = ci.solve_condensed(pb)                     # the cold interior-point solve: the reference point
+        x_ref, lc_ref, lf_ref = info["warm"]
+        nu = 2 * pb.T
+        step = float(np.abs(u - prev_u).max()) if prev_u is not None else 9.0
+        if prev is not None and prev["merit"] <= 1e-12 and prev["step"] < 0.1:          # the kernel's warm-start gate
+            x, lam, fac, ok = active_set_solve(H, g, F, f, C, c, pb.ro_obs, prev["warm"][0].copy(), prev["warm"][1].copy())
+            sw, uw, dw, iw = ci.solve_condensed(pb, warm=prev["warm"])
+            e = np.maximum(f - F @ x, 0)
+            kkt = max(np.abs(H @ x + g - pb.ro_obs * F.T @ e + C.T @ lam).max() / (1 + np.abs(g).max()),
+                      np.maximum(C @ x - c, 0).max() / (1 + np.abs(c).max()), np.maximum(-lam, 0).max()) if ok else np.nan
+            rows.append(dict(ok=ok, fac=fac, du=float(np.abs(x[:nu] - x_ref[:nu]).max()) if ok else np.nan, kkt=float(kkt),
+                             ipm_warm=iw["iters_total"], tight=int(((lam + (C @ x - c)) > 0).sum()), k=k))
+        info["step"] = step
+        prev, prev_u = info, u
+    return name, len(pbs), rows
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    procs = int(sys.argv[2]) if len(sys.argv) > 2 else (os.cpu_count() or 1)
+    from concurrent.futures import ProcessPoolExecutor
+    import multiprocessing as mp
+    with ProcessPoolExecutor(procs, mp_context=mp.get_context("spawn")) as ex:
+        res = list(ex.map(job, [(w, b) for w in WORK for b in range(n)]))
+    lines = [f"primal-dual active-set iteration from the previous PAN iteration's solution, every QP behind the kernel's warm-start gate, {n} scenes per workload (tests/tools/qp_active_set_study.py)",
+             "one 'factorisation' = one equality-constrained solve of the guessed active set; the interior-point column counts its iterations (one factorisation + TWO solves each) on the same QPs"]
+    for w in WORK:
+        rows = [r for name, _, rs in res if name == w for r in rs]
+        total = sum(np_ for name, np_, _ in res if name == w)
+        ok = [r for r in rows if r["ok"]]
+        fac = np.array([r["fac"] for r in ok])
+        lines.append(f"{w}: {total} QPs, {len(rows)} behind the gate, active-set iteration converged on {len(ok)} ({100.0 * len(ok) / max(len(rows), 1):.1f} %)")
+        lines.append(f"   factorisations: mean {fac.mean():.2f}, histogram {np.bincount(fac).tolist()}   |   warm interior-point iterations on the same QPs: mean {np.mean([r['ipm_warm'] for r in ok]):.2f}")
+        lines.append(f"   |u - u_ipm| median {np.median([r['du'] for r in ok]):.1e} max {max(r['du'] for r in ok):.1e}   KKT residual median {np.median([r['kkt'] for r in ok]):.1e} max {max(r['kkt'] for r in ok):.1e}   tight linear rows: median {int(np.median([r['tight'] for r in ok]))} max {max(r['tight'] for r in ok)}")
+        bad = [r for r in rows if not r["ok"]]
+        if bad:
+            lines.append(f"   not converged in 8 guesses: {len(bad)} (warm interior-point iterations there: mean {np.mean([r['ipm_warm'] for r in bad]):.1f})")
+    txt = "\n".join(lines)
+    print(txt)
+    with open(os.path.join(ROOT, "profiles", "r03_qp_active_set_study.txt"), "w") as f:
+        f.write(txt + "\n")
+
+
+if __name__ == "__main__":
+    main()
