@@ -51,6 +51,110 @@ def active_set_solve(H, g, F, f, C, c, ro, x, lam, max_it=8):
     return x, lam, max_it, False
 
 
+def active_set_solve_kernel_form(pb, H, g, F, f, C, c, x, lam, max_it=8):
+    """The same iteration in the form the wave kernel can run (what DESIGN.md section 7 proposes), as a check that nothing
+    but 2T x 2T Cholesky solves is needed.  Per guess:
+      * d_t: fixed at the bound its tight row names; else eliminated through its own stationarity condition (needs a hinge
+        row that is on in step t: kappa_t = ro |I_t|, exactly the per-step blocks S'_t = S_t - v v'/kappa of the kernel);
+      * u: the tight speed / rate rows of a control channel tie runs of consecutive steps, u_t = z_group + offset_t; a run
+        that contains a tight speed row is fixed altogether.  K' is summed over the runs (rows and columns), the other
+        members of a run get unit rows: one SPD solve of the kernel's size;
+      * multipliers of the tight rows from the stationarity residual along each run (running sums), signs checked by the
+        next guess."""
+    T = pb.T; nu = 2 * T; M = pb.M; ro = pb.ro_obs
+    Hu, gu = H[:nu, :nu], g[:nu]
+    nb, nr = 4 * T, 4 * (T - 1)
+    dlo = max(pb.d_min, 0.0)
+    prev = None
+    for it in range(max_it + 1):
+        on = (f - F @ x) > 0
+        tight = (lam + (C @ x - c)) > 0
+        key = (on.tobytes(), tight.tobytes())
+        if key == prev:
+            return x, lam, it, True
+        if it == max_it:
+            break
+        prev = key
+        # ---- d: fixed or eliminated ----
+        K = Hu.copy(); r = -gu.copy()
+        dfix = np.full(T, np.nan)
+        for t in range(T):
+            up, lo = tight[nb + nr + 2 * t], tight[nb + nr + 2 * t + 1]
+            I = np.where(on[t * M:(t + 1) * M])[0] + t * M
+            if up or lo or len(I) == 0:
+                dfix[t] = pb.d_max if (up or len(I) == 0) else dlo          # (no hinge row on: -eta pushes d to its upper bound)
+                Fu = F[I][:, :nu]
+                K += ro * Fu.T @ Fu
+                r += ro * Fu.T @ (f[I] + dfix[t])                            # F_j x = Fu u - d
+            else:
+                Fu = F[I][:, :nu]; v = ro * Fu.sum(0); kap = ro * len(I)
+                K += ro * Fu.T @ Fu - np.outer(v, v) / kap
+                r += ro * Fu.T @ f[I] - v * (ro * f[I].sum() - pb.eta) / kap
+        # ---- u: runs tied by tight rate rows, anchored by tight speed rows ----
+        Z = np.zeros((nu, nu)); off = np.zeros(nu); free = np.zeros(nu, bool); rep = np.arange(nu)
+        for k in range(2):
+            t = 0
+            while t < T:
+                a0 = 2 * t + k; members = [a0]; o = [0.0]
+                while t + 1 < T:
+                    q = nb + 4 * t + 2 * k                                     # rows (t -> t+1, channel k): +, -
+                    if tight[q]: o.append(o[-1] + pb.acce_bound[k])
+                    elif tight[q + 1]: o.append(o[-1] - pb.acce_bound[k])
+                    else: break
+                    t += 1; members.append(2 * t + k)
+                anchor = None
+                for a, oa in zip(members, o):
+                    if tight[2 * a]: anchor = pb.speed_bound[k] - oa; break
+                    if tight[2 * a + 1]: anchor = -pb.speed_bound[k] - oa; break
+                for a, oa in zip(members, o):
+                    rep[a] = a0
+                    if anchor is None: Z[a, a0] = 1.0; off[a] = oa
+                    else: off[a] = anchor + oa
+                free[a0] = anchor is None
+                t += 1
+        Kr = Z.T @ K @ Z; rr = Z.T @ (r - K @ off)
+        idx = np.where(free)[0]
+        Kr2 = np.eye(nu); Kr2[np.ix_(idx, idx)] = Kr[np.ix_(idx, idx)]      # unit rows for the tied / fixed members
+        rr2 = np.zeros(nu); rr2[idx] = rr[idx]
+        try:
+            L = np.linalg.cholesky(Kr2)
+        except np.linalg.LinAlgError:
+            break
+        z = np.linalg.solve(L.T, np.linalg.solve(L, rr2))
+        u = Z @ z + off
+        # ---- d of the eliminated steps, then the multipliers of every tight row from the stationarity residual ----
+        xn = np.zeros_like(x); xn[:nu] = u
+        for t in range(T):
+            if np.isnan(dfix[t]):
+                I = np.where(on[t * M:(t + 1) * M])[0] + t * M
+                xn[nu + t] = (pb.eta / ro - (f[I] - F[I][:, :nu] @ u).sum()) / len(I)
+            else:
+                xn[nu + t] = dfix[t]
+        e = np.where(on, f - F @ xn, 0.0)
+        res = -(H @ xn + g - ro * F.T @ e)                                     # = C' lam at a KKT point of the guess
+        lamn = np.zeros(C.shape[0])
+        for t in range(T):                                                      # d rows: +d <= dmax, -d <= -dlo
+            if res[nu + t] > 0: lamn[nb + nr + 2 * t] = res[nu + t]
+            else: lamn[nb + nr + 2 * t + 1] = -res[nu + t]
+        for k in range(2):                                                      # u rows: running sums along each run, from its end
+            acc = 0.0
+            for t in range(T - 1, -1, -1):
+                a = 2 * t + k
+                acc += res[a]
+                if t > 0 and rep[a] == rep[a - 2]:                             # tied to its predecessor: the rate row carries acc
+                    q = nb + 4 * (t - 1) + 2 * k
+                    if tight[q]: lamn[q] = acc
+                    else: lamn[q + 1] = -acc
+                else:                                                           # head of a run: what is left belongs to its speed row (if any)
+                    for a2 in range(a, nu, 2):
+                        if rep[a2] != rep[a]: break
+                        if tight[2 * a2]: lamn[2 * a2] = acc; break
+                        if tight[2 * a2 + 1]: lamn[2 * a2 + 1] = -acc; break
+                    acc = 0.0
+        x, lam = xn, lamn
+    return x, lam, max_it, False
+
+
 def job(arg):
     name, b = arg
     from helpers import CONFIGS, make_oracle
@@ -78,12 +182,14 @@ def job(arg):
         step = float(np.abs(u - prev_u).max()) if prev_u is not None else 9.0
         if prev is not None and prev["merit"] <= 1e-12 and prev["step"] < 0.1:          # the kernel's warm-start gate
             x, lam, fac, ok = active_set_solve(H, g, F, f, C, c, pb.ro_obs, prev["warm"][0].copy(), prev["warm"][1].copy())
+            xk, lk, fack, okk = active_set_solve_kernel_form(pb, H, g, F, f, C, c, prev["warm"][0].copy(), prev["warm"][1].copy())
             sw, uw, dw, iw = ci.solve_condensed(pb, warm=prev["warm"])
             e = np.maximum(f - F @ x, 0)
             kkt = max(np.abs(H @ x + g - pb.ro_obs * F.T @ e + C.T @ lam).max() / (1 + np.abs(g).max()),
                       np.maximum(C @ x - c, 0).max() / (1 + np.abs(c).max()), np.maximum(-lam, 0).max()) if ok else np.nan
             rows.append(dict(ok=ok, fac=fac, du=float(np.abs(x[:nu] - x_ref[:nu]).max()) if ok else np.nan, kkt=float(kkt),
-                             ipm_warm=iw["iters_total"], tight=int(((lam + (C @ x - c)) > 0).sum()), k=k))
+                             ipm_warm=iw["iters_total"], tight=int(((lam + (C @ x - c)) > 0).sum()), k=k,
+                             kf_ok=okk, kf_fac=fack, kf_du=float(np.abs(xk[:nu] - x[:nu]).max()) if (ok and okk) else np.nan))
         info["step"] = step
         prev, prev_u = info, u
     return name, len(pbs), rows
@@ -106,6 +212,9 @@ def main():
         lines.append(f"{w}: {total} QPs, {len(rows)} behind the gate, active-set iteration converged on {len(ok)} ({100.0 * len(ok) / max(len(rows), 1):.1f} %)")
         lines.append(f"   factorisations: mean {fac.mean():.2f}, histogram {np.bincount(fac).tolist()}   |   warm interior-point iterations on the same QPs: mean {np.mean([r['ipm_warm'] for r in ok]):.2f}")
         lines.append(f"   |u - u_ipm| median {np.median([r['du'] for r in ok]):.1e} max {max(r['du'] for r in ok):.1e}   KKT residual median {np.median([r['kkt'] for r in ok]):.1e} max {max(r['kkt'] for r in ok):.1e}   tight linear rows: median {int(np.median([r['tight'] for r in ok]))} max {max(r['tight'] for r in ok)}")
+        kf = [r for r in rows if r["ok"] and r["kf_ok"]]
+        lines.append(f"   kernel form (d eliminated per step, tied runs of controls, one 2T x 2T Cholesky per guess): converged on {sum(r['kf_ok'] for r in rows)}, "
+                     f"same guesses ({np.mean([r['kf_fac'] == r['fac'] for r in kf]) * 100:.0f} % with the same count), |u - u_exact| max {max(r['kf_du'] for r in kf):.1e}")
         bad = [r for r in rows if not r["ok"]]
         if bad:
             lines.append(f"   not converged in 8 guesses: {len(bad)} (warm interior-point iterations there: mean {np.mean([r['ipm_warm'] for r in bad]):.1f})")
