@@ -14,7 +14,24 @@ previous PAN iteration's solution under the kernel's warm-start gate, and report
 
     python tests/tools/qp_active_set_study.py [scenes per workload] [procs]    -> profiles/r03_qp_active_set_study.txt
 
-Nothing of this is in the product; DESIGN.md section 7 lists it as the next algorithmic step."""
+Nothing of this is in the product; DESIGN.md section 7 lists it as the next algorithmic step.
+
+Lane-level plan for the T = 10 / M = 10 instantiation (variable a = 2t + k in lane a, pair p in lane p, as today):
+  A. structure.  Pair lanes publish their tight flags through LDS; variable lane a reads tie(a) (sign of the tight rate row
+     between a - 2 and a) and bnd(a) (sign of its tight speed row).  Runs along the stride-2 chains of a channel by a
+     segmented Hillis-Steele scan, 4 steps of lane distance 2 / 4 / 8 / 16 (ds_bpermute: the chains cross the 16-lane DPP
+     rows): off(a) = offset to the head's value, head(a).  A run with a tight speed row is anchored: members publish
+     +-b - off(a) to slot[head(a)], everybody reads slot[head(a)].
+  B. matrix.  rhs -= K' off_vec (20 column-uniform values: LDS broadcast reads); column merge K'Z with wave-uniform 0/1
+     multipliers (arow[c-2] += m_c arow[c], then arow[c] = 0: ~70 issue slots); K' is symmetric, so Z'K'Z = ((K'Z)'Z)':
+     transpose through the LDS matrix the substitutions already use and merge the columns once more; Z'rhs by one segmented
+     scan; unit rows for tied / fixed members.  Per-step blocks S'_t with weights ro on the hinge rows that are on and
+     kappa_t = ro |I_t| (d free) or no kappa term (d fixed): the existing P_t / K' build with different inputs, no band terms.
+  C. the existing factorisation and substitutions; u_a = z[head(a)] + off_vec(a) (one ds_bpermute).
+  D. d of the free steps; stationarity residual with the existing residual phase (lam_c = 0, lam_f = ro e); multipliers of
+     the tight rows = segmented suffix sums of the residual along the runs, handed to the pair lanes through LDS; the next
+     guess tests signs and primal feasibility.  Same guess twice = KKT point: write out, skip the interior-point loop.
+`active_set_solve_kernel_form` below is this at the matrix level."""
 import os, sys
 for _k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
     os.environ.setdefault(_k, "1")
