@@ -153,21 +153,29 @@ def active_set_solve_kernel_form(pb, H, g, F, f, C, c, x, lam, max_it=8):
         for t in range(T):                                                      # d rows: +d <= dmax, -d <= -dlo
             if res[nu + t] > 0: lamn[nb + nr + 2 * t] = res[nu + t]
             else: lamn[nb + nr + 2 * t + 1] = -res[nu + t]
-        for k in range(2):                                                      # u rows: running sums along each run, from its end
-            acc = 0.0
+        # u rows.  Along a run, stationarity of member a reads res[a] = (+-)lam_tie(a) - (+-)lam_tie(a + 2) [+ beta at the member
+        # whose speed row is tight]: the tie row into member j carries S[j] = sum of res over the members from j to the run's
+        # end, less beta if the anchored member sits at or behind j; beta = S[head] (the head has no tie row of its own).
+        for k in range(2):
+            S = np.zeros(nu)
             for t in range(T - 1, -1, -1):
                 a = 2 * t + k
-                acc += res[a]
-                if t > 0 and rep[a] == rep[a - 2]:                             # tied to its predecessor: the rate row carries acc
-                    q = nb + 4 * (t - 1) + 2 * k
-                    if tight[q]: lamn[q] = acc
-                    else: lamn[q + 1] = -acc
-                else:                                                           # head of a run: what is left belongs to its speed row (if any)
-                    for a2 in range(a, nu, 2):
-                        if rep[a2] != rep[a]: break
-                        if tight[2 * a2]: lamn[2 * a2] = acc; break
-                        if tight[2 * a2 + 1]: lamn[2 * a2 + 1] = -acc; break
-                    acc = 0.0
+                S[a] = res[a] + (S[a + 2] if (t + 1 < T and rep[a + 2] == rep[a]) else 0.0)
+            for t in range(T):
+                a = 2 * t + k
+                if rep[a] != a:
+                    continue
+                members = [a2 for a2 in range(a, nu, 2) if rep[a2] == a]
+                m = next((a2 for a2 in members if tight[2 * a2] or tight[2 * a2 + 1]), None)
+                beta = S[a] if m is not None else 0.0
+                if m is not None:
+                    if tight[2 * m]: lamn[2 * m] = beta
+                    else: lamn[2 * m + 1] = -beta
+                for j in members[1:]:
+                    v = S[j] - (beta if (m is not None and m >= j) else 0.0)
+                    q = nb + 2 * (j - 2)
+                    if tight[q]: lamn[q] = v
+                    else: lamn[q + 1] = -v
         x, lam = xn, lamn
     return x, lam, max_it, False
 
@@ -206,7 +214,8 @@ def job(arg):
                       np.maximum(C @ x - c, 0).max() / (1 + np.abs(c).max()), np.maximum(-lam, 0).max()) if ok else np.nan
             rows.append(dict(ok=ok, fac=fac, du=float(np.abs(x[:nu] - x_ref[:nu]).max()) if ok else np.nan, kkt=float(kkt),
                              ipm_warm=iw["iters_total"], tight=int(((lam + (C @ x - c)) > 0).sum()), k=k,
-                             kf_ok=okk, kf_fac=fack, kf_du=float(np.abs(xk[:nu] - x[:nu]).max()) if (ok and okk) else np.nan))
+                             kf_ok=okk, kf_fac=fack, kf_du=float(np.abs(xk[:nu] - x[:nu]).max()) if (ok and okk) else np.nan,
+                             kf_dl=float(np.abs(lk - lam).max() / (1.0 + np.abs(lam).max())) if (ok and okk) else np.nan))
         info["step"] = step
         prev, prev_u = info, u
     return name, len(pbs), rows
@@ -231,7 +240,7 @@ def main():
         lines.append(f"   |u - u_ipm| median {np.median([r['du'] for r in ok]):.1e} max {max(r['du'] for r in ok):.1e}   KKT residual median {np.median([r['kkt'] for r in ok]):.1e} max {max(r['kkt'] for r in ok):.1e}   tight linear rows: median {int(np.median([r['tight'] for r in ok]))} max {max(r['tight'] for r in ok)}")
         kf = [r for r in rows if r["ok"] and r["kf_ok"]]
         lines.append(f"   kernel form (d eliminated per step, tied runs of controls, one 2T x 2T Cholesky per guess): converged on {sum(r['kf_ok'] for r in rows)}, "
-                     f"same guesses ({np.mean([r['kf_fac'] == r['fac'] for r in kf]) * 100:.0f} % with the same count), |u - u_exact| max {max(r['kf_du'] for r in kf):.1e}")
+                     f"same guesses ({np.mean([r['kf_fac'] == r['fac'] for r in kf]) * 100:.0f} % with the same count), |u - u_exact| max {max(r['kf_du'] for r in kf):.1e}, multipliers of the tight rows within {max(r['kf_dl'] for r in kf):.1e} (relative)")
         bad = [r for r in rows if not r["ok"]]
         if bad:
             lines.append(f"   not converged in 8 guesses: {len(bad)} (warm interior-point iterations there: mean {np.mean([r['ipm_warm'] for r in bad]):.1f})")
