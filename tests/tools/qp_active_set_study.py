@@ -19,7 +19,7 @@ Nothing of this is in the product; DESIGN.md section 7 lists it as the next algo
 Lane-level plan for the T = 10 / M = 10 instantiation (variable a = 2t + k in lane a, pair p in lane p, as today):
   A. structure.  Pair lanes publish their tight flags through LDS; variable lane a reads tie(a) (sign of the tight rate row
      between a - 2 and a) and bnd(a) (sign of its tight speed row).  Runs along the stride-2 chains of a channel by a
-     segmented Hillis-Steele scan, 4 steps of lane distance 2 / 4 / 8 / 16 (ds_bpermute: the chains cross the 16-lane DPP
+     segmented Hillis-Steele scan, 4 steps of lane distance 2 / 4 / 8 / 16 (5 at T = 20; ds_bpermute: the chains cross the 16-lane DPP
      rows): off(a) = offset to the head's value, head(a).  A run with a tight speed row is anchored: members publish
      +-b - off(a) to slot[head(a)], everybody reads slot[head(a)].
   B. matrix.  rhs -= K' off_vec (20 column-uniform values: LDS broadcast reads); column merge K'Z with wave-uniform 0/1
@@ -68,7 +68,7 @@ def active_set_solve(H, g, F, f, C, c, ro, x, lam, max_it=8):
     return x, lam, max_it, False
 
 
-def active_set_solve_kernel_form(pb, H, g, F, f, C, c, x, lam, max_it=8):
+def active_set_solve_kernel_form(pb, H, g, F, f, C, c, x, lam, max_it=8, lane_check=None):
     """The same iteration in the form the wave kernel can run (what DESIGN.md section 7 proposes), as a check that nothing
     but 2T x 2T Cholesky solves is needed.  Per guess:
       * d_t: fixed at the bound its tight row names; else eliminated through its own stationarity condition (needs a hinge
@@ -133,6 +133,15 @@ def active_set_solve_kernel_form(pb, H, g, F, f, C, c, x, lam, max_it=8):
         idx = np.where(free)[0]
         Kr2 = np.eye(nu); Kr2[np.ix_(idx, idx)] = Kr[np.ix_(idx, idx)]      # unit rows for the tied / fixed members
         rr2 = np.zeros(nu); rr2[idx] = rr[idx]
+        if lane_check is not None:                                          # the same reduction lane by lane
+            tie = np.zeros(nu); bnd = np.zeros(nu)
+            for a in range(nu):
+                if a >= 2: tie[a] = 1.0 if tight[nb + 2 * (a - 2)] else (-1.0 if tight[nb + 2 * (a - 2) + 1] else 0.0)
+                bnd[a] = 1.0 if tight[2 * a] else (-1.0 if tight[2 * a + 1] else 0.0)
+            Kl, rl, headl, offl, ancl = lane_level_reduction(K, r, tie, bnd, pb.acce_bound, pb.speed_bound, nu)
+            sc = 1.0 + np.abs(Kr2).max()
+            lane_check.append(max(np.abs(Kl - Kr2).max() / sc, np.abs(rl - rr2).max() / (1.0 + np.abs(rr2).max()),
+                                  np.abs(offl - off).max(), float(np.abs(headl - rep).max())))
         try:
             L = np.linalg.cholesky(Kr2)
         except np.linalg.LinAlgError:
@@ -180,6 +189,75 @@ def active_set_solve_kernel_form(pb, H, g, F, f, C, c, x, lam, max_it=8):
     return x, lam, max_it, False
 
 
+# ---- the same reduction, lane by lane (64-lane arrays, ds_bpermute-style gathers, Hillis-Steele segmented scans): what the HIP
+# code has to do, checked here against the matrix form ---------------------------------------------------------------------
+NL = 64
+
+
+def _bperm(v, src, fill=0.0):
+    """lane i reads v[src[i]]; lanes whose source is outside the wave read `fill`"""
+    src = np.asarray(src)
+    okl = (src >= 0) & (src < NL)
+    return np.where(okl, v[np.clip(src, 0, NL - 1)], fill)
+
+
+def lane_level_reduction(K, r, tie, bnd, acc, spd, nu):
+    """K (nu, nu) symmetric, r (nu): the system before the tight u rows are eliminated.  tie[a] in {0, +1, -1}: u_a = u_(a-2) +- acc_k
+    is tight; bnd[a] in {0, +1, -1}: u_a = +-spd_k is tight (k = a & 1).  Returns (Kred rows in lanes, rred, head, offvec, anchored)."""
+    lane = np.arange(NL)
+    live = lane < nu
+    k = lane & 1
+    tie_l = np.zeros(NL); tie_l[:nu] = tie
+    bnd_l = np.zeros(NL); bnd_l[:nu] = bnd
+    # A. offsets and heads: segmented inclusive scan along the stride-2 chains (flag = 1 at the head of a run)
+    v = np.where(live, tie_l * np.where(k == 0, acc[0], acc[1]), 0.0)
+    flag = (~live) | (tie_l == 0)
+    h = np.where(flag, lane, -1).astype(float)
+    for dist in (2, 4, 8, 16, 32):
+        vp = _bperm(v, lane - dist); fp = _bperm(flag.astype(float), lane - dist, 1.0) > 0; hp = _bperm(h, lane - dist, -1.0)
+        v = np.where(flag, v, v + vp); h = np.where(flag, h, hp); flag = flag | fp
+    off = v; head = h.astype(int)
+    slot = np.full(NL, np.nan)                                       # an LDS array: members with a tight speed row publish the head's value
+    for a in range(nu):
+        if bnd_l[a] != 0 and np.isnan(slot[head[a]]):
+            slot[head[a]] = bnd_l[a] * spd[a & 1] - off[a]
+    anchor = _bperm(slot, head, np.nan)
+    anchored = ~np.isnan(anchor) & live
+    offvec = np.where(anchored, anchor + off, off)
+    # B. rhs -= K offvec (column-uniform values, broadcast reads), then merge / clear the columns, transpose, merge again
+    rows = np.zeros((NL, nu)); rows[:nu] = K                          # lane a holds row a in nu registers
+    rl = np.zeros(NL); rl[:nu] = r
+    rl = rl - rows @ offvec[:nu]
+    m = (tie_l[:nu] != 0) & ~anchored[:nu]                            # column c folds into column c - 2 (wave-uniform per column)
+    gone = (tie_l[:nu] != 0) | anchored[:nu]                          # column c leaves the system
+
+    def merge(rows):
+        rows = rows.copy()
+        for c in range(nu - 1, 1, -1):
+            if m[c]: rows[:, c - 2] += rows[:, c]
+        rows[:, gone] = 0.0
+        return rows
+    rows = merge(rows)
+    t = np.zeros((NL, nu)); t[:nu] = rows[:nu].T                      # through the LDS matrix: lane a reads column a
+    rows = merge(t)
+    for a in range(nu):
+        if gone[a]: rows[a, a] = 1.0                                  # unit rows for the members that left
+    # Z' rhs: reverse segmented sums by pointer jumping -- val[a] = sum over the members of a's run from a on, link[a] = "the span
+    # collected so far ends on a member that is folded into its predecessor as well"
+    cont = np.zeros(NL, bool); cont[:nu] = m                          # lane a is folded into lane a - 2
+    val = np.where(live, rl, 0.0)
+    link = _bperm(cont.astype(float), lane + 2) > 0
+    for dist in (2, 4, 8, 16, 32):
+        val, link = val + np.where(link, _bperm(val, lane + dist), 0.0), link & (_bperm(link.astype(float), lane + dist) > 0)
+    rl = np.where(gone_l(gone, nu), 0.0, val)
+    return rows[:nu], rl[:nu], head[:nu], offvec[:nu], anchored[:nu]
+
+
+def gone_l(gone, nu):
+    g = np.zeros(NL, bool); g[:nu] = gone
+    return g
+
+
 def job(arg):
     name, b = arg
     from helpers import CONFIGS, make_oracle
@@ -207,7 +285,8 @@ def job(arg):
         step = float(np.abs(u - prev_u).max()) if prev_u is not None else 9.0
         if prev is not None and prev["merit"] <= 1e-12 and prev["step"] < 0.1:          # the kernel's warm-start gate
             x, lam, fac, ok = active_set_solve(H, g, F, f, C, c, pb.ro_obs, prev["warm"][0].copy(), prev["warm"][1].copy())
-            xk, lk, fack, okk = active_set_solve_kernel_form(pb, H, g, F, f, C, c, prev["warm"][0].copy(), prev["warm"][1].copy())
+            lchk = []
+            xk, lk, fack, okk = active_set_solve_kernel_form(pb, H, g, F, f, C, c, prev["warm"][0].copy(), prev["warm"][1].copy(), lane_check=lchk)
             sw, uw, dw, iw = ci.solve_condensed(pb, warm=prev["warm"])
             e = np.maximum(f - F @ x, 0)
             kkt = max(np.abs(H @ x + g - pb.ro_obs * F.T @ e + C.T @ lam).max() / (1 + np.abs(g).max()),
@@ -215,7 +294,8 @@ def job(arg):
             rows.append(dict(ok=ok, fac=fac, du=float(np.abs(x[:nu] - x_ref[:nu]).max()) if ok else np.nan, kkt=float(kkt),
                              ipm_warm=iw["iters_total"], tight=int(((lam + (C @ x - c)) > 0).sum()), k=k,
                              kf_ok=okk, kf_fac=fack, kf_du=float(np.abs(xk[:nu] - x[:nu]).max()) if (ok and okk) else np.nan,
-                             kf_dl=float(np.abs(lk - lam).max() / (1.0 + np.abs(lam).max())) if (ok and okk) else np.nan))
+                             kf_dl=float(np.abs(lk - lam).max() / (1.0 + np.abs(lam).max())) if (ok and okk) else np.nan,
+                             lane=max(lchk) if lchk else 0.0, guesses=len(lchk)))
         info["step"] = step
         prev, prev_u = info, u
     return name, len(pbs), rows
@@ -241,6 +321,8 @@ def main():
         kf = [r for r in rows if r["ok"] and r["kf_ok"]]
         lines.append(f"   kernel form (d eliminated per step, tied runs of controls, one 2T x 2T Cholesky per guess): converged on {sum(r['kf_ok'] for r in rows)}, "
                      f"same guesses ({np.mean([r['kf_fac'] == r['fac'] for r in kf]) * 100:.0f} % with the same count), |u - u_exact| max {max(r['kf_du'] for r in kf):.1e}, multipliers of the tight rows within {max(r['kf_dl'] for r in kf):.1e} (relative)")
+        lines.append(f"   lane-level form of the reduction (64-lane arrays, gathers and segmented scans: the docstring's steps A and B) against the matrix form, "
+                     f"{sum(r['guesses'] for r in rows)} guesses: largest deviation {max(r['lane'] for r in rows):.1e}")
         bad = [r for r in rows if not r["ok"]]
         if bad:
             lines.append(f"   not converged in 8 guesses: {len(bad)} (warm interior-point iterations there: mean {np.mean([r['ipm_warm'] for r in bad]):.1f})")
