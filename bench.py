@@ -156,7 +156,7 @@ def main():
     steps = []
     for j in range(nfl):
         with torch.cuda.stream(streams[j]):
-            steps.append(pans[j].make_step(*args_dev[j], reset_state=True, graph=(args.graph and j not in timed_idx)))
+            steps.append(pans[j].make_step(*args_dev[j], reset_every_step=True, graph=(args.graph and j not in timed_idx)))
     torch.cuda.synchronize(dev)
 
     loop = StepLoop(steps, streams, gatherer, cur, threads=args.issue_threads)
@@ -380,7 +380,7 @@ def main():
             st_w = []
             for j in range(nfl):
                 with torch.cuda.stream(streams[j]):
-                    st_w.append(pans[j].make_step(*a_w, reset_state=True))
+                    st_w.append(pans[j].make_step(*a_w, reset_every_step=True))
             torch.cuda.synchronize(dev)
             nw = args.steps
             serve_steps(args.warmup, st_w, streams, None, cur)

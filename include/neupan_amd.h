@@ -114,6 +114,30 @@ int npa_geo_report(const npa_handle *h, float *out, int n);
  * the distrust). */
 int npa_audit_read(npa_handle *h, uint64_t *tiles, uint64_t *points, uint64_t *violations, float *worst_excess, int reset);
 
+/* The violation count of npa_audit_read WITHOUT synchronising the device: the selection kernel mirrors every violation
+ * it counts into pinned host memory, and this reads that word.  Cheap enough to poll after every step of a serving loop
+ * (neupan_amd.PAN does, and warns).  A non-zero value means: at least one launch may have emitted rows from a selection
+ * that missed a true member (the plans of THAT launch are suspect), every later launch ran on exact keys (slow, right).
+ * What to do then: npa_use_network_keys (or rebuild the handle with NPA_KEY_TERMS=1), re-plan the affected step. */
+int npa_audit_peek(const npa_handle *h, uint64_t *violations);
+
+/* Switch a handle from geometric to network keys for good (calibrates them, resets the audit).  The workspace grows by the
+ * key buffer: call npa_workspace_bytes again and re-allocate (a forward call with the old size fails with NPA_E_ARG).  No
+ * forward call may be in progress; synchronises the device.  A no-op on a handle that already uses network keys. */
+int npa_use_network_keys(npa_handle *h);
+
+/* What the create-time self-test (npa_create runs every kernel of the handle once on a fixed synthetic problem sized to
+ * the robot) changed about this handle.  Hard failures of npa_create are only: two runs that differ bitwise, a control
+ * that is not finite or outside its speed bound.  Soft outcomes are reported here:
+ *   NPA_SELFTEST_WARM_OFF      warm- and cold-started solves of the test problem differed by more than 1e-4 (a QP that is
+ *                              flat along steering directions can do that legitimately): the interior-point warm start
+ *                              across PAN iterations is switched off for this handle;
+ *   NPA_SELFTEST_GEO_REJECTED  the geometric-key selection missed a member of the exact selection on the test cloud: the
+ *                              handle uses network keys (npa_key_mode tells which). */
+#define NPA_SELFTEST_WARM_OFF 1
+#define NPA_SELFTEST_GEO_REJECTED 2
+int npa_selftest_flags(const npa_handle *h, int *flags);
+
 /* Replaces NRMP.update_adjust_parameters_value (nrmp.py:170-217). */
 int npa_set_adjust(npa_handle *h, const float q_s[3], float p_u, float eta, float d_max, float d_min);
 

@@ -41,6 +41,9 @@ SYMBOLS = {
     "npa_key_mode": (_I, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "npa_geo_report": (_I, [_P, C.POINTER(C.c_float), _I]),
     "npa_audit_read": (_I, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_float), _I]),
+    "npa_audit_peek": (_I, [_P, C.POINTER(C.c_uint64)]),
+    "npa_use_network_keys": (_I, [_P]),
+    "npa_selftest_flags": (_I, [_P, C.POINTER(C.c_int)]),
     "npa_set_adjust": (_I, [_P, C.POINTER(C.c_float * 3), C.c_float, C.c_float, C.c_float, C.c_float]),
     "npa_workspace_bytes": (_SZ, [_P, _I]),
     "npa_state_bytes": (_SZ, [_P, _I]),

@@ -27,7 +27,7 @@ extern "C" hipError_t npa_launch_select_geo(const DevParams& P, const float* wpa
                                             const int* n_points, const int* flags, const float* trig, float* mu_sorted,
                                             float* lam_sorted, float* pts_sorted, float* dist_sorted, int* count,
                                             unsigned* stats, int debug, unsigned* audit, unsigned audit_thresh,
-                                            unsigned audit_seed, float margin_scale, hipStream_t stream,
+                                            unsigned audit_seed, float margin_scale, int rows_bf16, hipStream_t stream,
                                             hipEvent_t ev_start, hipEvent_t ev_stop);
 extern "C" hipError_t npa_launch_select(const DevParams& P, const float* wpack, int batch, int scene0, int t0,
                                         int n_stride, const float* cur_s, const float* points, const float* vel,
@@ -104,6 +104,10 @@ struct npa_handle {
   // run-time audit of the margin (select_geo_kernel): [0] audit tiles run, [1] points they checked, [2] bound violations seen
   // (candidates and audit tiles), [3] float bits of the largest excess |exact - g| - margin
   unsigned* audit_dev = nullptr;
+  unsigned* audit_host = nullptr;        // pinned, host-mapped mirror of the violation count (words 6, 7 of audit_dev point at it)
+  bool rows_bf16 = false;                // NPA_ROWS_PRECISION=bf16: the labelled reduced-precision tier of the rows (geometric keys, E = 4 / 8)
+  int selftest_flags = 0;                // NPA_SELFTEST_* : what the create-time self-test changed about this handle
+  double key_safety = -1.0;              // NPA_KEY_SAFETY at creation (< 0: the defaults)
   unsigned audit_thresh = 0;             // fraction of the slice waves that run an audit tile, x 2^32
   unsigned launch_seq = 0;
   float margin_scale = 1.f;              // NPA_GEO_MARGIN_SCALE (tests only: a deliberately wrong margin)
@@ -132,6 +136,51 @@ extern "C" const char* npa_version(void) { return "neupan_amd 0.2 (gfx950, hipcc
 static int mdim(const DevParams& P) { return P.M > 0 ? P.M : 1; }
 // per-slice stride of the key buffer inside the workspace: none with geometric keys (select_kernel keeps them in LDS)
 static int kstride(const npa_handle* h) { return h->key_terms == 4 ? 0 : h->P.key_stride; }
+
+// Network keys (dune_kernel): measure the key error of the single-product (1) and the split-product (3) mode on a
+// 1024 x 1024 grid over the training square and pick the cheapest mode whose margin stays under its cap; neither -> the
+// exact fp32 encoder (0).  forced = 1 / 3 pins a mode (NPA_KEY_TERMS), < 0 = automatic.  Also the fallback of a handle
+// whose geometric keys were rejected (self-test) or distrusted at run time (npa_use_network_keys).
+static hipError_t calibrate_network_keys(npa_handle* h, int forced) {
+  const DevParams& P = h->P;
+  unsigned* dmax = nullptr;
+  const int modes[2] = {1, 3};
+  const float floor_e0[2] = {1e-4f, 2e-5f}, cap_e0[2] = {5e-2f, 1e-3f};
+  bool ok[2] = {false, false};
+  const double sf = h->key_safety > 0 ? h->key_safety : 5.0;
+  hipError_t e = hipMalloc(&dmax, sizeof(unsigned));
+  for (int m = 0; m < 2 && e == hipSuccess; ++m) {
+    if (forced > 0 && forced != modes[m]) continue;
+    unsigned bits = 0;
+    e = hipMemset(dmax, 0, sizeof(unsigned));
+    if (e == hipSuccess) e = npa_launch_key_calib(P, h->wpack, modes[m], 1024, 25.0f, dmax, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(&bits, dmax, sizeof(unsigned), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) break;
+    float err;
+    memcpy(&err, &bits, sizeof(err));
+    h->err_mode[m] = err;
+    h->e0_mode[m] = std::max((float)(sf * err), floor_e0[m]);
+    ok[m] = h->e0_mode[m] <= cap_e0[m] || forced == modes[m];
+  }
+  if (dmax) hipFree(dmax);
+  if (e != hipSuccess) return e;
+  const int pick = ok[0] ? 0 : (ok[1] ? 1 : -1);
+  h->key_terms = 0; h->key_err = 0.f; h->key_e0 = 0.f;
+  if (pick >= 0) { h->key_terms = modes[pick]; h->key_err = h->err_mode[pick]; h->key_e0 = h->e0_mode[pick]; }
+  h->key_auto = forced < 0 && ok[0] && ok[1];
+  return hipSuccess;
+}
+
+// the audit block: words 0..4 counters (npa_audit_read), 6..7 the address of the pinned host mirror of the violation count
+static hipError_t audit_block_reset(npa_handle* h) {
+  if (!h->audit_dev) return hipSuccess;
+  unsigned blk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  void* mirror = nullptr;                        // the device's address of the pinned counter
+  if (h->audit_host && hipHostGetDevicePointer(&mirror, h->audit_host, 0) != hipSuccess) mirror = nullptr;
+  memcpy(&blk[6], &mirror, sizeof(mirror));
+  if (h->audit_host) *(volatile unsigned*)h->audit_host = 0;
+  return hipMemcpy(h->audit_dev, blk, sizeof(blk), hipMemcpyHostToDevice);
+}
 
 static int npa_self_test(npa_handle* h);
 extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_handle** out) {
@@ -304,6 +353,22 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
     pack[WP_KSC + 3] = (float)TANH_SCALE;              // after LayerNorm 1, 2: feeds a split layer
     pack[WP_KSC + 4] = (float)TANH_SCALE;
     pack[WP_KSC + 5] = 1.0f;                           // after LayerNorm 3: feeds the output layer
+    {
+      // bf16 A-fragments of the exact network's four 32x32 layers (RNE), for the reduced-precision tier of the rows
+      uint16_t* wb = reinterpret_cast<uint16_t*>(&pack[WP_WB16]);
+      auto to_bf16 = [](float f) -> uint16_t {
+        uint32_t u;
+        memcpy(&u, &f, 4);
+        if ((u & 0x7F800000u) == 0x7F800000u) return (uint16_t)(u >> 16);        // inf / nan: truncate
+        u += 0x7FFFu + ((u >> 16) & 1u);                                           // round to nearest even
+        return (uint16_t)(u >> 16);
+      };
+      for (int L = 0; L < 4; ++L)
+        for (int s2 = 0; s2 < 2; ++s2)
+          for (int l = 0; l < 64; ++l)
+            for (int q = 0; q < 8; ++q)
+              wb[(((size_t)L * 2 + s2) * 64 + l) * 8 + q] = to_bf16(w->lin_w[1 + L][(l & 31) * 32 + npa_feat(8 * s2 + q, l >> 5)]);
+    }
     _Float16* kh = reinterpret_cast<_Float16*>(&pack[WP_BF]);
     for (int L = 0; L < 4; ++L)
       for (int s2 = 0; s2 < 2; ++s2)
@@ -443,38 +508,28 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
         }
       }
     }
-    unsigned* dmax = nullptr;
-    const int modes[2] = {1, 3};
-    const float floor_e0[2] = {1e-4f, 2e-5f}, cap_e0[2] = {5e-2f, 1e-3f};
-    bool ok[2] = {false, false};
-    if (!geo_ok && e == hipSuccess && forced != 0 && forced != 4) {
-      const double sf = safety > 0 ? safety : 5.0;
-      e = hipMalloc(&dmax, sizeof(unsigned));
-      for (int m = 0; m < 2 && e == hipSuccess; ++m) {
-        if (forced > 0 && forced != modes[m]) continue;
-        unsigned bits = 0;
-        e = hipMemset(dmax, 0, sizeof(unsigned));
-        if (e == hipSuccess) e = npa_launch_key_calib(P, h->wpack, modes[m], 1024, 25.0f, dmax, nullptr);
-        if (e == hipSuccess) e = hipMemcpy(&bits, dmax, sizeof(unsigned), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) break;
-        float err;
-        memcpy(&err, &bits, sizeof(err));
-        h->err_mode[m] = err;
-        h->e0_mode[m] = std::max((float)(sf * err), floor_e0[m]);
-        ok[m] = h->e0_mode[m] <= cap_e0[m] || forced == modes[m];
-      }
-      if (dmax) hipFree(dmax);
-      const int pick = ok[0] ? 0 : (ok[1] ? 1 : -1);
-      if (pick >= 0) { h->key_terms = modes[pick]; h->key_err = h->err_mode[pick]; h->key_e0 = h->e0_mode[pick]; }
-      h->key_auto = forced < 0 && ok[0] && ok[1];
-    }
+    h->key_safety = safety;
+    if (!geo_ok && e == hipSuccess && forced != 0 && forced != 4) e = calibrate_network_keys(h, forced);
     if (e == hipSuccess) e = hipMalloc(&h->sel_stats_dev, sizeof(unsigned));
     if (e == hipSuccess) e = hipMemset(h->sel_stats_dev, 0, sizeof(unsigned));
     if (e == hipSuccess) e = hipHostMalloc(&h->sel_stats_host, sizeof(unsigned), hipHostMallocDefault);
     if (e == hipSuccess) *h->sel_stats_host = 0;
     if (e == hipSuccess) e = hipMalloc(&h->audit_dev, 8 * sizeof(unsigned));       // [4]: launches seen (device side)
-    if (e == hipSuccess) e = hipMemset(h->audit_dev, 0, 8 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipHostMalloc(&h->audit_host, sizeof(unsigned), hipHostMallocMapped);
+    if (e == hipSuccess) e = audit_block_reset(h);
     h->select_v1 = getenv("NPA_SELECT_V1") != nullptr;
+    if (const char* env = getenv("NPA_ROWS_PRECISION")) {
+      if (!strcmp(env, "bf16")) {
+        if (e == hipSuccess && !(h->key_terms == 4 && !h->select_v1 && (P.E == 4 || P.E == 8))) {
+          npa_destroy(h);
+          return fail(NPA_E_UNSUPPORTED, "NPA_ROWS_PRECISION=bf16 needs geometric keys (select_geo_kernel) and a polygon of 4 or 8 edges");
+        }
+        h->rows_bf16 = true;
+      } else if (strcmp(env, "fp32") != 0) {
+        npa_destroy(h);
+        return fail(NPA_E_ARG, "NPA_ROWS_PRECISION must be fp32 or bf16");
+      }
+    }
     {
       double rate = 1.0 / 64.0;              // audit tiles: one slice wave in 64 (NPA_AUDIT_RATE in [0, 1]; 0 = candidates only)
       if (const char* env = getenv("NPA_AUDIT_RATE")) { double v = atof(env); if (v >= 0.0 && v <= 1.0) rate = v; }
@@ -520,6 +575,7 @@ extern "C" int npa_destroy(npa_handle* h) {
   if (h->sel_stats_dev) hipFree(h->sel_stats_dev);
   if (h->sel_stats_host) hipHostFree(h->sel_stats_host);
   if (h->audit_dev) hipFree(h->audit_dev);
+  if (h->audit_host) hipHostFree(h->audit_host);
   if (h->stage_cand) hipFree(h->stage_cand);
   delete h;
   return NPA_OK;
@@ -549,7 +605,10 @@ extern "C" int npa_audit_read(npa_handle* h, uint64_t* tiles, uint64_t* points, 
     if (cur != h->device) HIP_TRY(hipSetDevice(h->device));
     hipError_t e = hipDeviceSynchronize();          // the counters of every queued launch of this handle
     if (e == hipSuccess) e = hipMemcpy(v, h->audit_dev, sizeof(v), hipMemcpyDeviceToHost);
-    if (e == hipSuccess && reset) e = hipMemset(h->audit_dev, 0, sizeof(v));
+    if (e == hipSuccess && reset) {
+      e = hipMemset(h->audit_dev, 0, sizeof(v));
+      if (h->audit_host) *(volatile unsigned*)h->audit_host = 0;
+    }
     if (cur != h->device) (void)hipSetDevice(cur);
     HIP_TRY(e);
   }
@@ -557,6 +616,35 @@ extern "C" int npa_audit_read(npa_handle* h, uint64_t* tiles, uint64_t* points, 
   if (points) *points = v[1];
   if (violations) *violations = v[2];
   if (worst_excess) memcpy(worst_excess, &v[3], 4);
+  return NPA_OK;
+}
+
+extern "C" int npa_audit_peek(const npa_handle* h, uint64_t* violations) {
+  if (!h || !violations) return fail(NPA_E_ARG, "npa_audit_peek: null argument");
+  *violations = h->audit_host ? (uint64_t)*(volatile unsigned*)h->audit_host : 0;
+  return NPA_OK;
+}
+
+extern "C" int npa_selftest_flags(const npa_handle* h, int* flags) {
+  if (!h || !flags) return fail(NPA_E_ARG, "npa_selftest_flags: null argument");
+  *flags = h->selftest_flags;
+  return NPA_OK;
+}
+
+extern "C" int npa_use_network_keys(npa_handle* h) {
+  if (!h) return fail(NPA_E_ARG, "npa_use_network_keys: null handle");
+  std::lock_guard<std::mutex> lock(h->mu);
+  if (h->pc.active) return fail(NPA_E_ARG, "npa_use_network_keys: a forward call is in progress on this handle");
+  if (h->key_terms != 4) return NPA_OK;
+  int cur = -1;
+  HIP_TRY(hipGetDevice(&cur));
+  if (cur != h->device) HIP_TRY(hipSetDevice(h->device));
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = calibrate_network_keys(h, -1);
+  if (e == hipSuccess) e = audit_block_reset(h);
+  if (cur != h->device) (void)hipSetDevice(cur);
+  HIP_TRY(e);
+  h->stats_mark = 0; h->tiles_window = 0; h->calls_window = 0; h->hold = 0;
   return NPA_OK;
 }
 
@@ -662,8 +750,8 @@ extern "C" int npa_dune_stage(npa_handle* h, int batch, int n_stride, const floa
   if (geo && !h->select_v1)
     HIP_TRY(npa_launch_select_geo(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr, trig,
                                   mu_sorted, lam_sorted, pts_sorted, dist_sorted, count, h->sel_stats_dev, h->sel_debug,
-                                  h->audit_dev, h->audit_thresh, h->launch_seq++, h->margin_scale, (hipStream_t)stream,
-                                  nullptr, nullptr));
+                                  h->rows_bf16 ? nullptr : h->audit_dev, h->audit_thresh, h->launch_seq++, h->margin_scale,
+                                  h->rows_bf16 ? 1 : 0, (hipStream_t)stream, nullptr, nullptr));
   else
     HIP_TRY(npa_launch_select(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr,
                               (const unsigned*)h->stage_cand, trig, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count,
@@ -850,8 +938,8 @@ extern "C" int npa_forward_iter(npa_handle* h, int k) {
     if (geo && !h->select_v1)
       HIP_TRY(npa_launch_select_geo(P, h->wpack, batch, 0, t0, pc->n_stride, cur_s, pc->points, pc->velocities, pc->n_points,
                                     flags, ws + L.trig, mu, lam, pts, dist, count, h->sel_stats_dev, h->sel_debug,
-                                    h->audit_dev, h->audit_thresh, h->launch_seq++, h->margin_scale, stream,
-                                    evs ? evs->a : nullptr, evs ? evs->b : nullptr));
+                                    h->rows_bf16 ? nullptr : h->audit_dev, h->audit_thresh, h->launch_seq++, h->margin_scale,
+                                    h->rows_bf16 ? 1 : 0, stream, evs ? evs->a : nullptr, evs ? evs->b : nullptr));
     else
       HIP_TRY(npa_launch_select(P, h->wpack, batch, 0, t0, pc->n_stride, cur_s, pc->points, pc->velocities,
                                 pc->n_points, flags, gkeys, ws + L.trig, mu, lam, pts, dist, count, h->key_terms, h->key_e0,
@@ -979,6 +1067,11 @@ static int npa_self_test(npa_handle* h) {
   const int kmax = P.K < 3 ? P.K : 3;
   std::vector<float> nom_s((size_t)B * 3 * (T + 1)), nom_u((size_t)B * 2 * T), ref_s(nom_s.size()), ref_us((size_t)B * T),
       pts((size_t)B * 2 * N);
+  float rbody = 2.5f;
+  if (h->geo_valid) {
+    rbody = 0.f;
+    for (int e = 0; e < P.E; ++e) rbody = std::max(rbody, std::sqrt(P.pvx[e] * P.pvx[e] + P.pvy[e] * P.pvy[e]));
+  }
   unsigned lcg = 12345u;
   auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return (float)((lcg >> 8) & 0xFFFF) / 65535.0f; };
   for (int b = 0; b < B; ++b) {
@@ -996,12 +1089,15 @@ static int npa_self_test(npa_handle* h) {
       nom_u[(size_t)b * 2 * T + t] = v; nom_u[(size_t)b * 2 * T + T + t] = 0.f;
       ref_us[(size_t)b * T + t] = v;
     }
-    // a ring of points 4 .. 9 m around the path's start (clear of any robot body the reference ships: the car is 4.6 m
-    // long), plus a cluster ahead and to the side of it that the horizon approaches
+    // a ring of points around the path's start and a cluster ahead and to the side of it that the horizon approaches, both
+    // placed relative to the robot's own size (rbody = its largest vertex radius: the ring starts at least 1.5 m outside the
+    // body whatever polygon the handle was created with; 2.5 m stands in when the rows are not a recognisable polygon)
+    // (never closer than the cloud the shipped robots were validated on: ring from 4 m, cluster at (5.5, 2.5))
+    const float ring0 = std::max(4.0f, rbody + 1.5f), cx = std::max(5.5f, (rbody + 3.0f) * 0.9f), cy = std::max(2.5f, (rbody + 3.0f) * 0.43f);
     for (int n = 0; n < N; ++n) {
-      const float ang = 6.2831853f * rnd(), r = 4.0f + 5.0f * rnd();
-      pts[(size_t)b * 2 * N + n] = (n < 80) ? r * std::cos(ang) : 5.5f + 0.6f * rnd();
-      pts[(size_t)b * 2 * N + N + n] = (n < 80) ? r * std::sin(ang) : 2.5f + 0.6f * rnd();
+      const float ang = 6.2831853f * rnd(), r = ring0 + 5.0f * rnd();
+      pts[(size_t)b * 2 * N + n] = (n < 80) ? r * std::cos(ang) : cx + 0.6f * rnd();
+      pts[(size_t)b * 2 * N + N + n] = (n < 80) ? r * std::sin(ang) : cy + 0.6f * rnd();
     }
   }
   const size_t wsb = npa_workspace_bytes(h, B), stb = npa_state_bytes(h, B);
@@ -1054,20 +1150,31 @@ static int npa_self_test(npa_handle* h) {
   if (memcmp(o0.data(), o1.data(), n_su * 4) != 0)
     return fail(NPA_E_UNSUPPORTED, "npa_create self-test: two runs of the same forward call differ (non-deterministic kernel: "
                                    "this build / runtime combination is not usable; library built with hipcc " NPA_HIPCC_VERSION ")");
+  // HARD failures are the two things no valid configuration can produce: a run-to-run difference (above) and a control
+  // that is not finite or leaves its box.  Warm against cold is a SOFT check: two converged solves of a QP that is flat
+  // along steering directions (car-like robots, tight bounds, a body overlapping the test cluster) may legitimately
+  // stop 1e-4 apart, so a disagreement only switches the warm start off for this handle (NPA_SELFTEST_WARM_OFF).
   const float* u0 = o0.data() + (size_t)B * 3 * (T + 1);
   const float* u2 = o2.data() + (size_t)B * 3 * (T + 1);
+  float warm_gap = 0.f;
   for (int b = 0; b < B; ++b)
     for (int k = 0; k < 2; ++k)
       for (int t = 0; t < T; ++t) {
         const float a = u0[(size_t)b * 2 * T + k * T + t], c = u2[(size_t)b * 2 * T + k * T + t];
         const double sb = P.speed_bound[k];
-        if (!(a == a) || !(std::fabs(a) < 1e30f) || (std::isfinite(sb) && std::fabs(a) > sb + 1e-4) || std::fabs(a - c) > 1e-4f) {
-          char msg[256];
-          snprintf(msg, sizeof(msg), "npa_create self-test: control [%d][%d][%d] = %g (cold-start solve: %g, bound %g): the QP kernel "
-                                     "misbehaves on this build / runtime (hipcc " NPA_HIPCC_VERSION ")", b, k, t, (double)a, (double)c, sb);
-          return fail(NPA_E_UNSUPPORTED, msg);
-        }
+        for (const float v : {a, c})
+          if (!(v == v) || !(std::fabs(v) < 1e30f) || (std::isfinite(sb) && std::fabs(v) > sb + 1e-4 * (1.0 + sb))) {
+            char msg[256];
+            snprintf(msg, sizeof(msg), "npa_create self-test: control [%d][%d][%d] = %g (bound %g): the QP kernel misbehaves on this "
+                                       "build / runtime (hipcc " NPA_HIPCC_VERSION ")", b, k, t, (double)v, sb);
+            return fail(NPA_E_UNSUPPORTED, msg);
+          }
+        warm_gap = std::max(warm_gap, std::fabs(a - c));
       }
+  if (warm_gap > 1e-4f && h->qp_warm) {
+    h->qp_warm = false;
+    h->selftest_flags |= NPA_SELFTEST_WARM_OFF;
+  }
   if (obs) {
     auto stage = [&](float* o) -> int {
       float* mu = o; float* lam = mu + (size_t)B * (T + 1) * M * E; float* pt = lam + (size_t)B * (T + 1) * M * 2;
@@ -1075,7 +1182,9 @@ static int npa_self_test(npa_handle* h) {
       return npa_dune_stage(h, B, N, d_nom_s, d_pts, nullptr, nullptr, mu, lam, pt, ds, cn, nullptr);
     };
     rc = stage(d_stage[0]);
-    const bool geo2 = h->key_terms == 4 && !h->select_v1 && h->audit_dev;
+    // (reduced-precision rows: the audit is off -- its bound is about the exact network -- so the two runs are a plain
+    // determinism check, like network keys)
+    const bool geo2 = h->key_terms == 4 && !h->select_v1 && h->audit_dev && !h->rows_bf16;
     const unsigned one[4] = {0, 0, 1, 0};
     if (rc == NPA_OK && geo2) HIP_TRY(hipMemcpy(h->audit_dev, one, sizeof(one), hipMemcpyHostToDevice));   // distrust: exact keys
     if (rc == NPA_OK) rc = stage(d_stage[1]);
@@ -1087,19 +1196,36 @@ static int npa_self_test(npa_handle* h) {
     // (rows only, and the number of rows: with NPA_SEL_DEBUG the upper bits of count[] carry candidate statistics, which
     // differ between the two runs by design)
     const size_t n_rows = (size_t)B * (T + 1) * M * (E + 5);
-    bool same = memcmp(s0.data(), s1.data(), n_rows * 4) == 0;
-    for (size_t i = n_rows; i < n_stage && same; ++i) {
-      int c0, c1;
-      memcpy(&c0, &s0[i], 4); memcpy(&c1, &s1[i], 4);
-      same = (c0 & 0xFF) == (c1 & 0xFF);
+    auto same_rows = [&]() {
+      bool eq = memcmp(s0.data(), s1.data(), n_rows * 4) == 0;
+      for (size_t i = n_rows; i < n_stage && eq; ++i) {
+        int c0, c1;
+        memcpy(&c0, &s0[i], 4); memcpy(&c1, &s1[i], 4);
+        eq = (c0 & 0xFF) == (c1 & 0xFF);
+      }
+      return eq;
+    };
+    bool same = same_rows();
+    if (!same && geo2) {
+      // the nomination left a true member out on the test cloud: this handle does not use geometric keys.  Network keys
+      // (calibrated now) take over, and THEIR determinism is checked like that of any network-key handle.
+      HIP_TRY(audit_block_reset(h));
+      HIP_TRY(calibrate_network_keys(h, -1));
+      h->selftest_flags |= NPA_SELFTEST_GEO_REJECTED;
+      rc = stage(d_stage[0]);
+      if (rc == NPA_OK) rc = stage(d_stage[1]);
+      if (rc != NPA_OK) return rc;
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipMemcpy(s0.data(), d_stage[0], n_stage * 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(s1.data(), d_stage[1], n_stage * 4, hipMemcpyDeviceToHost));
+      same = same_rows();
     }
     if (!same)
-      return fail(NPA_E_UNSUPPORTED, geo2 ? "npa_create self-test: the geometric-key selection differs from the exact whole-slice "
-                                            "selection on the test cloud (margin or kernel broken on this build / runtime)"
-                                          : "npa_create self-test: two runs of the DUNE stage differ (non-deterministic keys)");
+      return fail(NPA_E_UNSUPPORTED, "npa_create self-test: two runs of the DUNE stage differ (non-deterministic keys: this build / "
+                                     "runtime combination is not usable; library built with hipcc " NPA_HIPCC_VERSION ")");
   }
   // leave no trace: counters, sequence numbers, the key policy's window
-  if (h->audit_dev) HIP_TRY(hipMemset(h->audit_dev, 0, 8 * sizeof(unsigned)));
+  HIP_TRY(audit_block_reset(h));
   if (h->sel_stats_dev) HIP_TRY(hipMemset(h->sel_stats_dev, 0, sizeof(unsigned)));
   if (h->sel_stats_host) *h->sel_stats_host = 0;
   h->launch_seq = 0; h->stats_mark = 0; h->tiles_window = 0; h->calls_window = 0; h->hold = 0;

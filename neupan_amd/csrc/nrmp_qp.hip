@@ -1717,13 +1717,14 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
   const size_t shmem = npa_qp_shmem_bytes_path(P.T, P.M, fast ? 1 : 0);      // one scene (wave) per workgroup, see the kernel
   // (T = 20 without the wide scans keeps Phi: npa_qp_shmem_bytes_path follows the same switch)
   const int nblocks = batch;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static NpaDeviceOnce attr_set;       // (per device: the attribute is, and a process may hold handles on several GPUs)
+  int dev_ = 0;
+  if (attr_set.need(&dev_)) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<10, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<20, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<20, 10, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+    attr_set.done(dev_);
   }
 #define QP_LAUNCH(...)                                                                                           \
   hipExtLaunchKernelGGL((nrmp_qp_kernel<__VA_ARGS__>), dim3(nblocks), dim3(QP_THREADS), shmem, stream, ev_start, ev_stop, 0, \
@@ -1750,12 +1751,13 @@ extern "C" hipError_t npa_launch_qp_backward(const DevParams& P, int batch, cons
   static const bool force_generic = getenv("NPA_QP_GENERIC") != nullptr;
   const bool fast = qp_fast_path(P.T, P.M) && !force_generic && (P.T <= 16 || qp_scan_wide());
   const size_t wave_bytes = npa_qp_shmem_bytes_path(P.T, P.M, fast ? 1 : 0);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static NpaDeviceOnce attr_set;
+  int dev_ = 0;
+  if (attr_set.need(&dev_)) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<10, 10, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<20, 10, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+    attr_set.done(dev_);
   }
   // (the register-resident instantiations since round 3: the gradient pass reads the multiplier directions of the d rows
   // from their owner lanes; NPA_QP_GENERIC=1 keeps the LDS kernel)

@@ -2,11 +2,27 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #define NPA_MAX_T 21
 #define NPA_MAX_M 32
 #define NPA_MAX_E 8
 #define NPA_MAX_POINTS 32768       // points per scene after decimation (select_kernel keeps a slice's keys in LDS)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE attribute, and launches come from several host threads
+// (serve.StepLoop): one bit per device ordinal instead of a process-wide `static bool` -- a second handle on another GPU of
+// the same process gets its attribute too, and concurrent first launches at worst set it twice.
+struct NpaDeviceOnce {
+  std::atomic<unsigned long long> mask{0};
+  // true when the attribute still has to be set on the current device (then call done() after setting it)
+  bool need(int* dev_out) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) d = 0;
+    *dev_out = d;
+    return !(mask.load(std::memory_order_acquire) & (1ull << (d & 63)));
+  }
+  void done(int d) { mask.fetch_or(1ull << (d & 63), std::memory_order_release); }
+};
 
 // Kernel-argument copy of npa_config (include/neupan_amd.h), passed by value.
 struct DevParams {
@@ -80,7 +96,12 @@ __host__ __device__ inline int npa_geo_band(float g) {
 // A-fragments with four 16-byte loads per lane right before the layer that uses them (16 + 16 registers for two layers in
 // flight instead of 64 for all four: that is what lets the kernel fit 128 registers without spills)
 #define WP_WLS (((WP_GEO + NPA_GEO_BANDS) + 3) & ~3)
-#define WP_TOTAL (WP_WLS + 4 * 64 * 16)
+// the four 32x32 layers as bf16 A-fragments of v_mfma_f32_32x32x16_bf16 (the labelled reduced-precision tier of the ROWS,
+// NPA_ROWS_PRECISION=bf16): [layer 4][K-step 2][lane 64][8 bf16], lane l holds W[i = l&31][feat(8 s + q, l >> 5)] -- the
+// exact network's weights rounded to bf16 (RNE), no scaling, no centring
+#define WP_WB16 (WP_WLS + 4 * 64 * 16)
+#define WP_WB16_FLOATS (4 * 2 * 64 * 4)
+#define WP_TOTAL (WP_WB16 + WP_WB16_FLOATS)
 // order of the per-feature vectors
 enum { V_B1 = 0, V_G1, V_BE1, V_B2, V_B3, V_G2, V_BE2, V_B4, V_B5, V_G3, V_BE3 };
 

@@ -378,10 +378,13 @@ class PAN(torch.nn.Module):
             check(lib.npa_forward_end(h), "npa_forward_end")
         out, self._pending = self._pending, None
         self.last_out = out
+        self._calls = getattr(self, "_calls", 0) + 1
+        if (self._calls & 63) == 0:                  # (a host read of one pinned word: no synchronisation)
+            self.check_audit()
         return out
 
     def make_step(self, nom_s, nom_u, ref_s, ref_us, points=None, velocities=None, n_points=None, reset_state=False,
-                  graph=False, out_u=None):
+                  graph=False, out_u=None, reset_every_step=False):
         """Serving-loop form of forward_batch: validate and convert the arguments ONCE and return `step()`, which plans
         the batch with ONE library call (npa_forward_batch_flags) on the current stream and returns the same dict of
         output tensors every time -- they are allocated here and REUSED (forward_batch returns fresh tensors per call,
@@ -389,10 +392,23 @@ class PAN(torch.nn.Module):
         a dozen ctypes calls were a third of a step's wall time).  The input tensors are read in place at every step():
         refresh them with copy_() between steps.  out_u: a caller-owned (B, 2, T) tensor the controls are written to (e.g. a
         slot of a gather staging buffer, neupan_amd.serve.ControlGatherer).
+        reset_state applies to the priming forward run here ONLY (a fresh planner); step() then carries the stop
+        criterion's memory, the QP warm start and the persisted min_distance from call to call like the reference's PAN
+        object does.  reset_every_step=True makes EVERY step() start from a cleared state (a benchmark whose steps must
+        all do the same work; bench.py).
+        step() re-validates what it captured: the input tensors must still live at the addresses they had here (a
+        tensor that was resize_()d / set_() / moved raises instead of planning stale memory; REBINDING a Python name to a
+        new tensor cannot be seen -- refresh inputs with copy_()), and every 64th call polls the margin audit
+        (check_audit) and warns once if the geometric-key margin was ever violated.
         graph=True: the step's launches (staging + K x {selection, QP}) are recorded once into a HIP graph and step()
         replays it: one graph launch instead of 1 + 2K kernel launches on the host (the kernels, their order and their
         results are the same; the per-launch profiling events of profile() do not exist inside a graph)."""
-        self.forward_begin(nom_s, nom_u, ref_s, ref_us, points, velocities, n_points, reset_state=reset_state, out_u=out_u)
+        # the caller's own device tensors (read in place by every step): their address and shape are re-checked per call
+        watched = [(t, t.data_ptr(), tuple(t.shape)) for t in (nom_s, nom_u, ref_s, ref_us, points, velocities, n_points, out_u)
+                   if isinstance(t, torch.Tensor) and t.device == self.device and t.is_contiguous()
+                   and t.dtype in (torch.float32, torch.int32)]
+        self.forward_begin(nom_s, nom_u, ref_s, ref_us, points, velocities, n_points,
+                           reset_state=(reset_state or reset_every_step), out_u=out_u)
         for k in range(self.iter_num):               # (the first step also runs here: buffers and the handle are warm)
             self.forward_iter(k)
         out = self.forward_end()
@@ -406,8 +422,22 @@ class PAN(torch.nn.Module):
         args = (h, B, n_stride, _ptr(nom_s), _ptr(nom_u), _ptr(ref_s), _ptr(ref_us), _ptr(pts), _ptr(vel), _ptr(npt),
                 _ptr(out["opt_s"]), _ptr(out["opt_u"]), _ptr(out["opt_d"]), _ptr(out["min_distance"]), _ptr(out["iters"]),
                 _ptr(out["nrmp_points"]), _ptr(ws), ws.numel(), _ptr(state), state.numel())
-        flags = 2 if reset_state else 0
+        flags = 2 if reset_every_step else 0
         fn = lib.npa_forward_batch_flags
+        # what step() re-validates per call: (tensor, address captured here) of every buffer the library call reads or writes
+        held = [t for t in (nom_s, nom_u, ref_s, ref_us, pts, vel, npt, out["opt_s"], out["opt_u"], out["opt_d"],
+                            out["min_distance"], out["iters"], out["nrmp_points"], ws, state) if t is not None]
+        held_ptrs = tuple(t.data_ptr() for t in held)
+        calls = [0]
+
+        def validate():
+            if tuple(t.data_ptr() for t in held) != held_ptrs or \
+                    any(t.data_ptr() != p0 or tuple(t.shape) != sh for t, p0, sh in watched):
+                raise NeupanAmdError("PAN.make_step: a tensor captured at prepare time has moved or changed shape (resize_ / "
+                                     "set_ / a new workspace): step() would plan stale memory -- make the step again")
+            calls[0] += 1
+            if (calls[0] & 63) == 0:
+                self.check_audit()
         cur_stream = torch.cuda.current_stream
         idx = dev.index if dev.index is not None else torch.cuda.current_device()
 
@@ -423,6 +453,7 @@ class PAN(torch.nn.Module):
             cur_stream(dev).wait_stream(side)
 
             def step_graph():
+                validate()
                 g.replay()
                 self._last = last
                 self.last_out = out
@@ -432,6 +463,7 @@ class PAN(torch.nn.Module):
             return step_graph
 
         def step():
+            validate()
             if cur_dev() != idx:                     # the launches must see the device of the handle
                 with torch.cuda.device(dev):
                     rc = fn(*args, C.c_void_p(cur_stream(dev).cuda_stream), flags)
@@ -645,6 +677,40 @@ class PAN(torch.nn.Module):
         with torch.cuda.device(self.device):
             check(self._lib.npa_audit_read(self._h, C.byref(t), C.byref(p), C.byref(v), C.byref(w), 1 if reset else 0), "npa_audit_read")
         return dict(tiles=t.value, points=p.value, violations=v.value, worst_excess=w.value)
+
+    def check_audit(self, fallback=False):
+        """Poll the margin audit WITHOUT synchronising the device (npa_audit_peek: the selection kernel mirrors violations
+        into pinned host memory).  Returns the violation count.  Non-zero: a real point exceeded the measured margin of the
+        geometric keys -- the launch that saw it may have planned from a selection that missed a member, every launch
+        since ran on exact keys (slow, right).  Warns once; fallback=True also switches the handle to network keys for
+        good (npa_use_network_keys: buffers are re-made on the next forward_batch, prepared steps must be made again)."""
+        if self.no_obs or not self._h.value:
+            return 0
+        v = C.c_uint64()
+        check(self._lib.npa_audit_peek(self._h, C.byref(v)), "npa_audit_peek")
+        if v.value:
+            if not getattr(self, "_audit_warned", False):
+                import warnings
+                warnings.warn(f"neupan_amd: the geometric-key margin of this checkpoint was violated at run time ({v.value} "
+                              "points): the selection kernel has switched to exact keys; plans of the launch that detected "
+                              "it are suspect.  Call PAN.use_network_keys() or rebuild with NPA_KEY_TERMS=1.", RuntimeWarning)
+                self._audit_warned = True
+            if fallback:
+                self.use_network_keys()
+        return int(v.value)
+
+    def use_network_keys(self):
+        """Switch this planner from geometric to network keys for good (npa_use_network_keys)."""
+        with torch.cuda.device(self.device):
+            check(self._lib.npa_use_network_keys(self._h), "npa_use_network_keys")
+        self._B = 0                                  # the workspace grows by the key buffer: re-made on the next call
+        self._ws = self._state = None
+
+    def selftest_flags(self):
+        """What the create-time self-test changed: dict(warm_off, geo_rejected) (npa_selftest_flags)."""
+        f = C.c_int()
+        check(self._lib.npa_selftest_flags(self._h, C.byref(f)), "npa_selftest_flags")
+        return dict(warm_off=bool(f.value & 1), geo_rejected=bool(f.value & 2))
 
     def last_qp_info(self):
         """(B,16) float64: per-scene diagnostics of the last QP solved by forward_batch

@@ -1,123 +1,151 @@
-"""The serving loop bench.py times, as a library function: `inflight` independent batches kept in flight, one stream each,
-the per-step all-gather of the controls issued from ONE dedicated communication stream.
+"""The serving loop bench.py times, as a library: `inflight` independent batches kept in flight (one stream each), their
+launches issued from a few host threads, and the controls of every step all-gathered across the ranks in COALESCED
+collectives on one communication stream.
 
-Why one comm stream: collectives on one communicator execute in issue order on every rank.  Issued from the batches'
-own streams (20 of them), each all-gather also waited for whatever that stream had queued, and every step became a
-cross-rank rendezvous in the middle of a compute chain.  Here a step's gather waits for exactly one event -- that step's
-last kernel -- on a stream that carries nothing else, and the ranks meet in the same order by construction (step i's
-gather is the i-th collective everywhere).
+Protocol of the gather (ControlGatherer), identical on every rank and on every device type:
 
-Device-agnostic on purpose: with `streams=None` (CPU tensors, gloo) the same schedule runs synchronously, which is how
-tests/test_dist_gloo.py drives it with two ranks.
+  * steps carry a global index i = 0, 1, 2, ... (the same on all ranks: every rank runs the same number of steps);
+    group g = i // slots, row r = i % slots, buffer parity p = g & 1;
+  * stage(i, opt_u, stream): whoever issued step i copies its controls, behind the step on the step's own stream, into
+    row r of staging buffer p -- after the flush of group g - 2 (the previous reader of that row) has been issued (host:
+    a condition variable, no spinning) and has completed (device: an event wait on the step's stream);
+  * collect(i): ONE thread, in step order: the communication stream waits for row r's copy; when the group is complete
+    one all-gather moves staging buffer p into result buffer p (world x slots rows).  The collectives are therefore
+    issued in the same order on every rank whatever the issuing threads' relative progress;
+  * join(): flushes a trailing partial group (every rank has the same one) and makes the current stream wait for the
+    communication stream.  The next run starts on a fresh group.
+
+A result row (world, B, 2, T) returned by collect() is valid once its group's collective has run (join() guarantees it
+for everything issued) and is overwritten two groups later.  Every step's controls cross the fabric inside the loop, in
+1/slots as many collectives as steps: a collective per step from 20 chains cost 25 % of the throughput even with ONE
+rank (504 k vs 668 k plans/s, round 3).
+
+Device-agnostic on purpose: with device=None the same protocol -- staging rows, parity alternation, flush order,
+trailing group, worker threads -- runs on CPU tensors over gloo; tests/test_dist_gloo.py drives it with two ranks, several
+issuing threads per rank, fewer steps than slots and uneven progress between the ranks.
 """
 from __future__ import annotations
 
+import threading
+
 import torch
 
-from .dist import gather_controls
+
+class _NullEvent:
+    def record(self, stream=None):
+        pass
 
 
 class ControlGatherer:
-    """All-gather of the steps' controls behind their work, on a stream of its own (or inline on CPU).
-
-    On a GPU the gathers are COALESCED: behind every step its controls are copied (on the step's own stream, so the next
-    step of that planner cannot overtake the copy) into that slot's row of a staging buffer [slots][B][2][T], and ONE
-    all_gather_into_tensor per `slots` steps moves the buffer -- every step's controls still cross the fabric inside the
-    loop, in 1/slots as many collectives (a collective per step from 20 chains cost 25 % of the throughput with ONE rank:
-    504 k vs 668 k plans/s).  Two staging / result buffers alternate by group, and a row is rewritten only after the
-    gather that read it two groups earlier has completed (an event wait that has practically always passed).
-    after_step() is called by whoever issues the step (possibly a worker thread), gather() by one thread in step order:
-    the collectives are issued in the same order on every rank."""
+    """Coalesced all-gather of the steps' controls (module docstring).  dist=None (or an uninitialised process group):
+    inactive -- collect() hands the step's own controls back and nothing is staged."""
 
     def __init__(self, dist=None, world: int = 1, device=None, slots: int = 1, shape=None):
-        self.dist, self.world, self.slots = dist, world, slots
-        self.active = dist is not None and dist.is_initialized()
-        self.cuda = device is not None and torch.device(device).type == "cuda"
-        self.comm = torch.cuda.Stream(device=device) if (self.active and self.cuda) else None
-        self.issued = 0              # gather() calls
+        self.dist, self.world, self.slots = dist, int(world), max(1, int(slots))
+        self.active = dist is not None and dist.is_initialized() and shape is not None
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        self.cuda = self.device.type == "cuda"
+        self.issued = 0              # steps handed to collect()
         self.collectives = 0         # collectives actually issued
-        self.coalesce = self.comm is not None and shape is not None
-        if self.coalesce:
-            self.stage = [torch.empty((slots,) + tuple(shape), dtype=torch.float32, device=device) for _ in range(2)]
-            self.out = [torch.empty((world, slots) + tuple(shape), dtype=torch.float32, device=device) for _ in range(2)]
-            self.copied = [[torch.cuda.Event() for _ in range(slots)] for _ in range(2)]
-            self.flushed = [None, None]          # event behind the last all-gather that read stage[parity]
-            self.group_of = [0] * slots          # how many steps each slot has staged
-            self.gathered_of = [0] * slots
-            self.pending = [0, 0]
-            self.flush_gen = [0, 0]              # all-gathers issued per staging buffer
-            self.gen_at = [[-1] * slots for _ in range(2)]   # flush_gen when a slot last contributed to that buffer
-        elif self.comm is not None:
-            self.events = [torch.cuda.Event() for _ in range(slots)]
-
-    def after_step(self, opt_u: torch.Tensor, slot: int, stream=None):
-        """Stage a finished step's controls (call right after issuing the step, on the thread that issued it; `stream` = the
-        step's stream, default the current one)."""
-        if not self.coalesce:
+        self._next = 0               # first index of the next run (a multiple of slots)
+        if not self.active:
             return
-        st = stream if stream is not None else torch.cuda.current_stream(opt_u.device)
-        par = self.group_of[slot] & 1
-        # (an issuing thread that runs ahead: the row's previous occupant -- two steps of this slot ago -- must have been
-        # handed to the gather, or its flush event does not exist yet)
-        import time
-        while self.gathered_of[slot] < self.group_of[slot] - 1 or \
-                (self.group_of[slot] >= 2 and self.flush_gen[par] <= self.gen_at[par][slot]):
-            time.sleep(0)
-        fl = self.flushed[par]
-        with torch.cuda.stream(st):
-            if fl is not None:
-                st.wait_event(fl)                # the gather that read this row two groups ago
-            self.stage[par][slot].copy_(opt_u, non_blocking=True)
-            self.copied[par][slot].record(st)
-        self.group_of[slot] += 1
+        self.comm = torch.cuda.Stream(device=self.device) if self.cuda else None
+        shape = tuple(shape)
+        kw = dict(dtype=torch.float32, device=self.device)
+        self.stage_buf = [torch.zeros((self.slots,) + shape, **kw) for _ in range(2)]
+        self.out = [torch.zeros((self.world, self.slots) + shape, **kw) for _ in range(2)]
+        mk = (lambda: torch.cuda.Event()) if self.cuda else (lambda: _NullEvent())
+        self._copied = [[mk() for _ in range(self.slots)] for _ in range(2)]
+        self._flush_ev = [None, None]            # event behind the last all-gather that read stage_buf[parity]
+        self._cv = threading.Condition()
+        self._staged_group = [[-1] * self.slots for _ in range(2)]   # group whose controls row (parity, r) holds
+        self._flushed = 0                        # groups flushed so far (groups flush in order)
+        self._pending = 0                        # rows of the current group handed to collect()
+        self._cur_group = 0
+        self._gloo = dist.get_backend() == "gloo"
 
-    def gather(self, opt_u: torch.Tensor, slot: int = 0, producer=None):
-        """Hand a step's controls to the gather (one thread, step order).  Returns the gathered controls of that step:
-        (world x B, 2, T), or a (world, B, 2, T) view of the coalesced result -- valid once the slot's group has been gathered
-        (join() makes everything valid on the current stream)."""
+    # ------------------------------------------------------------------ indices
+    def begin(self, n: int) -> int:
+        """Reserve the indices of a run of n steps: returns the index of its first step (group aligned)."""
+        base = self._next
+        self._next = base + (n + self.slots - 1) // self.slots * self.slots
+        return base
+
+    # ------------------------------------------------------------------ issuing threads
+    def stage(self, i: int, opt_u: torch.Tensor, stream=None):
+        """Stage the controls of step i behind the step (call on the thread that issued it; stream = the step's stream,
+        default the current one)."""
+        if not self.active:
+            return
+        g, r = divmod(i, self.slots)
+        p = g & 1
+        with self._cv:
+            # the row's previous occupant (group g - 2) must have been handed to its all-gather
+            self._cv.wait_for(lambda: self._flushed >= g - 1)
+            fl = self._flush_ev[p] if g >= 2 else None
+        if self.cuda:
+            st = stream if stream is not None else torch.cuda.current_stream(self.device)
+            with torch.cuda.stream(st):
+                if fl is not None:
+                    st.wait_event(fl)
+                self.stage_buf[p][r].copy_(opt_u, non_blocking=True)
+                self._copied[p][r].record(st)
+        else:
+            self.stage_buf[p][r].copy_(opt_u)
+        with self._cv:
+            self._staged_group[p][r] = g
+            self._cv.notify_all()
+
+    # ------------------------------------------------------------------ the collecting thread (one, in step order)
+    def collect(self, i: int, opt_u: torch.Tensor | None = None):
+        """Hand step i to the gather.  Returns the gathered controls of that step, a (world, B, 2, T) view of the result
+        buffer (inactive gatherer: opt_u itself)."""
+        self.issued += 1
         if not self.active:
             return opt_u
-        self.issued += 1
-        if self.comm is None:
-            self.collectives += 1
-            return gather_controls(opt_u, self.dist, self.world, equal_shards=True)
-        if not self.coalesce:
-            ev = self.events[slot]
-            ev.record(producer if producer is not None else torch.cuda.current_stream(opt_u.device))
-            self.comm.wait_event(ev)
-            with torch.cuda.stream(self.comm):
-                out = gather_controls(opt_u, self.dist, self.world, equal_shards=True)
-            opt_u.record_stream(self.comm)
-            self.collectives += 1
-            return out
-        if self.group_of[slot] == self.gathered_of[slot]:     # the caller did not stage it: do it here, on the producer's stream
-            self.after_step(opt_u, slot, producer)
-        par = self.gathered_of[slot] & 1
-        self.gathered_of[slot] += 1
-        self.comm.wait_event(self.copied[par][slot])
-        self.gen_at[par][slot] = self.flush_gen[par]
-        self.pending[par] += 1
-        if self.pending[par] >= self.slots:
-            self._flush(par)
-        return self.out[par][:, slot]
+        g, r = divmod(i, self.slots)
+        p = g & 1
+        if g != self._cur_group:                 # (a new run after join(): groups are consecutive, rows start at 0)
+            assert self._pending == 0 and g == self._flushed, "collect() out of order"
+            self._cur_group = g
+        with self._cv:
+            self._cv.wait_for(lambda: self._staged_group[p][r] == g)
+        if self.cuda:
+            self.comm.wait_event(self._copied[p][r])
+        self._pending += 1
+        if r == self.slots - 1:
+            self._flush(g)
+        return self.out[p][:, r]
 
-    def _flush(self, par):
-        with torch.cuda.stream(self.comm):
-            self.dist.all_gather_into_tensor(self.out[par].view(-1), self.stage[par].view(-1))
-            ev = torch.cuda.Event()
-            ev.record(self.comm)
-        self.flushed[par] = ev
-        self.flush_gen[par] += 1
+    def _flush(self, g):
+        p = g & 1
+        ev = None
+        if self.cuda:
+            with torch.cuda.stream(self.comm):
+                self.dist.all_gather_into_tensor(self.out[p].view(-1), self.stage_buf[p].view(-1))
+                ev = torch.cuda.Event()
+                ev.record(self.comm)
+        elif self._gloo:
+            self.dist.all_gather([self.out[p][w] for w in range(self.world)], self.stage_buf[p])
+        else:
+            self.dist.all_gather_into_tensor(self.out[p].view(-1), self.stage_buf[p].view(-1))
         self.collectives += 1
-        self.pending[par] = 0
+        self._pending = 0
+        with self._cv:
+            self._flush_ev[p] = ev
+            self._flushed = g + 1
+            self._cur_group = g + 1
+            self._cv.notify_all()
 
     def join(self, stream=None):
-        if self.comm is not None:
-            if self.coalesce:
-                for par in (0, 1):
-                    if self.pending[par] > 0:
-                        self._flush(par)
-            (stream if stream is not None else torch.cuda.current_stream(self.comm.device)).wait_stream(self.comm)
+        """Flush a trailing partial group; the current stream (or `stream`) then waits for every collective issued."""
+        if not self.active:
+            return
+        if self._pending > 0:
+            self._flush(self._cur_group)
+        if self.cuda:
+            (stream if stream is not None else torch.cuda.current_stream(self.device)).wait_stream(self.comm)
 
 
 def run_steps(n: int, steps, streams=None, gatherer: ControlGatherer | None = None, cur=None):
@@ -126,6 +154,7 @@ def run_steps(n: int, steps, streams=None, gatherer: ControlGatherer | None = No
     Returns the last (out, gathered) of every slot.  Nothing synchronises the host."""
     nfl = len(steps)
     last = [None] * nfl
+    base = gatherer.begin(n) if gatherer is not None else 0
     if streams is not None:
         for st in streams:
             st.wait_stream(cur)
@@ -135,33 +164,34 @@ def run_steps(n: int, steps, streams=None, gatherer: ControlGatherer | None = No
             with torch.cuda.stream(streams[j]):
                 o = steps[j]()
             if gatherer is not None:
-                gatherer.after_step(o["opt_u"], j, streams[j])
-            g = gatherer.gather(o["opt_u"], j, streams[j]) if gatherer is not None else o["opt_u"]
+                gatherer.stage(base + i, o["opt_u"], streams[j])
         else:
             o = steps[j]()
-            g = gatherer.gather(o["opt_u"], j) if gatherer is not None else o["opt_u"]
+            if gatherer is not None:
+                gatherer.stage(base + i, o["opt_u"])
+        g = gatherer.collect(base + i, o["opt_u"]) if gatherer is not None else o["opt_u"]
         last[j] = (o, g)
     if streams is not None:
         for st in streams:
             cur.wait_stream(st)
-        if gatherer is not None:
-            gatherer.join(cur)
+    if gatherer is not None:
+        gatherer.join(cur)
     return last
 
 
 class StepLoop:
     """run_steps with the launches issued from several host threads: slot j (one planner, one stream) belongs to thread
-    j % threads, which issues that slot's steps in order (a handle plans one batch at a time); the main thread hands every
-    step's controls to the gatherer in step order.  One Python thread needs ~5 us per kernel launch -- 0.11 ms for the 21
-    launches of a step -- which is what a short timed region mostly measures; the library call releases the GIL, so the
-    launches of different planners proceed in parallel.  threads = 0: plain run_steps."""
+    j % threads, which issues that slot's steps in order (a handle plans one batch at a time) and stages their controls;
+    the calling thread hands every step to the gatherer in step order.  One Python thread needs ~5 us per kernel launch
+    -- 0.11 ms for the 21 launches of a step -- which is what a short timed region mostly measures; the library call
+    releases the GIL, so the launches of different planners proceed in parallel.  threads = 0: plain run_steps.
+    streams=None (CPU stand-in planners, tests): the same threading without streams."""
 
     def __init__(self, steps, streams, gatherer=None, cur=None, threads=0):
         import queue
-        import threading
         self.steps, self.streams, self.gatherer, self.cur = steps, streams, gatherer, cur
         self.nfl = len(steps)
-        self.threads = min(int(threads), self.nfl) if streams is not None else 0
+        self.threads = min(int(threads), self.nfl)
         self._q = [queue.Queue() for _ in range(self.threads)]
         self._workers = []
         self._err = None
@@ -170,21 +200,30 @@ class StepLoop:
             t.start()
             self._workers.append(t)
 
+    def _issue(self, i, base):
+        j = i % self.nfl
+        if self.streams is not None:
+            with torch.cuda.stream(self.streams[j]):
+                o = self.steps[j]()
+            if self.gatherer is not None:
+                self.gatherer.stage(base + i, o["opt_u"], self.streams[j])
+        else:
+            o = self.steps[j]()
+            if self.gatherer is not None:
+                self.gatherer.stage(base + i, o["opt_u"])
+        return o
+
     def _work(self, w):
         while True:
             cmd = self._q[w].get()
             if cmd is None:
                 return
-            n, outs, evs = cmd
+            n, base, outs, evs = cmd
             try:
                 for i in range(n):
-                    j = i % self.nfl
-                    if j % self.threads != w:
+                    if (i % self.nfl) % self.threads != w:
                         continue
-                    with torch.cuda.stream(self.streams[j]):
-                        outs[i] = self.steps[j]()
-                    if self.gatherer is not None:
-                        self.gatherer.after_step(outs[i]["opt_u"], j, self.streams[j])
+                    outs[i] = self._issue(i, base)
                     evs[i].set()
             except BaseException as e:      # surface it in run(); unblock the main thread
                 self._err = e
@@ -194,23 +233,25 @@ class StepLoop:
     def run(self, n):
         if self.threads == 0:
             return run_steps(n, self.steps, self.streams, self.gatherer, self.cur)
-        import threading
         last = [None] * self.nfl
-        for st in self.streams:
-            st.wait_stream(self.cur)
+        base = self.gatherer.begin(n) if self.gatherer is not None else 0
+        if self.streams is not None:
+            for st in self.streams:
+                st.wait_stream(self.cur)
         outs, evs = [None] * n, [threading.Event() for _ in range(n)]
         for q in self._q:
-            q.put((n, outs, evs))
+            q.put((n, base, outs, evs))
         for i in range(n):
             evs[i].wait()
             if self._err is not None:
                 raise self._err
             j = i % self.nfl
             o = outs[i]
-            g = self.gatherer.gather(o["opt_u"], j, self.streams[j]) if self.gatherer is not None else o["opt_u"]
+            g = self.gatherer.collect(base + i, o["opt_u"]) if self.gatherer is not None else o["opt_u"]
             last[j] = (o, g)
-        for st in self.streams:
-            self.cur.wait_stream(st)
+        if self.streams is not None:
+            for st in self.streams:
+                self.cur.wait_stream(st)
         if self.gatherer is not None:
             self.gatherer.join(self.cur)
         return last

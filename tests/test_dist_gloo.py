@@ -85,64 +85,111 @@ def test_rccl_all_gather_branch_on_one_gpu():
         dist.destroy_process_group()
 
 
-def _loop_worker(rank, world, port, inflight, n_steps, q):
-    """bench.py's serving loop (neupan_amd.serve.run_steps + ControlGatherer) with stand-in planners: `inflight` slots, each
-    step's controls a known function of (rank, slot, how often the slot ran)."""
+def _value(rank, i):
+    """controls of global step i on `rank` (every element)"""
+    return float(10000 * rank + i)
+
+
+def _loop_worker(rank, world, port, inflight, runs, threads, q):
+    """The serving loop (neupan_amd.serve: StepLoop / run_steps + ControlGatherer) with stand-in planners on CPU tensors over
+    gloo: the SAME coalesced protocol the GPU runs (staging rows, alternating buffers, flush order, trailing partial group,
+    consecutive runs on one gatherer), `threads` issuing threads per rank, and uneven progress: rank 1's planners sleep,
+    and its slot 0 sleeps longest."""
+    import time
     import torch.distributed as dist
-    from neupan_amd.serve import ControlGatherer, run_steps
+    from neupan_amd.serve import ControlGatherer, StepLoop
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     B, T = 4, 10
-    runs = [0] * inflight
+    counter = {"base": 0}
+    ran = [0] * inflight
 
     def make(j):
         def step():
-            runs[j] += 1
-            return {"opt_u": torch.full((B, 2, T), float(1000 * rank + 10 * j + runs[j]))}
+            i = counter["base"] + j + inflight * ran[j]          # slot j runs steps j, j + inflight, ... of the current run
+            ran[j] += 1
+            if rank == 1:
+                time.sleep(0.004 if j == 0 else 0.0005 * (j % 3))
+            return {"opt_u": torch.full((B, 2, T), _value(rank, i)), "index": i}
         return step
-    g = ControlGatherer(dist, world, device=None, slots=inflight)
-    last = run_steps(n_steps, [make(j) for j in range(inflight)], None, g, None)
-    rows = []
-    for j, item in enumerate(last):
-        if item is None:
-            rows.append(None)
-            continue
-        o, gathered = item
-        rows.append((tuple(gathered.shape), [float(gathered[r * B, 0, 0]) for r in range(world)]))
-    q.put((rank, rows, g.issued))
+
+    snaps = []
+
+    class Recording(ControlGatherer):
+        def _flush(self, g):
+            rows = self._pending
+            super()._flush(g)
+            snaps.append((g, rows, self.out[g & 1][:, :, 0, 0, 0].clone()))       # (world, slots): first element of every row
+
+    g = Recording(dist, world, device=None, slots=inflight, shape=(B, 2, T))
+    loop = StepLoop([make(j) for j in range(inflight)], None, g, None, threads=threads)
+    report = []
+    for n in runs:
+        base = g._next
+        counter["base"] = base
+        for j in range(inflight):
+            ran[j] = 0
+        last = loop.run(n)
+        rows = []
+        for j, item in enumerate(last):
+            if item is None:
+                rows.append(None)
+                continue
+            o, gathered = item
+            rows.append((o["index"], tuple(gathered.shape), [float(gathered[r, 0, 0, 0]) for r in range(world)]))
+        report.append((base, rows))
+    loop.close()
+    q.put((rank, report, [(gg, rows, t.tolist()) for gg, rows, t in snaps], g.issued, g.collectives))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("inflight,n_steps", [(1, 3), (4, 10), (5, 3)])
-def test_serving_loop_schedule_with_two_ranks(inflight, n_steps):
-    """The schedule bench.py times, two ranks over gloo: one gather per step, issued in step order on every rank (no
-    deadlock with several slots in flight, also when fewer steps than slots run), every rank sees every rank's controls
-    of the SAME step in rank order."""
+@pytest.mark.parametrize("inflight,runs,threads", [(1, (3,), 0), (4, (10,), 0), (5, (3,), 0), (5, (3, 12, 23), 3), (4, (9, 2, 8), 2)])
+def test_serving_loop_with_two_ranks(inflight, runs, threads):
+    """Two ranks over gloo drive the coalesced gather exactly as the GPU loop does: every group's collective carries the
+    controls of the SAME steps from both ranks, in rank order; one collective per `inflight` steps plus one per trailing
+    partial group; no deadlock with several issuing threads, fewer steps than slots, or a slow rank; consecutive runs on
+    one gatherer start on fresh groups."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_loop_worker, args=(r, 2, port, inflight, n_steps, q)) for r in range(2)]
+    procs = [ctx.Process(target=_loop_worker, args=(r, 2, port, inflight, runs, threads, q)) for r in range(2)]
     for p in procs:
         p.start()
     got = {}
     for _ in range(2):
-        rank, rows, issued = q.get(timeout=120)
-        got[rank] = rows
-        assert issued == n_steps
+        rank, report, snaps, issued, collectives = q.get(timeout=180)
+        got[rank] = (report, snaps)
+        assert issued == sum(runs)
+        assert collectives == sum((n + inflight - 1) // inflight for n in runs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert got[0] == got[1]
-    for j, row in enumerate(got[0]):
-        ran = len(range(j, n_steps, inflight))           # how often slot j ran
-        if ran == 0:
-            assert row is None
-            continue
-        shape, firsts = row
-        assert shape == (2 * 4, 2, 10)
-        assert firsts == [float(1000 * r + 10 * j + ran) for r in range(2)]
+    assert got[0] == got[1]                       # both ranks saw the same gathered data, group by group
+    report, snaps = got[0]
+    # every collective: row r of group g holds step g * inflight + r of BOTH ranks
+    expect_groups = []
+    base = 0
+    for n in runs:
+        for k in range((n + inflight - 1) // inflight):
+            expect_groups.append((base // inflight + k, min(inflight, n - k * inflight)))
+        base += (n + inflight - 1) // inflight * inflight
+    assert [(g, rows) for g, rows, _ in snaps] == expect_groups
+    for g, rows, t in snaps:
+        for r in range(rows):
+            assert [t[w][r] for w in range(2)] == [_value(w, g * inflight + r) for w in range(2)], (g, r)
+    # what run() returns per slot: the gathered controls of that slot's last step
+    for (base, rows), n in zip(report, runs):
+        for j, row in enumerate(rows):
+            times = len(range(j, n, inflight))
+            if times == 0:
+                assert row is None
+                continue
+            idx, shape, firsts = row
+            assert idx == base + j + inflight * (times - 1)
+            assert shape == (2, 4, 2, 10)
+            assert firsts == [_value(w, idx) for w in range(2)]
 
 
 @pytest.mark.gpu
@@ -162,12 +209,13 @@ def test_coalesced_gather_over_rccl_on_one_gpu():
         streams = [torch.cuda.Stream(device=dev) for _ in range(slots)]
         outs = [torch.empty((B, 2, T), device=dev) for _ in range(slots)]       # "the planners'" reused output tensors
         views = [None] * slots
+        base = g.begin(7)
         for i in range(7):                       # 2 full groups + 1 trailing step
             j = i % slots
             with torch.cuda.stream(streams[j]):
                 outs[j].fill_(float(100 * i + j))
-            g.after_step(outs[j], j, streams[j])
-            views[j] = g.gather(outs[j], j, streams[j])
+            g.stage(base + i, outs[j], streams[j])
+            views[j] = g.collect(base + i, outs[j])
         g.join()
         torch.cuda.synchronize()
         assert g.issued == 7 and g.collectives == 3
@@ -175,10 +223,13 @@ def test_coalesced_gather_over_rccl_on_one_gpu():
         for j in range(slots):
             assert tuple(views[j].shape) == (1, B, 2, T)
             assert torch.all(views[j] == want[j]), (j, float(views[j].flatten()[0]))
-        # a step whose issuer did not stage it is staged by gather() itself, behind its producer
+        # a second run on the same gatherer starts on a fresh group
+        base = g.begin(1)
+        assert base == 9
         outs[1].fill_(7.0)
-        v = g.gather(outs[1], 1, torch.cuda.current_stream(dev))
+        g.stage(base, outs[1])
+        v = g.collect(base, outs[1])
         g.join(); torch.cuda.synchronize()
-        assert torch.all(v == 7.0)
+        assert torch.all(v == 7.0) and g.collectives == 4
     finally:
         dist.destroy_process_group()
