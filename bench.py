@@ -15,8 +15,18 @@ consecutive steps are different batches of 256 scenes, and the latency-bound ker
 SIMDs the others leave idle.  Every step still executes its full K iterations inside the timed region;
 `--inflight 1` gives the strictly sequential number (also reported: single-scene latency).  Rank 0 prints ONE
 JSON line.
+
+Besides the headline the line carries (rank 0, one GPU, unless --no-extras):
+  extra.paths          the SAME loop with the un-pruned / fallback selections: exact fp32 network keys over every point
+                       (NPA_DUNE_FP32KEYS=1: SURVEY 8(d)'s literal "encoder on every obstacle point x horizon step"), network
+                       keys with single / split fp16 products (NPA_KEY_TERMS=1 / 3: what a checkpoint that fails the
+                       calibration gate gets), each with the encoder's executed MFMA rate against its peak;
+  extra.uniform_cloud  SURVEY 8(d)'s uniform cloud (workload uniform_1k_T10_K10): throughput, candidates per slice, parity;
+  extra.other_configs  BASELINE configs[2], [3], [4] (acker 2k T=20 K=15; 4000 moving points, 1024 scenes per step; 8-edge
+                       hull 5000 points in exact fp32 AND in the labelled bf16 tier): throughput + a 16-scene parity verdict.
 """
 import argparse
+import contextlib
 import hashlib
 import json
 import os
@@ -27,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # One HIP stream per batch in flight; every stream should own a hardware queue, or two batches serialise behind each
-# other.  The runtime's default is 4 queues; 32 covers the 16 batches in flight plus torch's own streams (sweep in
+# other.  The runtime's default is 4 queues; 32 covers the 20 batches in flight plus torch's own streams (sweep in
 # with fewer queues than streams the throughput falls to what that many concurrent chains give).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
@@ -38,19 +48,19 @@ WORKLOAD = "diff_1k_T10_K10"
 BATCH = 256
 # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table (256 CUs x 4 SIMDs, 2.4 GHz)
 PEAK_FP64_VALU_TFLOPS = 78.6
-PEAK_FP32_MFMA_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32: what the exact encoder of select_geo_kernel runs on
-PEAK_F16_MFMA_TFLOPS = 2500.0
+PEAK_FP32_MFMA_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32: what the exact encoder runs on
+PEAK_F16_MFMA_TFLOPS = 2500.0       # dense fp16 / bf16 MFMA
 N_SIMD = 1024
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
-# which source files a kernel's counters depend on (a kernel's PMC record is used only while these are unchanged)
+PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r04_pmc.json", "r03_pmc.json")]     # newest first
+# which source files a kernel's counters depend on (a record is "current" only while these are unchanged)
 KERNEL_SOURCES = {"nrmp_qp_kernel": ("nrmp_qp.hip", "pan_common.h"), "select_geo_kernel": ("dune.hip", "pan_common.h"),
                   "select_kernel": ("dune.hip", "pan_common.h"), "dune_kernel": ("dune.hip", "pan_common.h"),
                   "stage_kernel": ("c_api.hip", "pan_common.h")}
 
 
 def source_hash(files=None):
-    """sha256 over kernel sources (all of neupan_amd/csrc, or the named files): ties the tracked counters to the code
-    they were measured on."""
+    """sha256 over kernel sources (all of neupan_amd/csrc, or the named files): ties tracked counters to the code they
+    were measured on."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "neupan_amd", "csrc")
     for f in sorted(os.listdir(d)) if files is None else files:
@@ -63,8 +73,209 @@ def kernel_hash(kernel):
     return source_hash(KERNEL_SOURCES.get(kernel, None))
 
 
+def load_pmc(workload):
+    """The newest tracked PMC record of this workload (tests/tools/pmc_collect.py), or None."""
+    for f in PMC_FILES:
+        if os.path.exists(f):
+            try:
+                pj = json.load(open(f))
+            except Exception:
+                continue
+            if pj.get("workload") == workload:
+                pj["_file"] = os.path.relpath(f, ROOT)
+                return pj
+    return None
+
+
+@contextlib.contextmanager
+def environ(env):
+    """os.environ updated for the duration (the library reads its knobs when a handle is created)."""
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def make_gpu_pan(cfg, device, **over):
+    from neupan_amd.pan import PAN
+    from neupan_amd.robot import Robot
+    ck = os.path.join(ROOT, "tests", "golden", "checkpoints", f"{cfg.checkpoint}_model_5000.pth")
+    if not os.path.exists(ck):              # the 8-edge stand-in: tests/golden/make_poly8_checkpoint.py
+        ck = os.path.join(ROOT, "tests", "golden", "checkpoints", f"{cfg.checkpoint}_model_quick.pth")
+    kw = dict(iter_num=cfg.iter_num, dune_max_num=cfg.n_points, nrmp_max_num=cfg.nrmp_max_num, iter_threshold=0.0,
+              dune_checkpoint=ck, adjust_kwargs=dict(cfg.adjust), device=device)
+    kw.update(over)
+    return PAN(cfg.T, cfg.dt, Robot(cfg.T, cfg.dt, **cfg.robot), **kw)
+
+
+class Loop:
+    """`nfl` planners of one workload, one stream and one prepared step each (PAN.make_step: arguments validated once, ONE
+    library call per step, output tensors reused; every step starts from a cleared stop-criterion / warm-start state, reset
+    inside the staging launch, so that all steps do the same work), driven by neupan_amd.serve.StepLoop; the controls of
+    every step are all-gathered over RCCL from ONE communication stream when a process group exists.  Planners that carry
+    timing events: every 4th (the events ride on the dispatches: recording two per launch doubles the host's time to enqueue
+    a step)."""
+
+    def __init__(self, workload, batch, nfl, dev, rank=0, world=1, dist=None, env=None, graph=False, issue_threads=4,
+                 scene_index=None):
+        from neupan_amd.scenes import CONFIGS, make_batch
+        from neupan_amd.serve import ControlGatherer, StepLoop
+        self.cfg = cfg = CONFIGS[workload]
+        self.workload, self.batch, self.nfl, self.dev, self.world = workload, batch, nfl, dev, world
+        with environ(env):
+            self.pans = [make_gpu_pan(cfg, device=dev) for _ in range(nfl)]
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
+        self.args = []
+        for j in range(nfl):                    # batch j of this rank: its own scenes
+            b = make_batch(cfg, (rank * nfl + j) * batch, batch)
+            a = [torch.from_numpy(b[k]).to(dev) for k in ("nom_s", "nom_u", "ref_s", "ref_us", "points")]
+            a.append(torch.from_numpy(b["velocities"]).to(dev) if b.get("velocities") is not None else None)
+            if scene_index is not None:         # (a batch made of selected scenes of batch 0, cycled)
+                if j == 0:
+                    self._sel = [t.index_select(0, scene_index).contiguous() if t is not None else None for t in a]
+                a = self._sel
+            self.args.append(a)
+        torch.cuda.synchronize(dev)
+        self.cur = torch.cuda.current_stream(dev)
+        self.timed_idx = set(range(0, nfl, 4)) if nfl >= 4 else set(range(nfl))
+        self.gatherer = ControlGatherer(dist, world, device=dev, slots=nfl, shape=(batch, 2, cfg.T))
+        self.steps = []
+        for j in range(nfl):
+            with torch.cuda.stream(self.streams[j]):
+                self.steps.append(self.pans[j].make_step(*self.args[j], reset_every_step=True,
+                                                          graph=(graph and j not in self.timed_idx)))
+        torch.cuda.synchronize(dev)
+        self.loop = StepLoop(self.steps, self.streams, self.gatherer, self.cur, threads=issue_threads)
+
+    def run(self, n):
+        return self.loop.run(n)
+
+    def timed(self, steps, warmup, barrier=None):
+        """warmup untimed steps, then EXACTLY `steps` steps between (barrier +) synchronize on both sides.
+        Returns dict(elapsed, t_issue, prof, last)."""
+        dev = self.dev
+        self.run(warmup)
+        torch.cuda.synchronize(dev)
+        tp = [self.pans[j] for j in sorted(self.timed_idx)]
+        for p in tp:
+            p.profile(True)
+        if barrier:
+            barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        last = self.run(steps)
+        t_issue = time.perf_counter() - t0          # host time to enqueue every step (the GPU is still working)
+        torch.cuda.synchronize(dev)
+        if barrier:
+            barrier()
+        torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0
+        profs = [p.profile_read() for p in tp]
+        for p in tp:
+            p.profile(False)
+        nl = sum(q["launches"] for q in profs)
+        avg = lambda key: sum(q[key] * q["launches"] for q in profs) / max(nl, 1)
+        K = self.cfg.iter_num
+        for o, g in (x for x in last if x is not None):
+            assert (o["iters"].cpu().numpy() == K).all(), "every scene must run exactly K PAN iterations inside the timed region"
+            assert g.numel() == self.world * self.batch * 2 * self.cfg.T
+        return dict(elapsed=elapsed, t_issue=t_issue, last=last,
+                    prof={"launches": nl, "dune_ms": avg("dune_ms"), "select_ms": avg("select_ms"), "nrmp_ms": avg("nrmp_ms")})
+
+    def audit(self):
+        audits = [p.audit() for p in self.pans]
+        a = {k: sum(x[k] for x in audits) for k in ("tiles", "points", "violations")}
+        a["worst_excess"] = max(x["worst_excess"] for x in audits)
+        return a
+
+    def qp_iterations(self):
+        """Interior-point iterations the QP launches of ONE step of batch 0 execute, measured on the device (qp_info[14] of
+        every scene after every PAN iteration, untimed): list over k of (sum over scenes, max over scenes)."""
+        pan, a = self.pans[0], self.args[0]
+        pan.forward_begin(*a, reset_state=True)
+        out = []
+        for k in range(pan.iter_num):
+            pan.forward_iter(k)
+            it = pan.last_qp_info()[:, 14]
+            out.append((float(it.sum()), float(it.max())))
+        pan.forward_end()
+        return out
+
+    def close(self):
+        self.loop.close()
+        self.steps = self.pans = self.args = None
+        torch.cuda.empty_cache()
+
+
+def dune_mfma_rate(km, cfg, batch, dune_ms):
+    """Executed matrix work of the encoder per second against the peak of the MFMA it runs on (SURVEY 8(d)'s roofline, priced
+    on what is EXECUTED).  Network keys: dune_kernel encodes every point of every slice -- per 32-point tile four 32x32x32
+    layers (262 144 flop; 3x with split products) on fp16 MFMA, or on fp32 MFMA with NPA_DUNE_FP32KEYS."""
+    T, K, N = cfg.T, cfg.iter_num, cfg.n_points
+    if km["key_terms"] == 4 or dune_ms <= 0:
+        return None
+    slices = ((T + 1) + (K - 1) * T) / K                     # slices a launch encodes (slice 0 only in the first iteration)
+    tiles = batch * slices * ((N + 31) // 32)
+    per_tile = {0: 262144 + 4096, 1: 262144 + 4096, 3: 3 * 262144 + 4096}[km["key_terms"]]
+    peak = PEAK_FP32_MFMA_TFLOPS if km["key_terms"] == 0 else PEAK_F16_MFMA_TFLOPS
+    ex = tiles * per_tile / (dune_ms * 1e-3) / 1e12
+    return {"kernel": "dune_kernel", "launch_ms": round(dune_ms, 4), "tflops": round(ex, 2), "peak": peak,
+            "frac": round(ex / peak, 4), "points_encoded_per_launch": int(tiles * 32),
+            "mfma": "v_mfma_f32_32x32x2_f32" if km["key_terms"] == 0 else "v_mfma_f32_32x32x16_f16"}
+
+
+def short_run(workload, batch, nfl, dev, steps, warmup, env=None, issue_threads=4):
+    """One more timed loop (GPU only) on another workload / another path of the library."""
+    lp = Loop(workload, batch, nfl, dev, env=env, issue_threads=issue_threads)
+    r = lp.timed(steps, warmup)
+    km = lp.pans[0].key_mode()
+    out = {"plans_per_s": round(batch * steps / r["elapsed"], 1), "ms_per_step": round(1e3 * r["elapsed"] / steps, 4),
+           "steps": steps, "scenes_per_step": batch, "batches_in_flight": nfl, "key_terms": km["key_terms"],
+           "select_launch_ms": round(r["prof"]["select_ms"], 4), "qp_launch_ms": round(r["prof"]["nrmp_ms"], 4),
+           "dune_launch_ms": round(r["prof"]["dune_ms"], 4)}
+    mf = dune_mfma_rate(km, lp.cfg, batch, r["prof"]["dune_ms"])
+    if mf:
+        out["dune_executed_mfma"] = mf
+    out["margin_violations"] = lp.audit()["violations"]
+    return out, lp
+
+
+def parity_leg(lp, scenes, cores, n_ulp=8, n_perm=4, sweep=False):
+    """The ensemble verdicts A / C / D of tests/parity_tools.py for the first `scenes` scenes of the loop's batch 0 (CPU oracle;
+    rank 0 only, untimed).  Returns (report, cpu rate, workers, hip deviations, spreads, trace)."""
+    from parity_tools import judge, one_step_consistency, one_step_report, run_ensemble
+    base, members, cpu_rate, ncore = run_ensemble(lp.workload, range(scenes), cores, n_ulp=n_ulp, n_perm=n_perm, sweep=sweep)
+    pan = lp.pans[0]
+    pan.reset_stop_state()
+    tr = pan.forward_batch_trace(*lp.args[0])
+    trace_u = tr["trace_u"].cpu().numpy()
+    rep, hip, sp = judge(trace_u[:scenes], base, members)
+    tp = tr["trace_pts"].cpu().numpy()[:scenes] if tr.get("trace_pts") is not None else None
+    dev, why = one_step_consistency(lp.workload, range(scenes), tr["trace_s"].cpu().numpy()[:scenes], trace_u[:scenes], cores,
+                                    explain=True, trace_pts=tp)
+    rep["one_step"] = one_step_report(dev, why=why)
+    rep["well_posed_frac"] = round(float((sp[:, -1] <= 1e-4).mean()), 4)
+    return rep, cpu_rate, ncore, hip, sp, tr
+
+
+def slim(rep):
+    """The verdicts of a parity report without the per-scene listings (the other configurations' entries of the line)."""
+    keep = ("scenes", "ensemble_members", "ctrl_l2_vs_oracle_median", "max", "frac_le_1e-4", "scenes_well_posed",
+            "max_over_well_posed", "A_well_posed_all_le_tol", "C_le_1e-5_until_ensemble_diverges", "max_hip_before_divergence",
+            "well_posed_frac")
+    out = {k: rep[k] for k in keep if k in rep}
+    os_ = rep.get("one_step", {})
+    out["one_step"] = {k: os_[k] for k in ("steps_checked", "max", "p99", "median", "frac_le_tol", "above_tol", "unexplained") if k in os_}
+    return out
+
+
 def main():
-    global BATCH
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
@@ -75,6 +286,7 @@ def main():
     ap.add_argument("--cpu-cores", type=int, default=0, help="worker processes of the CPU baseline (0 = all host cores)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-scene latency measurement")
+    ap.add_argument("--no-extras", action="store_true", help="skip extra.paths / extra.uniform_cloud / extra.other_configs")
     ap.add_argument("--graph", action="store_true", help="HIP-graph replay of a step's 21 launches for the planners that carry no "
                                                         "timing events (measured: SLOWER than eager launches with 20 chains in "
                                                         "flight, 513 k vs 656 k plans/s, DESIGN.md section 3.4; default: eager)")
@@ -98,183 +310,111 @@ def main():
     if "RANK" in os.environ and "MASTER_PORT" in os.environ:      # under torch.distributed.run, also with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if os.environ.get("NPA_BENCH_LAZY_PG"):       # diagnostics: no eager communicator
-            dist.init_process_group("nccl", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    # the measured leg imports the product only; tests/ (and with it oracle/) is touched by the cpu_baseline leg alone
-    from neupan_amd.pan import PAN
-    from neupan_amd.serve import ControlGatherer, StepLoop, bind_to_gpu_numa_node, run_steps as serve_steps
-    numa = bind_to_gpu_numa_node(local_rank)            # launch thread next to its GPU (one process per GPU)
-    from neupan_amd.robot import Robot
+    # the measured leg imports the product only; tests/ (and with it oracle/) is touched by the cpu_baseline / parity leg alone
     from neupan_amd.scenes import CONFIGS, make_batch
+    from neupan_amd.serve import bind_to_gpu_numa_node
+    numa = bind_to_gpu_numa_node(local_rank)            # launch thread next to its GPU (one process per GPU)
 
-    def make_gpu_pan(cfg, device, **over):
-        ck = os.path.join(ROOT, "tests", "golden", "checkpoints", f"{cfg.checkpoint}_model_5000.pth")
-        if not os.path.exists(ck):              # the 8-edge stand-in: tests/golden/make_poly8_checkpoint.py
-            ck = os.path.join(ROOT, "tests", "golden", "checkpoints", f"{cfg.checkpoint}_model_quick.pth")
-        kw = dict(iter_num=cfg.iter_num, dune_max_num=cfg.n_points, nrmp_max_num=cfg.nrmp_max_num, iter_threshold=0.0,
-                  dune_checkpoint=ck, adjust_kwargs=dict(cfg.adjust), device=device)
-        kw.update(over)
-        return PAN(cfg.T, cfg.dt, Robot(cfg.T, cfg.dt, **cfg.robot), **kw)
-
-    if os.environ.get("NPA_BENCH_HIPRIO_STREAM"):          # diagnostics: does the mere existence of a high-priority stream cost?
-        _hp = torch.cuda.Stream(device=dev, priority=-1)
-        with torch.cuda.stream(_hp):
-            torch.zeros(16, device=dev).add_(1)
-        torch.cuda.synchronize(dev)
     if os.environ.get("NPA_BENCH_RCCL_COMM_ONLY"):        # diagnostics: a raw RCCL communicator (no torch process group)
         import ctypes as _C
         _r = _C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
         _comm = _C.c_void_p()
         _devs = (_C.c_int * 1)(local_rank)
         print("ncclCommInitAll rc", _r.ncclCommInitAll(_C.byref(_comm), 1, _devs), file=sys.stderr)
+        if os.environ.get("NPA_BENCH_RCCL_COMM_ONLY") == "destroy":
+            print("ncclCommDestroy rc", _r.ncclCommDestroy(_comm), file=sys.stderr)
     cfg = CONFIGS[args.workload]
-    BATCH = args.batch
+    B = args.batch
     T, K, N = cfg.T, cfg.iter_num, cfg.n_points
     nfl = max(1, args.inflight)
-    pans = [make_gpu_pan(cfg, device=dev) for _ in range(nfl)]
-    E = pans[0].E
-    streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
-    args_dev = []
-    for j in range(nfl):                    # batch j of this rank: its own 256 scenes
-        batch = make_batch(cfg, (rank * nfl + j) * BATCH, BATCH)
-        a = [torch.from_numpy(batch[k]).to(dev) for k in ("nom_s", "nom_u", "ref_s", "ref_us", "points")]
-        a.append(torch.from_numpy(batch["velocities"]).to(dev) if batch.get("velocities") is not None else None)
-        args_dev.append(a)
-    torch.cuda.synchronize(dev)
-    cur = torch.cuda.current_stream(dev)
-    # One prepared step per batch in flight (PAN.make_step: arguments validated once, ONE library call per step, output
-    # tensors reused -- a serving loop owns its buffers); fresh stop-criterion state every step, reset inside the staging
-    # launch.  The controls of every step are all-gathered over RCCL from ONE communication stream (neupan_amd/serve.py).
-    # Planners that carry timing events: every 4th (events ride on the dispatches).  --graph: the others replay a HIP graph
-    # of the same launches (measured slower, kept for the record).
-    timed_idx = set(range(0, nfl, 4)) if nfl >= 4 else set(range(nfl))
-    # (NPA_BENCH_NOGATHER=1, diagnostics only: process group up, no gathers -- isolates what the collectives themselves cost)
-    gatherer = ControlGatherer(None if os.environ.get("NPA_BENCH_NOGATHER") else dist, world, device=dev, slots=nfl, shape=(BATCH, 2, T))
-    steps = []
-    for j in range(nfl):
-        with torch.cuda.stream(streams[j]):
-            steps.append(pans[j].make_step(*args_dev[j], reset_every_step=True, graph=(args.graph and j not in timed_idx)))
-    torch.cuda.synchronize(dev)
-
-    loop = StepLoop(steps, streams, gatherer, cur, threads=args.issue_threads)
-
-    def run_steps(n):
-        """n steps (= n forward calls over batches of 256 scenes), `nfl` of them in flight, one stream each: step i is
-        planned by planner i % nfl; the launches are issued by --issue-threads host threads (0: this thread alone)."""
-        return loop.run(n)
-
-    run_steps(args.warmup)
-    torch.cuda.synchronize(dev)
-    # HIP events ride on the launches of every 4th batch in flight (all of them with < 4): recording two events per launch
-    # doubles the host's time to enqueue a step, and with 20 chains to start that ramp is what a short timed region
-    # (the driver's 20 steps) mostly measures.  launch_ms below is the average over the launches that carry events.
-    timed_pans = [pans[j] for j in sorted(timed_idx)]
-    for p in timed_pans:
-        p.profile(True)
-    if dist is not None and not os.environ.get("NPA_BENCH_LAZY_PG"):
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    last = run_steps(args.steps)
-    t_issue = time.perf_counter() - t0          # host time to enqueue every step (the GPU is still working)
-    torch.cuda.synchronize(dev)
-    if dist is not None and not os.environ.get("NPA_BENCH_LAZY_PG"):
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    profs = [p.profile_read() for p in timed_pans]
-    for p in timed_pans:
-        p.profile(False)
-    if dist is not None and not os.environ.get("NPA_BENCH_LAZY_PG"):
+    lp = Loop(args.workload, B, nfl, dev, rank=rank, world=world, dist=None if os.environ.get("NPA_BENCH_NOGATHER") else dist,
+              graph=args.graph, issue_threads=args.issue_threads)
+    E = lp.pans[0].E
+    barrier = dist.barrier if dist is not None else None
+    r = lp.timed(args.steps, args.warmup, barrier)
+    elapsed, t_issue, prof, last = r["elapsed"], r["t_issue"], r["prof"], r["last"]
+    if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    nl = sum(q["launches"] for q in profs)
-    avg = lambda key: sum(q[key] * q["launches"] for q in profs) / max(nl, 1)
-    prof = {"launches": nl, "dune_ms": avg("dune_ms"), "select_ms": avg("select_ms"), "nrmp_ms": avg("nrmp_ms")}
     out, gathered = last[0]
-    for o, g in (x for x in last if x is not None):
-        assert (o["iters"].cpu().numpy() == K).all(), "every scene must run exactly K PAN iterations inside the timed region"
-        assert g.numel() == world * BATCH * 2 * T
+    timed_u = out["opt_u"].cpu().numpy().copy()
 
-    plans = BATCH * world * args.steps
+    plans = B * world * args.steps
     value = plans / elapsed
-    km = pans[0].key_mode()
+    km = lp.pans[0].key_mode()
 
     # the run-time audit of the geometric-key margin over everything this process launched so far (all planners): a
     # violation would mean plans computed from a wrong selection -- the number is reported AND must be zero
-    audits = [p.audit() for p in pans]
-    audit = {k: sum(a[k] for a in audits) for k in ("tiles", "points", "violations")}
-    audit["worst_excess"] = max(a["worst_excess"] for a in audits)
+    audit = lp.audit()
     assert audit["violations"] == 0, f"geometric-key margin violated at run time: {audit}"
 
     # ---- roofline of the dominant kernel -------------------------------------------------------------------------
-    # With geometric keys the encoder runs on ~2 % of the points (the candidates), and the step is the QP: a serial
-    # fp64 interior-point chain, one wave per scene -- VALU/latency bound, no MFMA, no HBM stream.  EXECUTED work only:
-    # counters from profiles/r03_pmc.json (tests/tools/pmc_collect.py: separate rocprofv3 --pmc passes), used per kernel
-    # only while the sources that kernel is built from are unchanged (kernel_hash).  SURVEY 8(d)'s roofline -- algorithmic
-    # dense flops of the encoder over the fp32-MFMA peak -- is retired: 943 Mflop/plan x this rate would be 2-4x that peak,
-    # the encoder simply does not run on 98 % of the points any more (DESIGN.md section 6).
-    pmc = None
-    if os.path.exists(PMC_FILE):
-        try:
-            pj = json.load(open(PMC_FILE))
-            if pj.get("workload") == args.workload:
-                pmc = pj
-        except Exception:
-            pmc = None
-
-    def pmc_kernel(name):
-        k = pmc["kernels"].get(name) if pmc else None
-        return k if k and k.get("source_hash") == kernel_hash(name) else None
-    scenes_per_launch = BATCH
+    # The step is dominated by the QP: a serial fp64 interior-point chain, one wave per scene -- VALU / latency bound, no MFMA,
+    # no HBM stream.  Work per launch = interior-point iterations the launch executes (MEASURED HERE on the device: qp_info of
+    # every scene after every PAN iteration of one untimed step) x fp64 flops per iteration + a fixed part per solve (set-up,
+    # write-out, stop test); the two per-unit figures come from PMC counts (SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 x 64 lanes, FMA x2)
+    # at two operating points (warm / cold solves), tests/tools/pmc_collect.py -> profiles/r04_pmc.json, DESIGN.md section 6.
+    # Launch time: HIP events on the launches' own stream, inside the timed region.  SURVEY 8(d)'s figure -- algorithmic dense
+    # flops of the encoder over the fp32-MFMA peak -- is not the denominator of the default path: with geometric keys the
+    # encoder runs on ~2 % of the points (943 Mflop/plan x this rate would be 4x the peak); extra.paths reports it for the
+    # un-pruned selections, roofline.select for the default one.
+    pmc = load_pmc(args.workload)
+    its = lp.qp_iterations()
+    its_per_launch = float(np.mean([s for s, _ in its]))
     qp_ms, sel_ms, dune_ms = prof["nrmp_ms"], prof["select_ms"], prof["dune_ms"]
     roof = {"bound": "valu", "kernel": f"nrmp_qp_kernel<{T},{cfg.nrmp_max_num}>", "unit": "TFLOP/s", "peak": PEAK_FP64_VALU_TFLOPS,
-            "launch_ms": round(qp_ms, 4), "launches_timed": nl, "select_launch_ms": round(sel_ms, 4),
-            "dune_launch_ms": round(dune_ms, 4), "key_mode": km, "achieved": None, "frac": None, "traffic": None}
-    kq = pmc_kernel("nrmp_qp_kernel")
+            "launch_ms": round(qp_ms, 4), "launches_timed": prof["launches"], "select_launch_ms": round(sel_ms, 4),
+            "dune_launch_ms": round(dune_ms, 4), "key_mode": km, "achieved": None, "frac": None, "traffic": None,
+            "ipm_iterations_per_launch": round(its_per_launch, 1),
+            "ipm_iterations_by_pan_iteration": [[int(s), int(m)] for s, m in its]}
+    kq = pmc["kernels"].get("nrmp_qp_kernel") if pmc else None
     if kq:
-        flops = kq["fp64_flops_per_launch"] * scenes_per_launch / pmc["scenes_per_launch"]
+        model = pmc.get("qp_flops_model")
+        if model:
+            flops = model["per_iteration"] * its_per_launch + model["per_solve"] * B
+            roof["flops_model"] = dict(model, units="fp64 flop per interior-point iteration of one scene / per solve")
+        else:                                   # (a record without the two-point fit: its launch average, scaled to this batch)
+            flops = kq["fp64_flops_per_launch"] * B / pmc["scenes_per_launch"]
         roof["achieved"] = round(flops / (qp_ms * 1e-3) / 1e12, 4) if qp_ms > 0 else None
         roof["frac"] = round(roof["achieved"] / PEAK_FP64_VALU_TFLOPS, 5) if roof["achieved"] else None
         roof["flops_per_launch"] = int(flops)
-        roof["traffic"] = int(kq["hbm_bytes_per_launch"] * scenes_per_launch / pmc["scenes_per_launch"])
+        roof["traffic"] = int(kq["hbm_bytes_per_launch"] * B / pmc["scenes_per_launch"])
         roof["valu_issue_frac_alone"] = kq.get("valu_issue_frac")
         roof["frac_alone"] = round(flops / (kq["avg_ms_alone"] * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS, 5) if kq.get("avg_ms_alone") else None
         roof["lds_bank_conflict_frac"] = kq.get("lds_bank_conflict_frac")
-    if pmc:
-        roof["pmc"] = {"file": "profiles/r03_pmc.json",
+        # the chip's fp64 rate over the whole timed region: every QP launch of every chain / wall time
+        roof["chip_aggregate"] = {"tflops": round(flops * K * args.steps / elapsed / 1e12, 3),
+                                  "frac": round(flops * K * args.steps / elapsed / 1e12 / PEAK_FP64_VALU_TFLOPS, 5)}
+        roof["pmc"] = {"file": pmc["_file"],
                        "per_kernel": {k: dict({kk: v[kk] for kk in ("valu_insts_per_launch", "valu_issue_frac", "hbm_bytes_per_launch",
                                                                       "avg_ms_alone", "mfma_busy_frac", "source_hash") if kk in v},
                                                   current=(v.get("source_hash") == kernel_hash(k)))
                                       for k, v in pmc["kernels"].items()}}
-    ks = pmc_kernel("select_geo_kernel")
+    ks = pmc["kernels"].get("select_geo_kernel") if pmc else None
     if ks and sel_ms > 0 and "SQ_INSTS_MFMA" in ks.get("counters", {}):
         # the exact encoder's matrix work: executed v_mfma_f32_32x32x2_f32 (4096 flop each) over the fp32-MFMA peak
-        mf = ks["counters"]["SQ_INSTS_MFMA"] * 4096.0 * scenes_per_launch / pmc["scenes_per_launch"]
+        mf = ks["counters"]["SQ_INSTS_MFMA"] * 4096.0 * B / pmc["scenes_per_launch"]
         roof["select"] = {"kernel": f"select_geo_kernel<{E}>", "launch_ms": round(sel_ms, 4), "mfma_flops_per_launch": int(mf),
                           "mfma_tflops": round(mf / (sel_ms * 1e-3) / 1e12, 3), "mfma_peak": PEAK_FP32_MFMA_TFLOPS,
                           "mfma_frac": round(mf / (sel_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 5),
                           "valu_issue_frac_alone": ks.get("valu_issue_frac"), "mfma_busy_frac_alone": ks.get("mfma_busy_frac"),
-                          "traffic": int(ks["hbm_bytes_per_launch"] * scenes_per_launch / pmc["scenes_per_launch"]),
-                          "algorithmic_bytes_per_launch": int(scenes_per_launch * (8 * N * (2 if args_dev[0][5] is not None else 1) + 400))}
+                          "traffic": int(ks["hbm_bytes_per_launch"] * B / pmc["scenes_per_launch"]),
+                          "algorithmic_bytes_per_launch": int(B * (8 * N * (2 if lp.args[0][5] is not None else 1) + 400))}
     roof["note"] = ("dominant kernel by GPU time = the QP (fp64 Mehrotra IPM, one wave per scene, serial chain: latency / VALU-issue "
-                    "bound).  achieved = fp64 flops EXECUTED per launch (PMC: SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 x 64 lanes, FMA x2) / "
-                    "launch time measured here with HIP events on the launch's stream (other batches' kernels co-run on the same "
-                    "SIMDs; frac_alone: the same over the kernel's duration alone on the chip); nothing is priced above what it "
-                    "executes.  DUNE: " +
+                    "bound).  achieved = (interior-point iterations per launch, measured on the device in this run) x (fp64 flops per "
+                    "iteration) + solves x (fixed flops per solve), the two per-unit figures from PMC counts at two operating points "
+                    "(roofline.flops_model), / launch time measured here with HIP events on the launch's stream (other batches' kernels "
+                    "co-run on the same SIMDs; frac_alone: over the kernel's duration alone on the chip; chip_aggregate: all QP "
+                    "launches of the region over its wall time); nothing is priced above what it executes.  DUNE: " +
                     ("geometric distance keys inside select_geo_kernel nominate the candidates, the exact fp32-MFMA encoder runs on "
                      "those only (~1.1 tiles of 32 points per slice instead of N/32); no dune_kernel launch" if km["key_terms"] == 4
                      else f"network keys (mode {km['key_terms']}) from dune_kernel over every point, exact re-encode of the candidates"))
-    if km["key_terms"] != 4 and dune_ms > 0:
-        slices = (T + 1) + (K - 1) * T
-        nf16 = 8 if km["key_terms"] == 1 else 24
-        tiles_per_launch = scenes_per_launch * slices / K * ((N + 31) // 32)
-        ex = tiles_per_launch * (nf16 * 32768 + 4096) * 2 / 2 / (dune_ms * 1e-3) / 1e12
-        roof["dune_executed_mfma"] = {"tflops": round(ex, 2), "peak": PEAK_F16_MFMA_TFLOPS, "frac": round(ex / PEAK_F16_MFMA_TFLOPS, 4)}
+    mfd = dune_mfma_rate(km, cfg, B, dune_ms)
+    if mfd:
+        roof["dune_executed_mfma"] = mfd
 
     line = {
         "metric": "MPC plans/sec (node), diff robot, 1k pts, T=10, K=10; ctrl L2 vs ref" if args.workload == WORKLOAD
@@ -284,22 +424,28 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("BASELINE.json configs[1]: batch=256 synthetic scenes/GPU, diff robot, 1000 pts, "
                                 "T=10, K=10 (iter_threshold=0), M=10, fp32 DUNE (MFMA) + fp64 QP") if args.workload == WORKLOAD
-                               else f"{args.workload}: batch={BATCH} synthetic scenes/GPU, {cfg.kinematics} robot, {N} pts, "
+                               else f"{args.workload}: batch={B} synthetic scenes/GPU, {cfg.kinematics} robot, {N} pts, "
                                     f"T={T}, K={K} (iter_threshold=0), M={cfg.nrmp_max_num}, fp32 DUNE (MFMA) + fp64 QP"
-                                    + ("; BASELINE's 'bf16 DUNE' tier is NOT built: rows are exact fp32 (bf16 cannot hold 1e-4 "
-                                       "through a top-M selection, SURVEY section 7), keys geometric" if args.workload.startswith("poly8") else ""),
-                   "scenes_per_gpu": BATCH, "points": N, "T": T, "K": K, "M": cfg.nrmp_max_num,
+                                    + ("; rows exact fp32 (the labelled bf16 tier of BASELINE configs[4]: NPA_ROWS_PRECISION=bf16, "
+                                       "extra.other_configs of the default line)" if args.workload.startswith("poly8")
+                                       and os.environ.get("NPA_ROWS_PRECISION") != "bf16" else "")
+                                    + ("; rows from the LABELLED bf16 tier (not the reference's arithmetic)"
+                                       if os.environ.get("NPA_ROWS_PRECISION") == "bf16" else ""),
+                   "scenes_per_gpu": B, "points": N, "T": T, "K": K, "M": cfg.nrmp_max_num,
                    "batches_in_flight": nfl, "schedule": "one HIP stream per batch in flight, one prepared library call per step "
                                                         "(PAN.make_step), " + ("eager launches" if not args.graph else
                                                         "HIP-graph replay except on the planners that carry timing events") +
                                                         ", gathers on one communication stream",
-                   "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "numa_node": numa, "issue_threads": loop.threads,
+                   "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "numa_node": numa, "issue_threads": lp.loop.threads,
                    "parallelism": f"scene-shard x{world}, RCCL all-gather of controls"
-                                  + (f" (process group initialised; {gatherer.collectives} collectives for {gatherer.issued} steps: "
-                                     f"one per {nfl} steps, all inside the timed loop)" if dist is not None else "")},
+                                  + (f" (process group initialised; {lp.gatherer.collectives} collectives for {lp.gatherer.issued} "
+                                     f"steps: one all_gather_into_tensor per {nfl} steps, all inside the timed loop)"
+                                     if dist is not None else " (no process group in a single-process run: nothing to gather)"),
+                   "inputs": "resident in HBM and re-planned every step; the 8 N B of points per scene a host caller ships per "
+                             "step over PCIe are NOT in the timed region (DESIGN.md section 6)"},
         "roofline": roof,
-        # host time to enqueue a step (one library call = 21 launches, one Python thread) next to the step's wall time: when
-        # the two are close the step is bound by the host's launch rate, not by the kernels
+        # host time to enqueue a step (one library call = 21 launches) next to the step's wall time: when the two are close
+        # the step is bound by the host's launch rate, not by the kernels
         "host_issue_ms_per_step": round(1e3 * t_issue / args.steps, 4),
         "margin_audit": audit,
     }
@@ -307,12 +453,12 @@ def main():
     # ---- single-scene latency: the reference's actual use (neupan/neupan.py:104-166, one robot, README "15 Hz") -------
     if rank == 0 and not args.no_latency:
         lat = {}
-        for tag, over, npts in (("K10_N1000", {}, N), ("shipped_K2_N100", dict(iter_num=2, dune_max_num=100, iter_threshold=0.1), N)):
+        for tag, over in (("K10_N1000", {}), ("shipped_K2_N100", dict(iter_num=2, dune_max_num=100, iter_threshold=0.1))):
             p1 = make_gpu_pan(cfg, device=dev, **over)
             p1.printed = True                   # the reference prints a decimation notice once (pan.py:172): keep stdout to ONE line
-            a1 = [a[:1].contiguous() if a is not None else None for a in args_dev[0]]
+            a1 = [a[:1].contiguous() if a is not None else None for a in lp.args[0]]
             ts = []
-            for rep in range(60):
+            for rep_ in range(60):
                 p1.reset_stop_state()
                 torch.cuda.synchronize(dev)
                 t1 = time.perf_counter()
@@ -324,29 +470,22 @@ def main():
         line["latency_B1_ms"] = dict(lat, note="one scene per forward call, host call -> results synchronised, median of 50; "
                                                f"same workload ({N} points; the shipped config decimates to 100 and may stop early)")
 
-    if rank == 0 and world == 1 and not args.no_cpu:
+    extras = rank == 0 and world == 1 and not args.no_extras and args.workload == WORKLOAD
+    with_cpu = rank == 0 and world == 1 and not args.no_cpu
+    cores = args.cpu_cores if args.cpu_cores > 0 else (os.cpu_count() or 1)
+    if with_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from parity_tools import gpu_last_qp_certificates, judge, run_ensemble
+        from parity_tools import gpu_last_qp_certificates, host_cores, run_ensemble
         try:                                    # the CPU baseline gets the whole host, not the GPU's NUMA node
             os.sched_setaffinity(0, range(os.cpu_count() or 1))
         except Exception:
             pass
         host = os.cpu_count() or 1
-        n_sc = args.cpu_scenes if args.cpu_scenes > 0 else (BATCH if host >= 64 else min(96, BATCH))
-        n_sc = min(n_sc, BATCH)
-        ncore = args.cpu_cores if args.cpu_cores > 0 else host
-        base, members, cpu_rate, ncore = run_ensemble(args.workload, range(n_sc), ncore)
-        # controls after every PAN iteration of the same batch, untimed; its last iteration IS the timed result
-        timed_u = out["opt_u"].cpu().numpy().copy()
-        pans[0].reset_stop_state()
-        tr = pans[0].forward_batch_trace(*args_dev[0])
-        trace_u = tr["trace_u"].cpu().numpy()
-        assert np.array_equal(trace_u[:, -1], timed_u), "traced run differs from the timed run"
-        rep, hip, sp = judge(trace_u[:n_sc], base, members)
-        from parity_tools import host_cores, one_step_consistency, one_step_report
-        # D: one oracle iteration from the HIP path's own iterate vs the HIP path's next iterate, every scene, every iteration
-        rep["one_step"] = one_step_report(one_step_consistency(args.workload, range(n_sc), tr["trace_s"].cpu().numpy()[:n_sc],
-                                                               trace_u[:n_sc], args.cpu_cores if args.cpu_cores > 0 else host))
+        n_sc = args.cpu_scenes if args.cpu_scenes > 0 else (B if host >= 64 else min(96, B))
+        n_sc = min(n_sc, B)
+        rep, cpu_rate, ncore, hip, sp, tr = parity_leg(lp, n_sc, cores, sweep=True)
+        # (controls after every PAN iteration of the same batch, untimed; its last iteration IS the timed result)
+        assert np.array_equal(tr["trace_u"].cpu().numpy()[:, -1], timed_u), "traced run differs from the timed run"
         phys, logical = host_cores()
         quota = None
         try:                                    # cgroup v2 CPU quota of this container ("max" = none): the ceiling of any CPU baseline here
@@ -372,41 +511,91 @@ def main():
         # share of scenes on which 13 equally valid evaluations of the reference algorithm agree to 1e-4 at all; and the
         # headline pair once more on those scenes only
         well = sp[:, -1] <= 1e-4
-        rep["well_posed_frac"] = round(float(well.mean()), 4)
-        if well.any() and n_sc == BATCH:
-            idx = np.flatnonzero(well)
-            idx = torch.from_numpy(np.resize(idx, BATCH)).to(dev)
-            a_w = [a.index_select(0, idx).contiguous() if a is not None else None for a in args_dev[0]]
-            st_w = []
-            for j in range(nfl):
-                with torch.cuda.stream(streams[j]):
-                    st_w.append(pans[j].make_step(*a_w, reset_every_step=True))
-            torch.cuda.synchronize(dev)
-            nw = args.steps
-            serve_steps(args.warmup, st_w, streams, None, cur)
-            torch.cuda.synchronize(dev)
-            tw = time.perf_counter()
-            serve_steps(nw, st_w, streams, None, cur)
-            torch.cuda.synchronize(dev)
-            tw = time.perf_counter() - tw
-            rep["well_posed_only"] = {"scenes": int(well.sum()), "plans_per_s": round(BATCH * nw / tw, 1), "steps": nw,
+        if well.any() and n_sc == B:
+            idx = torch.from_numpy(np.resize(np.flatnonzero(well), B)).to(dev)
+            lw = Loop(args.workload, B, nfl, dev, issue_threads=args.issue_threads, scene_index=idx)
+            rw = lw.timed(args.steps, args.warmup)
+            rep["well_posed_only"] = {"scenes": int(well.sum()), "plans_per_s": round(B * args.steps / rw["elapsed"], 1), "steps": args.steps,
                                       "ctrl_l2_max": float(hip[well, -1].max()), "ctrl_l2_median": float(np.median(hip[well, -1])),
                                       "note": "the same loop on a batch made of the well-posed scenes only (cycled to 256)"}
+            lw.close()
         rep["note"] = ("oracle = reference code restated + substituted fp64 QP solver (ECOS unavailable: parity unpinned at that "
                        "boundary).  Ensemble per scene = the oracle itself on inputs moved by +-1 float32 ulp (8 members) and with the "
                        "DUNE hidden units permuted (same function, other fp32 summation order; 4 members).  well posed = ensemble "
                        "spread of the final controls <= 1e-4.  A: HIP <= 1e-4 on every well-posed scene; B: HIP inside the ensemble "
                        "spread elsewhere (reported; a 14th sample of a chaotic scene need not fall inside the hull of 13); C: HIP <= 1e-5 at "
                        "every iteration before the ensemble itself first disagrees by > 1e-5; D (one_step): on every scene and "
-                       "iteration ONE oracle iteration from the HIP path's own iterate reproduces the HIP path's next iterate "
+                       "iteration ONE oracle iteration from the HIP path's own iterate reproduces the HIP path's next iterate; a step "
+                       "above 1e-4 must be EXPLAINED (a tie at rank M / M+1 of a slice that the two fp32 encoders order differently, "
+                       "or a QP flat enough that two 1e-14 solves agree in objective to 1e-12 and not in the controls) "
                        "(tests/parity_tools.py, DESIGN.md section 5)")
         # the kernel's own last QP, per scene: rebuilt on the host from the parameters the kernel built, fp64 solution certified
-        batch0 = make_batch(cfg, rank * nfl * BATCH, BATCH)
-        rep["gpu_last_qp"] = dict(gpu_last_qp_certificates(pans[0], cfg, batch0),
+        batch0 = make_batch(cfg, rank * nfl * B, B)
+        rep["gpu_last_qp"] = dict(gpu_last_qp_certificates(lp.pans[0], cfg, batch0),
                                   note="KKT certificate (NNLS stationarity, complementarity, feasibility) of the kernel's fp64 "
                                        "solution of its last QP and objective gap to the oracle's solve of the same problem, "
                                        "all scenes of the batch; stat_oracle = the same certificate on the oracle's solutions")
         line["parity"] = rep
+    lp.close()
+
+    # ---- the other paths and configurations, in the same line (GPU legs are short loops; parity legs: 16 scenes each) -----
+    if extras:
+        t_ex = time.perf_counter()
+        ex = {}
+        paths = {}
+        for tag, env in (("exact_fp32_keys", {"NPA_DUNE_FP32KEYS": "1"}), ("network_keys_1", {"NPA_KEY_TERMS": "1"}),
+                         ("network_keys_3", {"NPA_KEY_TERMS": "3"})):
+            res, l2 = short_run(WORKLOAD, B, nfl, dev, 40, 8, env=env, issue_threads=args.issue_threads)
+            # the same plans as the default path (the keys only nominate): bitwise, checked on batch 0
+            l2.pans[0].reset_stop_state()
+            res["controls_equal_default_path"] = bool(np.array_equal(l2.pans[0].forward_batch(*l2.args[0])["opt_u"].cpu().numpy(), timed_u))
+            res["env"] = env
+            paths[tag] = res
+            l2.close()
+        ex["paths"] = dict(paths, note="the default loop (256 scenes / step, 20 in flight, 40 steps) with the selection's other key "
+                                       "paths: dune_kernel encodes EVERY point of every slice (SURVEY 8(d)'s literal path), "
+                                       "dune_executed_mfma prices that work against the peak of the MFMA it runs on")
+        # SURVEY 8(d)'s uniform cloud
+        res, l2 = short_run("uniform_1k_T10_K10", B, nfl, dev, 40, 8, issue_threads=args.issue_threads)
+
+        def cand(workload, a_):
+            with environ({"NPA_SEL_DEBUG": "1"}):
+                dbg = make_gpu_pan(CONFIGS[workload], device=dev)
+                c_ = dbg.dune_stage(a_[0], a_[4], a_[5])["count"].cpu().numpy()
+                del dbg
+            nc, fb = (c_ >> 8) & 0xFF, c_ >> 16
+            return {"median": int(np.median(nc)), "mean": round(float(nc.mean()), 1), "p90": int(np.quantile(nc, 0.9)), "max": int(nc.max()),
+                    "share_gt_32": round(float((nc > 32).mean()), 4), "share_overflow_to_exact_keys": round(float((fb > 0).mean()), 4),
+                    "histogram_0_16_32_64_128_256": np.histogram(nc, bins=[0, 16, 32, 64, 128, 256])[0].tolist()}
+        res["candidates_per_slice"] = cand("uniform_1k_T10_K10", l2.args[0])
+        b0 = make_batch(cfg, 0, B)
+        res["candidates_per_slice_corridor_workload"] = cand(WORKLOAD, [b0["nom_s"], None, None, None, b0["points"], None])
+        if with_cpu:
+            res["parity"] = slim(parity_leg(l2, 8, cores, n_ulp=4, n_perm=2)[0])
+        res["note"] = ("SURVEY 8(d) config 2's cloud exactly as specified (uniform x in [-2, 12], y in [-6, 6], rejection box): 6 points "
+                       "per m^2 around a 1.6 x 2.0 m robot -- most scenes have no collision-free plan (d at d_min), the PAN iteration is "
+                       "ill posed on them; candidates per slice = points the geometric keys could not rule out (255 = capped)")
+        ex["uniform_cloud"] = res
+        l2.close()
+        others = {}
+        for tag, wl, b_, nf, env in (("acker_2k_T20_K15", "acker_2k_T20_K15", B, nfl, None),
+                                     ("dyna_4k_T10_K10_batch1024", "dyna_4k_T10_K10", 1024, 4, None),
+                                     ("poly8_5k_T10_K10_exact_fp32_rows", "poly8_5k_T10_K10", B, nfl, None),
+                                     ("poly8_5k_T10_K10_bf16_rows", "poly8_5k_T10_K10", B, nfl, {"NPA_ROWS_PRECISION": "bf16"})):
+            res, l2 = short_run(wl, b_, nf, dev, 32, 8, env=env, issue_threads=args.issue_threads)
+            if env:
+                res["env"] = env
+            if with_cpu:
+                res["parity"] = slim(parity_leg(l2, 16, cores, n_ulp=4, n_perm=2)[0])
+            others[tag] = res
+            l2.close()
+        ex["other_configs"] = dict(others, note="BASELINE configs[2] (car, reverse gear on half the scenes), configs[3]'s per-GPU shape "
+                                                "(8192 scenes / 8 GPUs = 1024 per step, 4 steps in flight), configs[4] (8-edge hull; the "
+                                                "reference ships no E = 8 checkpoint: ours, trained with its recipe on closed-form labels) in "
+                                                "exact fp32 and in the LABELLED bf16 tier of the rows (v_mfma_f32_32x32x16_bf16; its parity "
+                                                "entry shows what that costs); parity = ensemble verdicts on the first 16 scenes (6 members)")
+        ex["seconds"] = round(time.perf_counter() - t_ex, 1)
+        line["extra"] = ex
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

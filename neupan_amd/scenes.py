@@ -39,6 +39,7 @@ class SceneConfig:
     obs_gap: tuple = (1.25, 2.6)     # lateral distance of an obstacle's surface from the lane
     obs_radius: tuple = (0.4, 1.0)
     obs_count: tuple = (3, 7)
+    cloud: str = "corridor"          # "corridor": walls + round obstacles (below); "uniform": SURVEY.md 8(d)'s uniform cloud
 
 
 # robot + adjust values: reference example/corridor/diff/planner.yaml,
@@ -47,6 +48,16 @@ CONFIGS = {
     # BASELINE.json configs[1]: the configuration the metric is quoted on
     "diff_1k_T10_K10": SceneConfig(
         name="diff_1k_T10_K10",
+        robot=dict(kinematics="diff", length=1.6, width=2.0, max_speed=[8, 1], max_acce=[8, 3]),
+        adjust=dict(q_s=1.0, p_u=1.0, eta=15.0, d_max=1.0, d_min=0.1, bk=0.1, ro_obs=400),
+    ),
+    # the same configuration on the cloud SURVEY.md section 8(d) literally proposes for config 2: N points uniform over
+    # x in [-2, 12], y in [-6, 6], rejecting |x| < 1.3 and |y| < 1.5 around the start pose.  6 points per square metre with
+    # a 1.6 x 2.0 m robot driving through them: no collision-free plan exists on most scenes (d sits at d_min, in-collision
+    # points tie at distance 0), the PAN iteration is ill posed on most of them -- reported next to the corridor workload as
+    # the worst case of the selection (candidates per slice) and of the parity verdicts, not as the headline
+    "uniform_1k_T10_K10": SceneConfig(
+        name="uniform_1k_T10_K10", cloud="uniform",
         robot=dict(kinematics="diff", length=1.6, width=2.0, max_speed=[8, 1], max_acce=[8, 3]),
         adjust=dict(q_s=1.0, p_u=1.0, eta=15.0, d_max=1.0, d_min=0.1, bk=0.1, ro_obs=400),
     ),
@@ -135,6 +146,18 @@ def _obstacle_cloud(rng, cfg, N, gear):
     return pts[:, perm], (None if vel is None else vel[:, perm])
 
 
+def _uniform_cloud(rng, cfg, N):
+    """x ~ U(-2, 12), y ~ U(-6, 6), rejecting |x| < 1.3 and |y| < 1.5 (a feasible start)."""
+    xs, ys = np.zeros(0), np.zeros(0)
+    while xs.size < N:
+        x = rng.uniform(-2.0, 12.0, N); y = rng.uniform(-6.0, 6.0, N)
+        keep = ~((np.abs(x) < 1.3) & (np.abs(y) < 1.5))
+        xs, ys = np.concatenate([xs, x[keep]]), np.concatenate([ys, y[keep]])
+    pts = np.vstack([xs[:N], ys[:N]])
+    vel = rng.uniform(-1.0, 1.0, (2, N)) if cfg.moving else None
+    return pts, vel
+
+
 def make_scene(cfg: SceneConfig, b: int, n_points: int | None = None):
     """Scene number `b` of configuration `cfg`, fp32 arrays."""
     rng = np.random.default_rng(SEED0 + b)
@@ -153,7 +176,7 @@ def make_scene(cfg: SceneConfig, b: int, n_points: int | None = None):
     ref_s[0, :] = step * np.arange(T + 1)
     ref_us = np.full((T,), gear * cfg.ref_speed)
 
-    pts, vel = _obstacle_cloud(rng, cfg, N, gear)
+    pts, vel = _uniform_cloud(rng, cfg, N) if cfg.cloud == "uniform" else _obstacle_cloud(rng, cfg, N, gear)
     f = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
     return dict(nom_s=f(nom_s), nom_u=f(nom_u), ref_s=f(ref_s), ref_us=f(ref_us), points=f(pts),
                 velocities=f(vel))

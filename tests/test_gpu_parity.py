@@ -149,8 +149,9 @@ def test_pan_forward_vs_reference_vectors(case, cfgname, over):
             assert pan.min_distance == float("inf")
 
 
-def _ensemble_verdict(cfgname, scenes):
-    """HIP per-iteration controls of `scenes` scenes against the oracle and its ensemble (tests/parity_tools.py)."""
+def _ensemble_verdict(cfgname, scenes, step_tol=None):
+    """HIP per-iteration controls of `scenes` scenes against the oracle and its ensemble (tests/parity_tools.py).  step_tol:
+    the threshold above which a single step's deviation has to be EXPLAINED (default: the north-star 1e-4)."""
     import os
     from gpu_helpers import make_gpu_pan
     from parity_tools import judge, run_ensemble
@@ -160,21 +161,33 @@ def _ensemble_verdict(cfgname, scenes):
     out = pan.forward_batch_trace(batch["nom_s"], batch["nom_u"], batch["ref_s"], batch["ref_us"], batch["points"],
                                   batch["velocities"])
     assert (out["iters"].cpu().numpy() == cfg.iter_num).all()
+    # every QP of every iteration converged: status 0 (include/neupan_amd.h: 2 non-finite, 3 lost definiteness short of
+    # convergence, 4 both cold attempts ended above 1e-9), final merit at the solver's own floor
+    qi = out["trace_qp_info"].cpu().numpy()
+    assert (qi[:, :, 3] == 0).all() and qi[:, :, 1].max() <= 1e-9, (np.argwhere(qi[:, :, 3] != 0)[:5], qi[:, :, 1].max())
     base, members, _, _ = run_ensemble(cfgname, range(scenes), os.cpu_count() or 1, sweep=False)
     rep, hip, sp = judge(out["trace_u"].cpu().numpy(), base, members)
     from parity_tools import one_step_consistency, one_step_report
-    rep["one_step"] = one_step_report(one_step_consistency(cfgname, range(scenes), out["trace_s"].cpu().numpy(),
-                                                           out["trace_u"].cpu().numpy(), os.cpu_count() or 1))
-    print({k: v for k, v in rep.items() if k != "worst_scenes"})
+    dev, why = one_step_consistency(cfgname, range(scenes), out["trace_s"].cpu().numpy(), out["trace_u"].cpu().numpy(),
+                                    os.cpu_count() or 1, explain=True, trace_pts=out["trace_pts"].cpu().numpy(), tol=step_tol)
+    rep["one_step"] = one_step_report(dev, tol=1e-4 if step_tol is None else step_tol, why=why)
+    rep["_hip"], rep["_spread"] = hip, sp
+    print({k: v for k, v in rep.items() if k not in ("worst_scenes", "_hip", "_spread")})
     return rep
 
 
-def _assert_follows_the_reference_step_by_step(rep, tol_frac=0.995):
+def _assert_follows_the_reference_step_by_step(rep, tol_frac=0.98, cap=None):
     """Verdict D (tests/parity_tools.one_step_consistency): one oracle iteration from the HIP path's own iterate lands on
-    the HIP path's next iterate -- on every scene, chaotic or not.  Allowed to miss on a handful of steps (a tie at rank
-    M / M+1 of a slice between the two fp32 encoders changes the QP discretely)."""
+    the HIP path's next iterate -- on every scene, chaotic or not.  A step above the tolerance must be EXPLAINED, instance
+    by instance (parity_tools._explain_step): a tie at rank M / M+1 of a slice that the two fp32 encoders order differently
+    (the QP changes discretely; the oracle's own distances put the swapped point within 1e-4 m of its
+    cut), or a step on which the oracle's own one-step answer moves by a comparable amount when its inputs move by one
+    float32 ulp.  No unexplained step, at most 2 % explained ones, and (cap) none larger than the cap."""
     d = rep["one_step"]
     assert d["median"] <= 2e-6 and d["frac_le_tol"] >= tol_frac, d
+    assert d["unexplained"] == 0, [w for w in d["above_tol"] if w["explained"] is None]
+    if cap is not None:
+        assert d["max"] <= cap, d["worst"]
 
 
 def test_config2_parity_distribution():
@@ -189,7 +202,7 @@ def test_config2_parity_distribution():
     rep = _ensemble_verdict("diff_1k_T10_K10", 48)
     assert rep["A_well_posed_all_le_tol"] and rep["C_le_1e-5_until_ensemble_diverges"], rep
     assert rep["ctrl_l2_vs_oracle_median"] <= 1e-5 and rep["scenes_well_posed"] >= 40, rep
-    _assert_follows_the_reference_step_by_step(rep)
+    _assert_follows_the_reference_step_by_step(rep, 0.995)
 
 
 @pytest.mark.parametrize("cfgname,scenes", [("acker_2k_T20_K15", 24), ("dyna_4k_T10_K10", 24), ("poly8_5k_T10_K10", 16)])
@@ -198,10 +211,15 @@ def test_other_baseline_configs_parity_distribution(cfgname, scenes):
     stand-in (8-vertex hull, 5000 pts) at full size: the same three verdicts.  Acker: the first QP of some scenes has
     steering directions so flat that two fp64 solvers stop 1e-5 .. 7e-5 apart at their own noise floor (merit ~1e-12;
     DESIGN.md section 5) -- there C is held to the north-star 1e-4 instead of 1e-5."""
-    rep = _ensemble_verdict(cfgname, scenes)
+    acker = cfgname.startswith("acker")
+    # (the car: every single step above 1e-5 -- not 1e-4 -- has to be explained, which is what replaces the former blanket
+    # relaxation of verdict C to 1e-4 on this workload)
+    rep = _ensemble_verdict(cfgname, scenes, step_tol=1e-5 if acker else None)
     assert rep["A_well_posed_all_le_tol"], rep
-    _assert_follows_the_reference_step_by_step(rep, 0.98 if cfgname.startswith("acker") else 0.995)
-    if cfgname.startswith("acker"):
+    _assert_follows_the_reference_step_by_step(rep, 0.9 if acker else 0.995)
+    if acker:
+        # C on the car: a scene may exceed 1e-5 before its ensemble diverges only through steps that are explained above
+        # (flat first QPs: the oracle's own one-step spread under +-1 ulp is as large), and never beyond the north-star 1e-4
         assert rep["max_hip_before_divergence"] <= 1e-4, rep
     else:
         assert rep["C_le_1e-5_until_ensemble_diverges"], rep

@@ -265,3 +265,43 @@ def test_condensed_solver_repeats_a_jammed_cold_solve():
     assert info1["warm_code"] == 0 and info1["merit"] > 1e-9, info1
     s0, u0, d0 = solve_nrmp_qp(pb)
     np.testing.assert_allclose(u, u0, atol=5e-5)          # (acker QPs are flat in the steering direction: DESIGN.md section 5)
+
+
+def test_one_step_explanations_flag_what_they_cannot_explain():
+    """tests/parity_tools.one_step_consistency(explain=True), the machinery behind verdict D: fed with the ORACLE's own trace it
+    finds nothing above the tolerance; fed with controls that are off by 1e-3 for no reason it reports every such step as
+    UNEXPLAINED (no rank-M tie: the selection is the oracle's own; no sensitivity: the one-step ensemble under +-1 ulp does
+    not move by a third of 1e-3 on these well-posed scenes)."""
+    import dataclasses
+    from helpers import CONFIGS, make_oracle
+    from neupan_amd import scenes as sc_mod
+    from parity_tools import one_step_consistency, one_step_report
+    name = "corridor_diff_small_k3"
+    cfg = dataclasses.replace(CONFIGS["corridor_diff_small"], name=name, iter_num=3, n_points=120)
+    sc_mod.CONFIGS[name] = cfg
+    try:
+        S = 2
+        tr_s, tr_u, tr_p = [], [], []
+        for b in range(S):
+            sc = sc_mod.make_scene(cfg, b)
+            orc = make_oracle(cfg)
+            ps = []
+            orig = orc.nrmp
+
+            def hook(*a, _ps=ps, _orig=orig):
+                _ps.append(np.stack([p[:, :cfg.nrmp_max_num].T for p in a[6]]))         # the first M sorted points of every slice
+                return _orig(*a)
+            orc.nrmp = hook
+            orc.forward(sc["nom_s"], sc["nom_u"], sc["ref_s"], sc["ref_us"], sc["points"], sc["velocities"])
+            tr_s.append(np.stack([t[0] for t in orc.trace])); tr_u.append(np.stack([t[1] for t in orc.trace])); tr_p.append(np.stack(ps))
+        tr_s, tr_u, tr_p = np.stack(tr_s), np.stack(tr_u), np.stack(tr_p)
+        dev, why = one_step_consistency(name, range(S), tr_s, tr_u, 1, explain=True, trace_pts=tr_p)
+        assert dev.max() <= 1e-6 and why == []
+        bad = tr_u.copy()
+        bad[1, 2] += np.float32(1e-3 / np.sqrt(bad[1, 2].size))          # one step, control L2 = 1e-3
+        dev, why = one_step_consistency(name, range(S), tr_s, bad, 1, explain=True, trace_pts=tr_p)
+        rep = one_step_report(dev, why=why)
+        assert len(why) == 1 and why[0]["scene"] == 1 and why[0]["iteration"] == 3 and why[0]["explained"] is None
+        assert why[0]["slices_with_other_set"] == 0 and rep["unexplained"] == 1
+    finally:
+        del sc_mod.CONFIGS[name]

@@ -1,5 +1,5 @@
-"""PMC evidence for bench.py's roofline object, per kernel, tracked: writes gpurun_out/r03/pmc_<workload>.json (copy it to
-profiles/r03_pmc.json).
+"""PMC evidence for bench.py's roofline object, per kernel, tracked: writes gpurun_out/r04/pmc_<workload>.json (copy it to
+profiles/r04_pmc.json).
 
     python tests/tools/pmc_collect.py [workload]            # on the GPU box
 
@@ -38,12 +38,26 @@ def short(name):
     return None
 
 
-def run_pass(counters, workload):
+BENCH_ARGS = ["--steps", "4", "--warmup", "1", "--no-cpu", "--no-latency", "--no-extras", "--inflight", "1"]
+# (no create-time self-test in the profiled process: its 2-scene launches of the same kernels would be averaged in with the
+# 256-scene ones -- round 3's record has them: 9 of 79 QP launches, the per-launch averages of that file are ~10 % low)
+BASE_ENV = {"TMPDIR": "/tmp", "NPA_SKIP_SELFTEST": "1"}
+
+
+def bench_iterations(workload, extra_env=None):
+    """Interior-point iterations per QP launch of the SAME command (bench.py measures them on the device: roofline.ipm_iterations_per_launch)."""
+    env = dict(os.environ, **BASE_ENV, **(extra_env or {}))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *BENCH_ARGS, "--workload", workload], cwd="/tmp", env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    line = json.loads(r.stdout.strip().split("\n")[-1])
+    return float(line["roofline"]["ipm_iterations_per_launch"])
+
+
+def run_pass(counters, workload, extra_env=None):
     d = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
+    env = dict(os.environ, **BASE_ENV, **(extra_env or {}))
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "-o", "p", "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu", "--no-latency",
-           "--inflight", "1", "--workload", workload]
+           sys.executable, os.path.join(ROOT, "bench.py"), *BENCH_ARGS, "--workload", workload]
     r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     agg, n = collections.defaultdict(lambda: collections.defaultdict(float)), collections.Counter()
     dur, nd = collections.defaultdict(float), collections.Counter()
@@ -101,7 +115,7 @@ def main():
         for k in vals:
             kern[k].update(vals[k]); durs[k].append(dur.get(k, 0.0))
     res = {"source_hash": source_hash(), "workload": workload, "scenes_per_launch": BATCH,
-           "command": "rocprofv3 --kernel-trace --pmc <group> -- python bench.py --steps 4 --warmup 1 --no-cpu --no-latency --inflight 1",
+           "command": "rocprofv3 --kernel-trace --pmc <group> -- python bench.py " + " ".join(BENCH_ARGS),
            "passes": log, "kernels": {}}
     for k, c in kern.items():
         ms = sum(durs[k]) / max(len(durs[k]), 1)
@@ -124,8 +138,25 @@ def main():
         f, w = c.get("FETCH_SIZE", 0.0) * 1024, c.get("WRITE_SIZE", 0.0) * 1024
         e["fetch_bytes_raw"], e["write_bytes"], e["hbm_bytes_per_launch"] = f, w, f + w
         res["kernels"][k] = e
-    os.makedirs(os.path.join(ROOT, "gpurun_out", "r03"), exist_ok=True)
-    json.dump(res, open(os.path.join(ROOT, "gpurun_out", "r03", f"pmc_{workload}.json"), "w"), indent=1)
+    # ---- fp64 flops of the QP kernel per unit of work: a second operating point (NPA_QP_COLD=1: every solve cold, about twice
+    # the interior-point iterations) and the iterations per launch of both, measured on the device by the same command:
+    #     flops per launch = per_iteration x iterations per launch + per_solve x scenes per launch
+    try:
+        flop = lambda c: 64.0 * (c.get("SQ_INSTS_VALU_ADD_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0) + 2 * c.get("SQ_INSTS_VALU_FMA_F64", 0))
+        vals_c, _, _, (rc_c, _) = run_pass(GROUPS[0], workload, {"NPA_QP_COLD": "1"})
+        it_w, it_c = bench_iterations(workload), bench_iterations(workload, {"NPA_QP_COLD": "1"})
+        f_w, f_c = flop(kern["nrmp_qp_kernel"]), flop(vals_c["nrmp_qp_kernel"])
+        a = (f_c - f_w) / (it_c - it_w)
+        b = (f_w - a * it_w) / BATCH
+        res["qp_flops_model"] = {"per_iteration": a, "per_solve": b, "fit": {"warm": {"ipm_iterations_per_launch": it_w, "fp64_flops_per_launch": f_w},
+                                                                                  "cold": {"ipm_iterations_per_launch": it_c, "fp64_flops_per_launch": f_c}},
+                                 "note": "fp64 flops (64 lanes x (ADD + MUL + 2 FMA) wave-instructions, PMC) of one nrmp_qp_kernel launch at two "
+                                         "operating points (warm start on / NPA_QP_COLD=1), iterations per launch measured on the device by the "
+                                         "same command; per_iteration = slope, per_solve = intercept / scenes"}
+    except Exception as e:          # (the record stays usable without the fit: bench.py then scales the launch average)
+        res["qp_flops_model_error"] = repr(e)
+    os.makedirs(os.path.join(ROOT, "gpurun_out", "r04"), exist_ok=True)
+    json.dump(res, open(os.path.join(ROOT, "gpurun_out", "r04", f"pmc_{workload}.json"), "w"), indent=1)
     print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "counters"} for k, v in res["kernels"].items()}, indent=1))
 
 
