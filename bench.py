@@ -545,18 +545,18 @@ def main():
         paths = {}
         for tag, env in (("exact_fp32_keys", {"NPA_DUNE_FP32KEYS": "1"}), ("network_keys_1", {"NPA_KEY_TERMS": "1"}),
                          ("network_keys_3", {"NPA_KEY_TERMS": "3"})):
-            res, l2 = short_run(WORKLOAD, B, nfl, dev, 40, 8, env=env, issue_threads=args.issue_threads)
+            res, l2 = short_run(WORKLOAD, B, nfl, dev, 60, 20, env=env, issue_threads=args.issue_threads)
             # the same plans as the default path (the keys only nominate): bitwise, checked on batch 0
             l2.pans[0].reset_stop_state()
             res["controls_equal_default_path"] = bool(np.array_equal(l2.pans[0].forward_batch(*l2.args[0])["opt_u"].cpu().numpy(), timed_u))
             res["env"] = env
             paths[tag] = res
             l2.close()
-        ex["paths"] = dict(paths, note="the default loop (256 scenes / step, 20 in flight, 40 steps) with the selection's other key "
+        ex["paths"] = dict(paths, note="the default loop (256 scenes / step, 20 in flight, 60 steps) with the selection's other key "
                                        "paths: dune_kernel encodes EVERY point of every slice (SURVEY 8(d)'s literal path), "
                                        "dune_executed_mfma prices that work against the peak of the MFMA it runs on")
         # SURVEY 8(d)'s uniform cloud
-        res, l2 = short_run("uniform_1k_T10_K10", B, nfl, dev, 40, 8, issue_threads=args.issue_threads)
+        res, l2 = short_run("uniform_1k_T10_K10", B, nfl, dev, 60, 20, issue_threads=args.issue_threads)
 
         def cand(workload, a_):
             with environ({"NPA_SEL_DEBUG": "1"}):
@@ -582,7 +582,8 @@ def main():
                                      ("dyna_4k_T10_K10_batch1024", "dyna_4k_T10_K10", 1024, 4, None),
                                      ("poly8_5k_T10_K10_exact_fp32_rows", "poly8_5k_T10_K10", B, nfl, None),
                                      ("poly8_5k_T10_K10_bf16_rows", "poly8_5k_T10_K10", B, nfl, {"NPA_ROWS_PRECISION": "bf16"})):
-            res, l2 = short_run(wl, b_, nf, dev, 32, 8, env=env, issue_threads=args.issue_threads)
+            # (K = 15 / T = 20 and 5000-point chains are 20 - 30 ms long: enough steps for several rounds of the chains in flight)
+            res, l2 = short_run(wl, b_, nf, dev, 24 if b_ > B else 100, 8 if b_ > B else 20, env=env, issue_threads=args.issue_threads)
             if env:
                 res["env"] = env
             if with_cpu:

@@ -75,10 +75,10 @@ def condense(pb: NrmpProblem):
 
 
 WARM_DELTA = 0.003      # QP_WARM_DELTA in nrmp_qp.hip
-# a warm attempt is dropped (the solve restarts cold) when its merit exceeds these at iteration 0 / 6, and repeated
+# a warm attempt is dropped (the solve restarts cold) when its merit exceeds these at iteration 0 / 3 / 6, and repeated
 # cold when it ends above WARM_ACCEPT -- the kernel's rules (nrmp_qp.hip, "a warm start that is not paying off").  The
-# gate on the PREVIOUS solve (converged, controls moved < QP_WARM_STEP) is the caller's: pass warm=None when it fails.
-WARM_DROP = {0: 0.05, 6: 1e-4}
+# gate on the PREVIOUS solve (it converged to 1e-12) is the caller's: pass warm=None when it fails.
+WARM_DROP = {0: 0.05, 3: 3e-3, 6: 1e-4}
 WARM_ACCEPT = 1e-10
 # the kernel's interior-point heuristics (same names without the QP_ prefix; tests/tools/qp_step_study.py tuned them)
 STEP_ETA = 0.995        # fraction of the step to the boundary: max(STEP_ETA, 1 - mu), capped at 1 - STEP_CAP

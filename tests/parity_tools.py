@@ -253,7 +253,7 @@ RANK_TIE_TOL = 1e-4        # [m] how far beyond the oracle's own cut a point the
                            # the two fp32 encoders agree to 3e-5 in mu / 5e-5 in the distance (test_dune_stage_vs_reference_vectors)
 
 
-def _explain_step(orc, cfg, sc, nom_s, nom_u, hip_pts, u_or, dev, b, k):
+def _explain_step(orc, cfg, sc, nom_s, nom_u, hip_pts, u_or, dev, b, k, hip_u=None):
     """Why does ONE oracle iteration from the HIP path's own iterate differ from the HIP path's next iterate by more than the
     tolerance?  Two measurable causes (reference semantics: dune.py:100-104 keeps the first M columns of an argsort):
       * selection: the HIP path's M points of a slice are not the oracle's first M.  For every such point the oracle's OWN
@@ -263,6 +263,9 @@ def _explain_step(orc, cfg, sc, nom_s, nom_u, hip_pts, u_or, dev, b, k):
         iterate), spreads by `ensemble_spread`: where that reaches a third of the deviation, the reference's own one-step
         answer is not defined better than the deviation (a QP that is flat along a steering direction: fp32 rounding of its
         58 parameters moves the optimum by that much).
+      * same optimum: same selection, and the oracle's OWN QP evaluated at the HIP path's controls (states through the oracle's
+        dynamics, d optimal for them) has the oracle's optimal objective to 1e-11 relative with the bounds held to 1e-6: two
+        solvers at their 1e-14 floor on a QP that is flat along the direction between them (steering of the car at low speed).
     Anything else is UNEXPLAINED and fails the tests."""
     from oracle import pan_oracle as po
     T, M = cfg.T, cfg.nrmp_max_num
@@ -300,10 +303,50 @@ def _explain_step(orc, cfg, sc, nom_s, nom_u, hip_pts, u_or, dev, b, k):
         _, u2, _ = o2.forward(nom_s, nom_u, sc["ref_s"], sc["ref_us"], pts, sc["velocities"])
         spread = max(spread, float(_l2(u2.astype(np.float32), u_or)))
     out["ensemble_spread"] = spread
+    # the oracle's OWN problem at the HIP path's point: states through the oracle's linearised dynamics, d optimal for those
+    # states (it separates per step), everything in fp64.  A point that is feasible to fp32 rounding and whose objective
+    # equals the oracle's optimum to 1e-11 (relative) is an optimum of the same QP to everything fp64 can measure: two 1e-14
+    # solvers may stop that far apart where the QP is flat (curvature ~ residual floor / deviation).
+    pb = getattr(orc, "last_problem", None)
+    if pb is not None and hip_u is not None:
+        uh = np.asarray(hip_u, dtype=np.float64)
+        sh = np.zeros((3, T + 1)); sh[:, 0] = pb.nom_s[:, 0]
+        for t in range(T):
+            sh[:, t + 1] = pb.A[t] @ sh[:, t] + pb.B[t] @ uh[:, t] + pb.C[t]
+        dh = None if pb.no_obs else _best_d(pb, sh)
+        so, uo, do = orc.last_solution
+        jo = pb.objective(so, uo, None if do is None else do.reshape(-1))
+        jh = pb.objective(sh, uh, dh)
+        out["objective_gap_rel"] = float((jh - jo) / max(1.0, abs(jo)))
+        viol = max(float((np.abs(uh) - pb.speed_bound[:, None]).max()),
+                   float((np.abs(np.diff(uh, axis=1)) - pb.acce_bound[:, None]).max()) if T > 1 else 0.0, 0.0)
+        out["bound_violation"] = viol
+    else:
+        out["objective_gap_rel"], out["bound_violation"] = float("nan"), float("nan")
     tie = out["slices_with_other_set"] > 0 and out["rank_gap"] <= RANK_TIE_TOL
     flat = spread >= dev / 3.0
-    out["explained"] = "rank-M tie" if tie else ("one-step ensemble spread" if flat else None)
+    same_opt = out["slices_with_other_set"] == 0 and abs(out["objective_gap_rel"]) <= 1e-11 and out["bound_violation"] <= 1e-6
+    out["explained"] = "rank-M tie" if tie else ("one-step ensemble spread" if flat else ("same optimum of a flat QP" if same_opt else None))
     return out
+
+
+def _best_d(pb, s):
+    """argmin over d_t in [max(d_min, 0), d_max] of  -eta d_t + ro/2 sum_j max(0, d_t - c_tj)^2  with c_tj = fa_tj . s_xy(t+1) - fb_tj
+    (the objective separates per step once the states are fixed: robot.py:183-198, nrmp.py:375-383)."""
+    T, lo, hi = pb.T, max(pb.d_min, 0.0), pb.d_max
+    c = np.einsum("tmk,kt->tm", pb.fa, s[0:2, 1:]) - pb.fb
+    d = np.zeros(T)
+    for t in range(T):
+        cs = np.sort(c[t])
+        # derivative -eta + ro sum_j max(0, d - c_j) is piecewise linear and increasing: find its zero
+        best = hi
+        for k in range(1, len(cs) + 1):                  # k rows active: d = (eta / ro + sum of the k smallest c) / k
+            cand = (pb.eta / pb.ro_obs + cs[:k].sum()) / k
+            if cand >= cs[k - 1] and (k == len(cs) or cand <= cs[k]):
+                best = cand
+                break
+        d[t] = min(max(best, lo), hi)
+    return d
 
 
 def one_step_job(job):
@@ -322,7 +365,8 @@ def one_step_job(job):
     if len(job) > 4 and job[4] is not None:
         dev = float(_l2(u, job[4]))
         if dev > (job[6] if len(job) > 6 else ONE_STEP_TOL):
-            why = _explain_step(orc, cfg, sc, nom_s, nom_u, job[5], u, dev, b, k)
+            orc.last_solution = (np.asarray(s, dtype=np.float64), np.asarray(u, dtype=np.float64), None if d is None else np.asarray(d, dtype=np.float64))
+            why = _explain_step(orc, cfg, sc, nom_s, nom_u, job[5], u, dev, b, k, hip_u=job[4])
     return b, k, u, why
 
 
@@ -386,7 +430,8 @@ def one_step_report(dev, tol=ONE_STEP_TOL, why=None):
     if why is not None:
         rep["above_tol"] = sorted(why, key=lambda w: -w["ctrl_l2"])[:24]
         rep["unexplained"] = int(sum(w["explained"] is None for w in why))
-        rep["explained_by"] = {c: int(sum(w["explained"] == c for w in why)) for c in ("rank-M tie", "one-step ensemble spread")}
+        rep["explained_by"] = {c: int(sum(w["explained"] == c for w in why))
+                               for c in ("rank-M tie", "one-step ensemble spread", "same optimum of a flat QP")}
         assert len(why) == int((flat > tol).sum())
     return rep
 

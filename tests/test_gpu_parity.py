@@ -719,7 +719,7 @@ def test_wrong_margin_is_detected_and_contained():
     import warnings
     with warnings.catch_warnings(record=True) as wlist:
         warnings.simplefilter("always")
-        assert bad.check_audit() == a["violations"]
+        assert bad.check_audit() == bad.audit()["violations"] >= a["violations"]      # (the exact-key launches kept counting)
     assert any("margin" in str(w.message) for w in wlist)
     # resetting the counters lifts the distrust (the owner's decision)
     bad.audit(reset=True)
@@ -809,11 +809,15 @@ def test_bf16_rows_tier_is_labelled_and_its_deviation_is_what_it_is():
         # one PAN iteration: the rows themselves (no amplification over iterations)
         se = exact.dune_stage(batch["nom_s"], batch["points"])
         st = tier.dune_stage(batch["nom_s"], batch["points"])
-        dmu = float((se["mu"] - st["mu"]).abs().max())
+        # (row j of a slice = its j-th nearest point: the sorted distances compare slot by slot, mu only where both tiers
+        # put the same point into the slot)
         ddist = float((se["dist"] - st["dist"]).abs().max())
+        same = (se["pts"] == st["pts"]).all(dim=-1)
+        dmu = float((se["mu"] - st["mu"]).abs().amax(dim=-1)[same].max())
         print(f"bf16 rows tier, {name}: control L2 vs exact rows median {np.median(l2):.2e} p90 {np.quantile(l2, 0.9):.2e} "
-              f"max {l2.max():.2e}, share <= 1e-4: {(l2 <= 1e-4).mean():.3f}; rows: max |d mu| {dmu:.2e}, max |d dist| {ddist:.2e}")
-        assert 1e-5 < dmu < 0.1 and ddist < 0.2            # bf16 rounding of four layers: visible, and bounded
+              f"max {l2.max():.2e}, share <= 1e-4: {(l2 <= 1e-4).mean():.3f}; rows: same point in {float(same.float().mean()):.3f} of the "
+              f"slots, max |d mu| there {dmu:.2e}, max |d sorted distance| {ddist:.2e}")
+        assert 1e-5 < dmu < 0.1 and 1e-5 < ddist < 0.1     # bf16 rounding of four layers: visible, and bounded
         assert np.median(l2) < 0.2                          # a planner, still -- not the reference's answer
 
 

@@ -1,8 +1,8 @@
 """CPU study behind the interior-point heuristics of the QP kernel (nrmp_qp.hip: QP_STEP_ETA / QP_STEP_CAP, QP_START_MU,
 QP_SIGMA_MU_MIN, QP_WARM_DELTA, the warm-start drop rules).  oracle/condensed_ipm.py is the kernel's method in numpy and
 carries the same constants; this tool replays it over EVERY QP the oracle's PAN loop produces on scenes of the four
-benchmark workloads -- warm-started along the loop under the kernel's gate (previous solve converged to 1e-12 and moved
-the controls by < 0.1) -- once per rule set, and counts interior-point iterations.
+benchmark workloads -- warm-started along the loop under the kernel's gate (previous solve converged to 1e-12) -- once
+per rule set, and counts interior-point iterations.
 
     python tests/tools/qp_step_study.py [scenes per workload] [procs]     -> profiles/r03_qp_step_study.txt
     python tests/tools/qp_step_study.py --trace                            -> profiles/r03_qp_tail_trajectories.txt
@@ -57,7 +57,7 @@ def job(arg):
             setattr(ci, k, v)
         rows = []; prev = None; prev_u = None
         for pb in pbs:
-            warm = prev["warm"] if prev is not None and prev["merit"] <= 1e-12 and prev["step"] < 0.1 else None
+            warm = prev["warm"] if prev is not None and prev["merit"] <= 1e-12 else None      # (the kernel's gate, see nrmp_qp.hip)
             s, u, d, info = ci.solve_condensed(pb, warm=warm)
             info["step"] = float(np.abs(u - prev_u).max()) if prev_u is not None else 9.0     # (first nominal: not a solve's output)
             rows.append((info["iters_total"], info["warm_code"], float(info["merit"])))
