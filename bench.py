@@ -185,8 +185,11 @@ class Loop:
         for o, g in (x for x in last if x is not None):
             assert (o["iters"].cpu().numpy() == K).all(), "every scene must run exactly K PAN iterations inside the timed region"
             assert g.numel() == self.world * self.batch * 2 * self.cfg.T
+        na = sum(q.get("aset_launches", 0) for q in profs)
         return dict(elapsed=elapsed, t_issue=t_issue, last=last,
-                    prof={"launches": nl, "dune_ms": avg("dune_ms"), "select_ms": avg("select_ms"), "nrmp_ms": avg("nrmp_ms")})
+                    prof={"launches": nl, "dune_ms": avg("dune_ms"), "select_ms": avg("select_ms"), "nrmp_ms": avg("nrmp_ms"),
+                          "aset_launches": na,
+                          "aset_ms": sum(q.get("aset_ms", 0.0) * q.get("aset_launches", 0) for q in profs) / max(na, 1)})
 
     def audit(self):
         audits = [p.audit() for p in self.pans]
@@ -258,7 +261,7 @@ def parity_leg(lp, scenes, cores, n_ulp=8, n_perm=4, sweep=False):
     rep, hip, sp = judge(trace_u[:scenes], base, members)
     tp = tr["trace_pts"].cpu().numpy()[:scenes] if tr.get("trace_pts") is not None else None
     dev, why = one_step_consistency(lp.workload, range(scenes), tr["trace_s"].cpu().numpy()[:scenes], trace_u[:scenes], cores,
-                                    explain=True, trace_pts=tp)
+                                    explain=True, trace_pts=tp, trace_merit=tr["trace_qp_info"].cpu().numpy()[:scenes, :, 1])
     rep["one_step"] = one_step_report(dev, why=why)
     rep["well_posed_frac"] = round(float((sp[:, -1] <= 1e-4).mean()), 4)
     return rep, cpu_rate, ncore, hip, sp, tr
@@ -367,7 +370,8 @@ def main():
     qp_ms, sel_ms, dune_ms = prof["nrmp_ms"], prof["select_ms"], prof["dune_ms"]
     roof = {"bound": "valu", "kernel": f"nrmp_qp_kernel<{T},{cfg.nrmp_max_num}>", "unit": "TFLOP/s", "peak": PEAK_FP64_VALU_TFLOPS,
             "launch_ms": round(qp_ms, 4), "launches_timed": prof["launches"], "select_launch_ms": round(sel_ms, 4),
-            "dune_launch_ms": round(dune_ms, 4), "key_mode": km, "achieved": None, "frac": None, "traffic": None,
+            "dune_launch_ms": round(dune_ms, 4), "aset_launch_ms": round(prof.get("aset_ms", 0.0), 4),
+            "aset_launches_timed": prof.get("aset_launches", 0), "key_mode": km, "achieved": None, "frac": None, "traffic": None,
             "ipm_iterations_per_launch": round(its_per_launch, 1),
             "ipm_iterations_by_pan_iteration": [[int(s), int(m)] for s, m in its]}
     kq = pmc["kernels"].get("nrmp_qp_kernel") if pmc else None

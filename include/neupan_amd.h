@@ -266,6 +266,9 @@ int npa_nrmp_backward(npa_handle *h, int batch, const float *nom_s, const float 
  * there is no such launch), select_kernel, nrmp_qp_kernel; launches = QP launches timed.  enable=0 turns it off. */
 int npa_profile_enable(npa_handle *h, int enable);
 int npa_profile_read(npa_handle *h, double *dune_ms_avg, double *select_ms_avg, double *nrmp_ms_avg, int64_t *launches);
+/* The active-set launches (NPA_QP_ASET=1: an extra launch of the QP kernel's active-set instantiation in front of the
+ * interior-point launch of every PAN iteration) seen by the LAST npa_profile_read: their average duration and count. */
+int npa_profile_read_aset(npa_handle *h, double *aset_ms_avg, int64_t *launches);
 
 /* ---- the two steps in front of PAN.forward (handle-free, stream-ordered) --------------------------
  *

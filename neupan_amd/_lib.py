@@ -64,6 +64,7 @@ SYMBOLS = {
     "npa_dune_labels": (_I, [_I, _P, _P, C.c_int64, _P, _P, _P, _P]),
     "npa_profile_enable": (_I, [_P, _I]),
     "npa_profile_read": (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "npa_profile_read_aset": (_I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "npa_last_error": (C.c_char_p, []),
     "npa_version": (C.c_char_p, []),
 }

@@ -42,7 +42,7 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
                                     float* out_s, float* out_u, float* out_d, float* out_min_distance,
                                     int* out_iters, float* out_nrmp_points, int* flags, float* state,
                                     double* qp_info, double* warm, float* trig_out, float* dbg_abc, float* dbg_f, double* dbg_x,
-                                    hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);
+                                    hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, int aset_launch);
 extern "C" size_t npa_qp_shmem_bytes(int T, int M);
 extern "C" hipError_t npa_launch_nominal(int batch, int T, int kin, double dt, double L, const double* state,
                                          const float* vel, const double* ref_speed, const double* path,
@@ -123,8 +123,11 @@ struct npa_handle {
   int calls_window = 0, hold = 0;
   // profiling (bench.py): HIP events on the launch stream around every stage launch
   bool prof = false;
-  std::vector<EventPair> ev_dune, ev_sel, ev_qp;
-  size_t n_dune = 0, n_sel = 0, n_qp = 0;
+  std::vector<EventPair> ev_dune, ev_sel, ev_qp, ev_aset;
+  size_t n_dune = 0, n_sel = 0, n_qp = 0, n_aset = 0;
+  double last_aset_ms = 0.0;             // average of the active-set launches seen by the last npa_profile_read
+  long long last_aset_n = 0;
+  int aset_min_batch = 32;               // NPA_QP_ASET_MIN_BATCH: smallest batch that gets the extra active-set launch
 };
 
 extern "C" const char* npa_last_error(void) { return g_err.c_str(); }
@@ -383,6 +386,15 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
   }
   h->sel_debug = getenv("NPA_SEL_DEBUG") != nullptr;
   h->qp_warm = getenv("NPA_QP_COLD") == nullptr;
+  P.qp_aset = (getenv("NPA_QP_ASET") != nullptr && atoi(getenv("NPA_QP_ASET")) != 0) ? 1 : 0;
+  P.prio_sel = 0; P.prio_qp0 = 3; P.prio_qp1 = 3; P.prio_qp2 = 3; P.prio_it1 = 1 << 30; P.prio_it2 = 1 << 30;
+  if (const char* env = getenv("NPA_PRIO")) {
+    int v[6];
+    if (sscanf(env, "%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]) == 6) {
+      P.prio_sel = v[0]; P.prio_qp0 = v[1]; P.prio_qp1 = v[2]; P.prio_qp2 = v[3]; P.prio_it1 = v[4]; P.prio_it2 = v[5];
+    }
+  }
+  if (const char* env = getenv("NPA_QP_ASET_MIN_BATCH")) { int v = atoi(env); if (v >= 1) h->aset_min_batch = v; }
   hipError_t e = hipGetDevice(&h->device);
   if (e == hipSuccess) {
     hipDeviceProp_t prop;
@@ -571,6 +583,7 @@ extern "C" int npa_destroy(npa_handle* h) {
   for (auto& p : h->ev_dune) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto& p : h->ev_sel) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto& p : h->ev_qp) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+  for (auto& p : h->ev_aset) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   if (h->wpack) hipFree(h->wpack);
   if (h->sel_stats_dev) hipFree(h->sel_stats_dev);
   if (h->sel_stats_host) hipHostFree(h->sel_stats_host);
@@ -689,7 +702,7 @@ static EventPair* next_event(npa_handle* h, std::vector<EventPair>& pool, size_t
 extern "C" int npa_profile_enable(npa_handle* h, int enable) {
   if (!h) return fail(NPA_E_ARG, "null handle");
   h->prof = enable != 0;
-  h->n_dune = h->n_sel = h->n_qp = 0;
+  h->n_dune = h->n_sel = h->n_qp = h->n_aset = 0;
   return NPA_OK;
 }
 
@@ -712,8 +725,17 @@ extern "C" int npa_profile_read(npa_handle* h, double* dune_ms_avg, double* sele
   HIP_TRY(avg(h->ev_dune, h->n_dune, dune_ms_avg));
   HIP_TRY(avg(h->ev_sel, h->n_sel, select_ms_avg));
   HIP_TRY(avg(h->ev_qp, h->n_qp, nrmp_ms_avg));
+  HIP_TRY(avg(h->ev_aset, h->n_aset, &h->last_aset_ms));
+  h->last_aset_n = (long long)h->n_aset;
   if (launches) *launches = (int64_t)h->n_qp;
-  h->n_dune = h->n_sel = h->n_qp = 0;
+  h->n_dune = h->n_sel = h->n_qp = h->n_aset = 0;
+  return NPA_OK;
+}
+
+extern "C" int npa_profile_read_aset(npa_handle* h, double* aset_ms_avg, int64_t* launches) {
+  if (!h) return fail(NPA_E_ARG, "null handle");
+  if (aset_ms_avg) *aset_ms_avg = h->last_aset_ms;
+  if (launches) *launches = (int64_t)h->last_aset_n;
   return NPA_OK;
 }
 
@@ -769,7 +791,7 @@ extern "C" int npa_nrmp_stage(npa_handle* h, int batch, const float* nom_s, cons
     return fail(NPA_E_ARG, "npa_nrmp_stage: obstacle arrays required when nrmp_max_num > 0");
   HIP_TRY(npa_launch_qp(h->P, batch, 0, nom_s, nom_u, ref_s, ref_us, mu_sorted, lam_sorted, pts_sorted, nullptr, count,
                         out_s, out_u, out_d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                        qp_info, nullptr, nullptr, nullptr, nullptr, x64, (hipStream_t)stream, nullptr, nullptr));
+                        qp_info, nullptr, nullptr, nullptr, nullptr, x64, (hipStream_t)stream, nullptr, nullptr, 0));
   return NPA_OK;
 }
 
@@ -782,7 +804,7 @@ extern "C" int npa_nrmp_params(npa_handle* h, int batch, const float* nom_s, con
   // (the reference trajectory only enters the cost: the nominal arrays stand in for it, the kernel returns before the solve)
   HIP_TRY(npa_launch_qp(h->P, batch, 0, nom_s, nom_u, nom_s, nom_u, mu_sorted, lam_sorted, pts_sorted, nullptr, count,
                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                        nullptr, nullptr, nullptr, out_abc, h->P.M > 0 ? out_f : nullptr, nullptr, (hipStream_t)stream, nullptr, nullptr));
+                        nullptr, nullptr, nullptr, out_abc, h->P.M > 0 ? out_f : nullptr, nullptr, (hipStream_t)stream, nullptr, nullptr, 0));
   return NPA_OK;
 }
 
@@ -945,12 +967,22 @@ extern "C" int npa_forward_iter(npa_handle* h, int k) {
                                 pc->n_points, flags, gkeys, ws + L.trig, mu, lam, pts, dist, count, h->key_terms, h->key_e0,
                                 h->sel_stats_dev, h->sel_debug, stream, evs ? evs->a : nullptr, evs ? evs->b : nullptr));
   }
+  // the active-set launch in front of the interior-point launch (nrmp_qp.hip, top of the kernel): scenes it finishes are skipped
+  // by the launch behind it.  Register-resident T = 10 / M = 10 instantiation only; small batches keep the single launch (a
+  // launch boundary costs ~10 us of a latency-bound chain: NPA_QP_ASET_MIN_BATCH, default 32)
+  if (P.qp_aset && h->qp_warm && P.T == 10 && P.M == 10 && batch >= h->aset_min_batch && !getenv("NPA_QP_GENERIC")) {
+    EventPair* eva = next_event(h, h->ev_aset, h->n_aset);
+    HIP_TRY(npa_launch_qp(P, batch, 0, cur_s, cur_u, pc->ref_s, pc->ref_us, mu, lam, pts, dist, count, cur_s, cur_u,
+                          cur_d, pc->out_s, pc->out_u, pc->out_d, pc->out_md, pc->out_iters, pc->out_np, flags,
+                          pc->state, qp_info, (double*)(ws + L.warm), pc->dune ? ws + L.trig : nullptr,
+                          nullptr, nullptr, nullptr, stream, eva ? eva->a : nullptr, eva ? eva->b : nullptr, 1));
+  }
   EventPair* ev = next_event(h, h->ev_qp, h->n_qp);
   HIP_TRY(npa_launch_qp(P, batch, 0, cur_s, cur_u, pc->ref_s, pc->ref_us, mu, lam, pts, dist, count, cur_s, cur_u,
                         cur_d, pc->out_s, pc->out_u, pc->out_d, pc->out_md, pc->out_iters, pc->out_np, flags,
                         pc->state, qp_info, h->qp_warm ? (double*)(ws + L.warm) : nullptr, pc->dune ? ws + L.trig : nullptr,
                         nullptr, nullptr, nullptr, stream,
-                        ev ? ev->a : nullptr, ev ? ev->b : nullptr));
+                        ev ? ev->a : nullptr, ev ? ev->b : nullptr, 0));
   if (h->key_auto && pc->dune && k == P.K - 1)
     HIP_TRY(hipMemcpyAsync(h->sel_stats_host, h->sel_stats_dev, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
   return NPA_OK;

@@ -1087,6 +1087,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
   const int t = r_ % nsl + t0, b = bl + scene0;
   const int T = P.T, M = P.M;
   if (flags && flags[b * 4 + 0]) return;
+  npa_setprio(P.prio_sel);
   int n_raw = n_points ? n_points[b] : n_stride;
   n_raw = n_raw < 0 ? 0 : (n_raw > n_stride ? n_stride : n_raw);
   const int n_use = n_raw < P.dune_max_num ? n_raw : P.dune_max_num;

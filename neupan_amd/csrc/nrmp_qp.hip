@@ -30,6 +30,7 @@
 // wave reductions are DPP (quad_perm / row_mirror) + 4 readlanes, and every division in a
 // serial loop is replaced by a reciprocal computed once per iteration.
 #include "pan_common.h"
+#include "aset_reduce.h"
 #include <hip/hip_ext.h>
 #include <cstdlib>
 
@@ -53,6 +54,9 @@
 #ifndef QP_CHOL_LOOK
 #define QP_CHOL_LOOK 3         // columns behind the pivot whose trailing update is broadcast with v_readlane (the rest: LDS, one pivot late)
 #endif
+#define QP_ASET_FIRST_MAX 0.05 // the attempt is not made from a warm point whose seeded merit is above this (most of those cycle: 85 % of the failures)
+#define QP_ASET_MAX_GUESS 2     // factorisations the active-set iteration may spend before the interior-point warm start takes over
+#define QP_ASET_TOL 1e-13      // what may be left of the scaled dual residual at a guess that repeated
 #define QP_RETRY_MERIT 1e-9    // a cold solve that ends above this is repeated once from round 2's start (unit multipliers)
 #define QP_SIGMA_MU_MIN 1e-15  // floor of the centring target: a gap driven to 1e-20 leaves the Newton matrix too ill
                                //   conditioned for the residuals to follow (solves that ended at 1e-11: 8 -> 1 of 640)
@@ -306,7 +310,7 @@ __device__ __forceinline__ PairC qp_pair(int p, int T, int npu, double sb0, doub
 // SCANW: the scan forms of the Phi products and the P_t blocks also for horizons of 17..32 steps (two DPP rows); the
 // launcher's default at T = 20 (acker: 69 k -> 79 k plans/s; the parity verdicts of tests/test_gpu_parity.py are the
 // same with and without them).  NPA_QP_NOSCAN_WIDE=1 selects the dense-product instantiation for A/B measurements.
-template <int TT, int MM, bool BWD = false, bool SCANW = false, int WV = NPA_QP_WAVES>
+template <int TT, int MM, bool BWD = false, bool SCANW = false, int WV = NPA_QP_WAVES, bool ASET_T = false>
 // (two waves per SIMD: <= 256 registers.  tests/test_abi.py reads the counts of the built code object and fails on any
 // spill or scratch use)
 __global__ __attribute__((amdgpu_flat_work_group_size(QP_THREADS, QP_THREADS), amdgpu_waves_per_eu(WV, 3)))
@@ -330,9 +334,21 @@ void nrmp_qp_kernel(
   const int b = blockIdx.x + scene0;
   double* sm = sm_all;
   if (flags && flags[b * 4 + 0]) return;
+  // Two launches per PAN iteration when the active-set iteration is on (P.qp_aset): the ASET instantiation goes first and tries
+  // the scenes whose previous solve converged; a scene it finishes (solution, warm record, stop test: the same tail as here)
+  // is marked in flags[3], and the interior-point instantiation that follows skips it.  A scene the attempt gives up on is
+  // left untouched (nothing of this kernel reaches global memory before its tail).
+  if constexpr (ASET_T) {
+    if (!(warm && flags && flags[b * 4 + 2] && P.qp_aset)) return;
+  } else {
+    if (flags && flags[b * 4 + 3]) {
+      if (lane == 0) flags[b * 4 + 3] = 0;
+      return;
+    }
+  }
   // this wave is a long dependent chain that shares its SIMD with throughput-bound selection waves of
   // the other batches in flight: win the issue arbitration, it needs few slots but needs them promptly
-  __builtin_amdgcn_s_setprio(3);
+  npa_setprio(P.prio_qp0);
 
   // with TT and MM fixed every LDS offset below folds to an immediate (one base register)
   PROF_DECL
@@ -661,7 +677,7 @@ void nrmp_qp_kernel(
   //   s = Phi v :  theta_t = sum_{r<=t} B_r[2,:] v_r ;  xy_t = sum_{r<=t} (a_r theta_{r-1} + B_r[:2,:] v_r)
   //   w = Phi'q :  l_xy,t = sum_{r>=t} q_r[:2] ;  l_2,t = sum_{r>=t} (q_r[2] + a_{r+1} . l_xy,r+1) ;  w_t = B_t' l_t
   // (checked against the dense forms in fp64: tests/tools/scan_forms_check.py)
-  auto phi_mul = [&](const double* v, double* out3) {
+  auto phi_mul = [&](const double* v, double* out3) __attribute__((always_inline)) {
     if constexpr (SCAN) {
       const bool on = lane < TT;
       const int t = on ? lane : 0;
@@ -692,7 +708,7 @@ void nrmp_qp_kernel(
     }
   };
   // w_a = sum_{t,k} Phi[t][k][a] in3[t][k]   (returned for a = lane, 0 for lane >= nu)
-  auto phi_tmul = [&](const double* in3) -> double {
+  auto phi_tmul = [&](const double* in3) __attribute__((always_inline)) -> double {
     double acc = 0;
     if constexpr (SCAN) {
       const bool on = lane < TT;
@@ -743,7 +759,7 @@ void nrmp_qp_kernel(
     return acc;
   };
   // C_u' y for variable a (y indexed like the u rows)
-  auto ct_mul = [&](const double* y, int a) -> double {
+  auto ct_mul = [&](const double* y, int a) __attribute__((always_inline)) -> double {
     // (no branches: the two rate pairs that may not exist are read at a clamped index and weighted 0, so that the three
     // 128-bit loads go out together)
     const int t = a >> 1;
@@ -774,11 +790,36 @@ void nrmp_qp_kernel(
   int it_total = 0, warm_code = 0;       // diagnostics: iterations over all attempts; 1 warm start used, 2 / 3 dropped at it 0 / 6, 4 not converged, 5 cold retry
   bool warm_now = can_warm;              // the solve in progress started from the previous solution
   bool need_cold = false;                // re-initialise at the top of the next iteration (a dropped warm attempt)
-  if (WARM && warm_now) {
+  // ---- active-set iteration on the warm solves (branch qp-active-set; NPA_QP_ASET=1; T = 10 / M = 10 instantiation) ----------
+  // tests/tools/qp_active_set_study.py states the method (active_set_solve_kernel_form with project_d) and measures it: from the
+  // previous PAN iteration's solution the guess of the active set reproduces itself after 1.0 - 1.3 factorisations on ~90 % of the
+  // QPs behind the warm-start gate.  Here the loop body below is REUSED: seeded with l = ro e, w = 0 on the hinge rows that are on
+  // (l = 0, w = slack on the others) and with l = 0 on every linear row, its residual phase, per-step blocks, K' build,
+  // factorisation and predictor pass compute exactly the Newton step of the guessed equality-constrained QP in (u, d) -- d
+  // eliminated per step as always, or frozen (1/kappa := 0) where it sits on a bound it is pushed against.  What is new: the
+  // tight speed / rate rows are eliminated from K' before the factorisation (aset::reduce_matrix), the right-hand side follows
+  // (reduce_rhs), the step is expanded (expand) and taken in full, d is clipped, and the next pass of the residual phase
+  // recovers the multipliers of the tight rows (multipliers) and makes the next guess.  A guess that repeats is a KKT point:
+  // accepted when what is left of the dual residual is below QP_ASET_TOL; anything else falls back to the interior-point warm
+  // start (warm_init once more).  NOT VALIDATED ON A GPU yet (only aset_reduce.h's parts were, in their first form).
+  constexpr bool ASET = ASET_T && WARM && REGROWS && SCAN && (NU <= 20);      // (its own instantiation: the extra state spills for now)
+  bool aset = false, aset_done = false;
+  int aset_guess = 0;
+  int aset_why = 0;                      // diagnostics (qp_info[5..7]): 1 accepted, 2 a repeated guess left a residual, 3 guesses used up, 4 restarted cold
+  double aset_left = 0.0;                // the scaled residual of the last repeated guess
+  double aset_first = 0.0;               // merit of the seeded warm point (first pass)
+  unsigned long long ag_on0 = 0, ag_on1 = 0, ag_tp = 0, ag_tm = 0, ag_d = 0;      // the guess in force, as ballots
+  bool aset_onx = false, aset_ony = false, aset_dtp = false, aset_dtm = false, aset_dfix = false, aset_tied = false;
+  double aset_lam_p = 0.0, aset_lam_m = 0.0, aset_cx = 0.0, aset_resd = 0.0;
+  aset::Lane AL{};
+  const aset::Scratch AS{s3, dxu, Km, reinterpret_cast<int*>(dxd), ldk};      // all dead while reduce_matrix runs
+  if constexpr (ASET) aset = true;       // (this instantiation does nothing else: the gate is at the kernel's top)
+  auto warm_init = [&]() __attribute__((always_inline)) {
     const double dl = QP_WARM_DELTA;
     for (int a = lane; a < nu; a += QP_THREADS) { xu[a] = wrm[a]; xbest[a] = wrm[a]; }
     for (int t = lane; t < T; t += QP_THREADS) { xd[t] = fmin(fmax(wrm[nu + t], dmin0), dmaxv); xbest[nu + t] = xd[t]; }
     LSYNC();
+    if constexpr (ASET) return;            // (the active-set iteration seeds its own rows from x in its residual phase)
     phi_mul(xu, s3);
     LSYNC();
     if constexpr (REGROWS) {
@@ -807,15 +848,27 @@ void nrmp_qp_kernel(
       }
     }
     LSYNC();
+  };
+  if (WARM && warm_now) warm_init();
+  if constexpr (ASET) {
+    if (aset) {
+      // an interior-point iterate sits 1e-15 inside its bounds: snap d, and take the record's multipliers of this lane's pair raw
+      for (int t = lane; t < T; t += QP_THREADS) { const double dv = xd[t]; xd[t] = dv >= dmaxv - 1e-8 ? dmaxv : (dv <= dmin0 + 1e-8 ? dmin0 : dv); }
+      if (lane < npu && my_pair.actf != 0.0) { const double* wl = wrm + nu + T + mf + 2 * lane; aset_lam_p = wl[0]; aset_lam_m = wl[1]; }
+      LSYNC();
+    }
   }
   for (it = 0; it <= QP_MAX_IT; ++it) {
-    if constexpr (WARM) {
+    if constexpr (WARM && !ASET) {
       if (need_cold) {                     // restart of a dropped warm attempt, or of a jammed cold one: the cold start again
         need_cold = false;
         QP_COLD_INIT();
         best_merit = 1e300; last_mu = 0; best_it = 0; stall = 0; status = 0;
       }
     }
+    // (iterations over all attempts of this solve: a dropped warm attempt's count)
+    if (it_total + it == P.prio_it1) npa_setprio(P.prio_qp1);
+    if (it_total + it == P.prio_it2) npa_setprio(P.prio_qp2);
     // ================= residuals =================
     PROF_B(8); PROF_C(8);
     phi_mul(xu, s3);
@@ -825,8 +878,20 @@ void nrmp_qp_kernel(
     if constexpr (HPAIR) {
       for (int h = lane; h < mf / 2; h += QP_THREADS) {
         const int t = h / (MM / 2), i = 2 * h;
-        const double2 l = ld2(lf + i), w = LD_WF(h), a0 = ld2(fa0 + i), a1 = ld2(fa1 + i), f = LD_FF(h);
+        double2 l = ld2(lf + i), w = LD_WF(h);
+        const double2 a0 = ld2(fa0 + i), a1 = ld2(fa1 + i), f = LD_FF(h);
         const double sx = s3[t * 3], sy = s3[t * 3 + 1], d = xd[t];
+        if constexpr (ASET) {
+          if (aset) {                        // seed: a row that is on carries l = ro e and no slack, the others l = 0 and their slack
+            const double ex = f.x + d - (a0.x * sx + a1.x * sy), ey = f.y + d - (a0.y * sx + a1.y * sy);
+            aset_onx = ex > 0.0; aset_ony = ey > 0.0;
+            const double ro = (double)P.ro_obs;
+            l = make_double2(aset_onx ? ro * ex : 0.0, aset_ony ? ro * ey : 0.0);
+            w = make_double2(aset_onx ? 0.0 : fmax(-ex, 1e-300), aset_ony ? 0.0 : fmax(-ey, 1e-300));
+            st2(lf + i, l.x, l.y);
+            ST_ROW(Rwf, wf, h, w.x, w.y);
+          }
+        }
         const double rx = a0.x * sx + a1.x * sy - d - f.x + l.x * iro - w.x;
         const double ry = a0.y * sx + a1.y * sy - d - f.y + l.y * iro - w.y;
         ST_ROW(Rr3, r3, h, rx, ry);
@@ -848,8 +913,17 @@ void nrmp_qp_kernel(
     PROF_B(2);
     for (int p = lane; p < npc; p += QP_THREADS) {
       const PairC c = PAIR_C(p);
-      const double2 l = ld2(lc + 2 * p), w = LD_WC(p);
+      double2 l = ld2(lc + 2 * p), w = LD_WC(p);
       const double cx = fma(-c.sb, xu[c.ib], xu[c.ia]);
+      if constexpr (ASET) {
+        if (aset) {                          // no weight from any linear row (the tight ones are eliminated, not penalised)
+          l = make_double2(0.0, 0.0);
+          w = c.actf != 0.0 ? make_double2(fmax(c.bp - cx, 1e-300), fmax(c.bm + cx, 1e-300)) : make_double2(1.0, 1.0);   // (a switched-off pair has no finite bound)
+          st2(lc + 2 * p, 0.0, 0.0);
+          ST_ROW(Rwc, wc, p, w.x, w.y);
+          aset_cx = cx;
+        }
+      }
       const double rp = (cx + w.x - c.bp) * c.actf, rm = (w.y - cx - c.bm) * c.actf;
       ST_ROW(Rr2, r2, p, rp, rm);
       st2(iwc + 2 * p, fast_rcp(w.x), fast_rcp(w.y));
@@ -897,6 +971,18 @@ void nrmp_qp_kernel(
         r1d = -(double)P.eta + ld_[2 * t] - ld_[2 * t + 1] + zs;       // g_d + C'lam - F'lam
       }
       double ik = obs ? fast_rcp(kap) : 0.0;
+      if constexpr (ASET) {
+        if (aset) {
+          // d of this step: frozen where it sits on a bound it is pushed against (its row then carries eta - zs as a multiplier),
+          // frozen as well when no hinge row is on (nothing to eliminate it through; eta pushes it up: consistent only on d_max),
+          // else eliminated as always (no weight from its rows: kappa = ro |rows on|)
+          const double resd = (double)P.eta - zs, dcur = xd[t];
+          aset_dtp = obs && dcur >= dmaxv && resd > 0.0; aset_dtm = obs && dcur <= dmin0 && resd < 0.0;
+          aset_dfix = aset_dtp || aset_dtm || !(sg > 0.0);
+          aset_resd = resd;
+          if (aset_dfix) { ik = 0.0; r1d = 0.0; }
+        }
+      }
       double* S = St + t * QP_ST_LD;
       S[0] = s00 - v0 * v0 * ik; S[1] = s01 - v0 * v1 * ik; S[2] = s11 - v1 * v1 * ik;
       S[3] = v0; S[4] = v1; S[5] = sg; S[6] = ik; S[7] = r1d;
@@ -927,6 +1013,67 @@ void nrmp_qp_kernel(
     if (qp_info && lane == 0 && it < 4) { double* qq = qp_info + (size_t)b * QP_INFO_STRIDE; qq[5 + 2 * it] = merit; qq[6 + 2 * it] = mu; }
 #endif
     if (!(merit == merit) || !(merit < 1e300)) { status = 2; break; }
+    if constexpr (ASET) {
+      if (aset) {
+        if (aset_guess == 0) {
+          aset_first = merit;
+          if (merit > QP_ASET_FIRST_MAX) { aset_why = 5; break; }      // far from a KKT point of any guess: the interior-point launch takes it
+        }
+        // (a) multipliers of the tight rows of the guess in force, from the gradient at this point (first pass: the warm record's)
+        double run_sum = 0.0;
+        const bool is_rate = lane >= 2 * T && lane < npu;
+        if (aset_guess > 0) {
+          double vt, bb;
+          aset::multipliers<NU>(lane < nu ? -r1u : 0.0, aset_tied, lane, AL, vt, bb, run_sum);
+          // a speed pair sits in its variable's lane; rate pair p = 2T + q leads INTO variable q + 2 and reads that lane
+          const double vt_r = aset::bperm_f64(vt, is_rate ? lane - 2 * T + 2 : lane);
+          const bool tp_prev = ((ag_tp >> lane) & 1ull) != 0, tm_prev = ((ag_tm >> lane) & 1ull) != 0;
+          if (lane < 2 * T) { aset_lam_p = tp_prev ? bb : 0.0; aset_lam_m = tm_prev ? -bb : 0.0; }
+          else if (is_rate) { aset_lam_p = tp_prev ? vt_r : 0.0; aset_lam_m = tm_prev ? -vt_r : 0.0; }
+        }
+        // (b) the next guess: a linear row is tight iff its multiplier plus its violation is positive
+        bool tp = false, tm = false;
+        if (lane < npu && my_pair.actf != 0.0) {
+          tp = aset_lam_p + (aset_cx - my_pair.bp) > 0.0;
+          tm = aset_lam_m + (-aset_cx - my_pair.bm) > 0.0;
+        }
+        const unsigned long long n_on0 = __ballot(aset_onx && lane < mf / 2), n_on1 = __ballot(aset_ony && lane < mf / 2);
+        const unsigned long long n_tp = __ballot(tp), n_tm = __ballot(tm);
+        const unsigned long long n_d = __ballot(aset_dtp && lane < T) | (__ballot(aset_dtm && lane < T) << 16) | (__ballot(aset_dfix && lane < T) << 32);
+        const bool same = aset_guess > 0 && n_on0 == ag_on0 && n_on1 == ag_on1 && n_tp == ag_tp && n_tm == ag_tm && n_d == ag_d;
+        bool give_up = false;
+        if (same) {
+          // this point is the KKT point of its own guess.  What can be left of the dual residual: the sum over a run that no
+          // speed row anchors (at its head), and eta - zs on a step whose d is not on a bound it is pushed against
+          double left = 0.0, viol = 0.0;
+          if (lane < nu && AL.head == lane && !AL.anchored) left = fabs(run_sum);
+          if (lane < T && obs && !(aset_dtp || aset_dtm)) left = fmax(left, fabs(aset_resd));
+          if (lane < npu && my_pair.actf != 0.0) viol = fmax(0.0, fmax(tp ? 0.0 : aset_cx - my_pair.bp, tm ? 0.0 : -aset_cx - my_pair.bm));
+          const double merit_a = wave_reduce<OpMax>(fmax(left * iscale_d, viol * iscale_p));
+          aset_left = merit_a;
+          if (merit_a <= QP_ASET_TOL) {
+            aset_why = 1;
+            best_merit = merit_a; best_it = it; last_mu = 0.0; stall = 0;
+            for (int a = lane; a < nu; a += QP_THREADS) xbest[a] = xu[a];
+            for (int t = lane; t < T; t += QP_THREADS) xbest[nu + t] = xd[t];
+            // the record the next solve starts from: the hinge rows carry theirs already; the linear rows get them here
+            if (lane < npu) st2(lc + 2 * lane, tp ? fmax(aset_lam_p, 0.0) : 0.0, tm ? fmax(aset_lam_m, 0.0) : 0.0);
+            if (lane < T && obs) st2(ld_ + 2 * lane, aset_dtp ? aset_resd : 0.0, aset_dtm ? -aset_resd : 0.0);
+            LSYNC();
+            aset_done = true;
+            break;
+          }
+          give_up = true;
+        }
+        if (give_up || aset_guess >= QP_ASET_MAX_GUESS) {     // not this time: the interior-point launch solves this scene
+          aset_why = give_up ? 2 : 3;
+          break;
+        }
+        ag_on0 = n_on0; ag_on1 = n_on1; ag_tp = n_tp; ag_tm = n_tm; ag_d = n_d;
+        ++aset_guess;
+      }
+    }
+    if constexpr (!ASET) {
     // a warm start that is not paying off is dropped at once: a good one starts at merit <= 1.2e-2 and needs 3 - 5
     // iterations with the adaptive step; one that starts far from feasibility is dropped before its first iteration, one
     // that is not below 3e-3 after three or has not reached 1e-4 after six is stuck (the one case in 1360 QPs went on for
@@ -981,6 +1128,7 @@ void nrmp_qp_kernel(
         break;
       }
     }
+    }   // !ASET
     PROF(1); PROF_B(6);
 
     // ================= reduced KKT matrix, Cholesky =================
@@ -1099,6 +1247,42 @@ void nrmp_qp_kernel(
       // computes on and above its diagonal are unused garbage and are not stored)
       // (written so that the next pivot's reciprocal square root -- the serial chain -- starts before the trailing
       // update of the current column, which is independent of it)
+      if constexpr (ASET) {
+        if (aset) {
+          // this lane's variable a = lane: the tight rate row into it (pair 2T + a - 2: u_a - u_(a-2) <= bp, -(..) <= bm) and its tight
+          // speed row (pair a: u_a <= bp, -u_a <= bm), from the guess in force
+          const bool isv = lane < nu, has_r = isv && lane >= 2;
+          const int pr = 2 * T + lane - 2;
+          const bool t_p = has_r && ((ag_tp >> pr) & 1ull) != 0, t_m = has_r && ((ag_tm >> pr) & 1ull) != 0;
+          const double rbp = aset::bperm_f64(my_pair.bp, has_r ? pr : lane), rbm = aset::bperm_f64(my_pair.bm, has_r ? pr : lane);
+          const double tieoff = t_p ? rbp : (t_m ? -rbm : 0.0);
+          const bool b_p = isv && ((ag_tp >> lane) & 1ull) != 0, b_m = isv && ((ag_tm >> lane) & 1ull) != 0;
+          aset_tied = t_p || t_m;
+          // the row build only fills the lower triangle (the factorisation reads nothing else); the reduction folds whole rows
+          // AND columns: complete the row from the other lanes' lower parts through the LDS matrix (free until L is parked)
+          if (lane < NU) {
+#pragma unroll
+            for (int c = 0; c < NU; ++c) Km[lane * ldk + c] = arow[c];
+          }
+          LSYNC();
+          {
+            const int a = lane < NU ? lane : 0;
+            int lo = lane;
+            asm volatile("" : "+v"(lo));
+#pragma unroll
+            // (both operands from LDS: with `c > lo ? Km[..] : arow[c]` the compiler selects between the two ADDRESSES, and an
+            // address of the register row escaping sends the whole row to scratch memory)
+            for (int c = 0; c < NU; ++c) { const double up = Km[c * ldk + a], low = Km[a * ldk + c]; arow[c] = c > lo ? up : low; }
+          }
+          LSYNC();
+          double adj;
+          aset::reduce_matrix<NU>(arow, tieoff, b_p || b_m, b_p ? my_pair.bp : -my_pair.bm, isv ? xu[lane] : 0.0, lane, AS, AL, adj);
+          r1u += adj;                        // the pass forms its right-hand side as (...) - r1u: K' offd leaves it through here
+          LSYNC();
+          if (lane < NU) Km[lane * ldk + NU - 1] = 0.0;       // (Km served as the transposition buffer: its last column is never parked)
+          LSYNC();
+        }
+      }
       double piv = readlane_f64(arow[0], 0);
       if (!(piv > 0.0)) chol_ok = false;
       double rinv = fast_rsqrt(piv);
@@ -1222,6 +1406,7 @@ void nrmp_qp_kernel(
     }
     // (past 1e-11 the reduced matrix can lose positive definiteness in fp64: the best iterate stands, converged)
     if (!chol_ok) {
+      if constexpr (ASET) { aset_why = 4; break; }        // (the reduced matrix of the guess does not factor: the interior-point launch)
       if constexpr (WARM) {
         if (warm_now && !(best_merit <= 1e-10)) { warm_code = 4; it_total += it; warm_now = false; need_cold = true; it = -1; continue; }
       }
@@ -1259,8 +1444,9 @@ void nrmp_qp_kernel(
     // ================= predictor / corrector =================
     double sigma_mu = 0, alpha = 1.0;
 #pragma nounroll
-    for (int pass = 0; pass < (adj ? 1 : 2); ++pass) {
+    for (int pass = 0; pass < ((adj || ASET) ? 1 : 2); ++pass) {
       PROF_C(7);
+      if constexpr (!ASET) {
       // per-row weights of the rhs, staged in dwf/dwc/dwd (overwritten by the directions below)
       //   tfw = (r4f + lf r3)/(wf + lf/ro) ; tcw = (lc r2 - r4c)/wc ; r4 = lam w [+ dw dl - sigma mu]
       // (pass 0 must not read dw / dl: they hold the previous iteration's directions, nothing at all in the first one)
@@ -1287,11 +1473,14 @@ void nrmp_qp_kernel(
         st2(dwc + i, af * ((l.x * r.x - r4x) * iw.x), af * ((l.y * r.y - r4y) * iw.y));
       }
       LSYNC();
+      }   // !ASET
       PROF_C(1);
       double pq0 = 0, pq1 = 0, rdr = 0;
       for (int t = lane; t < T; t += QP_THREADS) {
         double z0 = 0, z1 = 0, zs = 0;
-        if constexpr (HPAIR) {
+        if constexpr (ASET) {
+          // (the seeded rows carry no weights: nothing to sum)
+        } else if constexpr (HPAIR) {
           constexpr int HB = WV >= 3 ? 2 : MM / 2;
 #pragma unroll
           for (int j0 = 0; j0 < MM / 2; j0 += HB) {
@@ -1316,7 +1505,7 @@ void nrmp_qp_kernel(
         }
         double rd = 0;
         const double* S = St + t * QP_ST_LD;                                       // v0 v1 at [3] [4], 1/kappa [6], r1_d [7]
-        if (obs) rd = -S[7] - (dwd[2 * t] - dwd[2 * t + 1]) + zs;           // rhs of the d rows
+        if (obs) rd = -S[7] - (ASET ? 0.0 : dwd[2 * t] - dwd[2 * t + 1]) + zs;           // rhs of the d rows
         double e = rd * S[6];                                               // rhs_d / kappa
         rdr = rd;
         pq0 = -(z0 - S[3] * e);
@@ -1328,7 +1517,10 @@ void nrmp_qp_kernel(
       LSYNC();
       PROF_C(2);
       rr = phi_tmul(q3);
-      if (lane < nu) rr += -r1u - ct_mul(dwc, lane);
+      if (lane < nu) rr += -r1u - (ASET ? 0.0 : ct_mul(dwc, lane));
+      if constexpr (ASET) {
+        if (aset) rr = aset::reduce_rhs<NU>(lane < nu ? rr : 0.0, lane, AL);      // Z'(r - K' offd) (offd went in with r1u), zero on the members that left
+      }
       PROF_C(3);
       if constexpr (TT > 0) {
         // forward substitution L y = rhs, backward L' dx = y; lane i owns entry i and reads row i / column i of the
@@ -1374,6 +1566,9 @@ void nrmp_qp_kernel(
           for (int k = NU - 1; k >= 0; --k) rr = fma(-Km[k * ldk + lr], readlane_f64(rr, k), rr);
         }
         rr *= myinv;                         // dx_u
+        if constexpr (ASET) {
+          if (aset) rr = aset::expand<NU>(rr, lane, AS, AL);                        // du = Z z + offd (offd waits in s3[0 .. NU): nothing writes s3 before phi_mul(dxu) below)
+        }
       } else {
         for (int k = 0; k < nu; ++k) {
           double yk = readlane_f64(rr * myinv, k);
@@ -1395,6 +1590,9 @@ void nrmp_qp_kernel(
         dxd[t] = (rdr + St[t * QP_ST_LD + 3] * s3[t * 3] + St[t * QP_ST_LD + 4] * s3[t * 3 + 1]) * St[t * QP_ST_LD + 6];
       LSYNC();
       PROF_C(5);
+      if constexpr (ASET) {
+        if (aset) { alpha = 1.0; break; }    // the Newton step of the guess is taken in full; the rows are re-seeded, not moved
+      }
       // directions of multipliers / slacks and the step to the boundary
       double amax = 1.0, gap_aff = 0;
       // step to the boundary of one row: dl, dw < 0 bound alpha by -l/dl, -w/dw
@@ -1506,6 +1704,9 @@ void nrmp_qp_kernel(
     }
     for (int a = lane; a < nu; a += QP_THREADS) xu[a] += alpha * dxu[a];
     for (int t = lane; t < T && obs; t += QP_THREADS) xd[t] += alpha * dxd[t];
+    if constexpr (ASET) {                    // d is projected onto its bounds (a frozen d then never has to travel); the rows are re-seeded, not moved
+      for (int t = lane; t < T && obs; t += QP_THREADS) xd[t] = fmin(fmax(xd[t], dmin0), dmaxv);
+    } else {
     if constexpr (HPAIR) {
       for (int h = lane; h < mf / 2; h += QP_THREADS) {
         const double2 l = ld2(lf + 2 * h), w = LD_WF(h), dl = LD_DLF(h), dw = ld2(dwf + 2 * h);
@@ -1518,12 +1719,25 @@ void nrmp_qp_kernel(
       const double2 l = ld2(lc + 2 * p), w = LD_WC(p), dl = LD_DLC(p), dw = ld2(dwc + 2 * p);
       st2(lc + 2 * p, l.x + alpha * dl.x, l.y + alpha * dl.y); ST_ROW(Rwc, wc, p, w.x + alpha * dw.x, w.y + alpha * dw.y);
     }
+    }   // !ASET
     LSYNC();
     PROF(8);
   }
   LSYNC();
   it_total += it;
+  if constexpr (ASET) {
+    if (!aset_done) {                      // nothing was written: the interior-point launch behind this one solves the scene
+#ifndef NPA_QP_PROF
+      if (qp_info && lane == 0) {
+        double* qi = qp_info + (size_t)b * QP_INFO_STRIDE;
+        qi[5] = aset_guess; qi[6] = aset_left; qi[7] = status == 2 ? 6 : aset_why; qi[8] = aset_first;
+      }
+#endif
+      return;
+    }
+  }
   if (warm_now) warm_code = 1;
+  if (aset_done) warm_code = 6;          // the active-set iteration delivered this solve
   if (status == 0 && !(best_merit <= QP_RETRY_MERIT)) status = 4;      // both cold attempts ended short of convergence
 
   if (bw.dbg_x)
@@ -1576,12 +1790,19 @@ void nrmp_qp_kernel(
     // by its merit anyway (> 0.05), and the moderately far ones that get through save more iterations than the few that
     // are dropped at iteration 6 cost -- 7.7 vs 8.1 iterations per solve on configs[1], 7.4 vs 7.5 on the car.  So the
     // condition is gone, on purpose.)
-    if (flags && lane == 0) flags[b * 4 + 2] = (status == 0 && best_merit <= 1e-12) ? 1 : 0;
+    if (flags && lane == 0) {
+      flags[b * 4 + 2] = (status == 0 && best_merit <= 1e-12) ? 1 : 0;
+      if constexpr (ASET) flags[b * 4 + 3] = 1;          // (the interior-point launch behind this one skips the scene)
+    }
   }
   if (qp_info && lane == 0) {
     double* qi = qp_info + (size_t)b * QP_INFO_STRIDE;
     qi[0] = best_it; qi[1] = best_merit; qi[2] = last_mu; qi[3] = status; qi[4] = it;
     qi[14] = it_total; qi[15] = warm_code;
+#ifndef NPA_QP_PROF
+    if constexpr (ASET) { qi[5] = aset_guess; qi[6] = aset_left; qi[7] = aset_why; qi[8] = aset_first; }
+    else if (P.qp_aset && !(can_warm)) { qi[5] = 0; qi[6] = 0; qi[7] = 0; qi[8] = 0; }      // (no attempt was made on this scene)
+#endif
 #ifdef NPA_QP_PROF
     PROF(9);
     for (int i = 0; i < 10; ++i) qi[5 + i] = (double)pacc_[i];
@@ -1713,7 +1934,7 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
                                     float* out_min_distance, int* out_iters, float* out_nrmp_points, int* flags,
                                     float* state, double* qp_info, double* warm, float* trig_out, float* dbg_abc,
                                     float* dbg_f, double* dbg_x,
-                                    hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                                    hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, int aset_launch) {
   static const bool force_generic = getenv("NPA_QP_GENERIC") != nullptr;     // tests: the generic (LDS) instantiation for every (T, M)
   const bool fast = qp_fast_path(P.T, P.M) && !force_generic;
   const size_t shmem = npa_qp_shmem_bytes_path(P.T, P.M, fast ? 1 : 0);      // one scene (wave) per workgroup, see the kernel
@@ -1724,6 +1945,7 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
   if (attr_set.need(&dev_)) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<10, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<10, 10, false, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<20, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<20, 10, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set.done(dev_);
@@ -1735,7 +1957,12 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
                         out_nrmp_points, flags, state, qp_info, warm, scene0, batch,                                 \
                         QpBackward{nullptr, nullptr, nullptr, nullptr, nullptr, dbg_abc, dbg_f, dbg_x}, trig_out)
   const bool scan_wide = qp_scan_wide();
-  if (P.T == 10 && P.M == 10 && !force_generic) QP_LAUNCH(10, 10);
+  if (aset_launch) {
+    // the active-set launch that precedes the interior-point launch of the same PAN iteration (see the kernel's top)
+    if (!(P.T == 10 && P.M == 10 && !force_generic && P.qp_aset && warm && flags)) return hipErrorInvalidValue;
+    QP_LAUNCH(10, 10, false, false, 2, true);
+  }
+  else if (P.T == 10 && P.M == 10 && !force_generic) QP_LAUNCH(10, 10);
   else if (P.T == 20 && P.M == 10 && !force_generic && scan_wide) QP_LAUNCH(20, 10, false, true);
   else if (P.T == 20 && P.M == 10 && !force_generic) QP_LAUNCH(20, 10);
   else QP_LAUNCH(0, 0);

@@ -735,7 +735,9 @@ class PAN(torch.nn.Module):
     def profile_read(self):
         a, s_, b, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
         check(self._lib.npa_profile_read(self._h, C.byref(a), C.byref(s_), C.byref(b), C.byref(n)), "npa_profile_read")
-        return dict(dune_ms=a.value, select_ms=s_.value, nrmp_ms=b.value, launches=n.value)
+        am, an = C.c_double(), C.c_int64()
+        check(self._lib.npa_profile_read_aset(self._h, C.byref(am), C.byref(an)), "npa_profile_read_aset")
+        return dict(dune_ms=a.value, select_ms=s_.value, nrmp_ms=b.value, launches=n.value, aset_ms=am.value, aset_launches=an.value)
 
 
 class _PanGrad(torch.autograd.Function):

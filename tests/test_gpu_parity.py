@@ -169,7 +169,8 @@ def _ensemble_verdict(cfgname, scenes, step_tol=None):
     rep, hip, sp = judge(out["trace_u"].cpu().numpy(), base, members)
     from parity_tools import one_step_consistency, one_step_report
     dev, why = one_step_consistency(cfgname, range(scenes), out["trace_s"].cpu().numpy(), out["trace_u"].cpu().numpy(),
-                                    os.cpu_count() or 1, explain=True, trace_pts=out["trace_pts"].cpu().numpy(), tol=step_tol)
+                                    os.cpu_count() or 1, explain=True, trace_pts=out["trace_pts"].cpu().numpy(), tol=step_tol,
+                                    trace_merit=qi[:, :, 1])
     rep["one_step"] = one_step_report(dev, tol=1e-4 if step_tol is None else step_tol, why=why)
     rep["_hip"], rep["_spread"] = hip, sp
     print({k: v for k, v in rep.items() if k not in ("worst_scenes", "_hip", "_spread")})

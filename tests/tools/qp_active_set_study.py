@@ -68,7 +68,7 @@ def active_set_solve(H, g, F, f, C, c, ro, x, lam, max_it=8):
     return x, lam, max_it, False
 
 
-def active_set_solve_kernel_form(pb, H, g, F, f, C, c, x, lam, max_it=8, lane_check=None):
+def active_set_solve_kernel_form(pb, H, g, F, f, C, c, x, lam, max_it=8, lane_check=None, project_d=False):
     """The same iteration in the form the wave kernel can run (what DESIGN.md section 7 proposes), as a check that nothing
     but 2T x 2T Cholesky solves is needed.  Per guess:
       * d_t: fixed at the bound its tight row names; else eliminated through its own stationarity condition (needs a hinge
@@ -83,9 +83,18 @@ def active_set_solve_kernel_form(pb, H, g, F, f, C, c, x, lam, max_it=8, lane_ch
     nb, nr = 4 * T, 4 * (T - 1)
     dlo = max(pb.d_min, 0.0)
     prev = None
+    if project_d:                                   # (an interior-point iterate sits 1e-15 inside its bounds: snap)
+        x = x.copy(); dd = x[nu:]
+        dd = np.where(dd >= pb.d_max - 1e-8, pb.d_max, np.where(dd <= dlo + 1e-8, dlo, dd)); x[nu:] = dd
     for it in range(max_it + 1):
         on = (f - F @ x) > 0
         tight = (lam + (C @ x - c)) > 0
+        if project_d:                                   # what the kernel integration does: see the comment at the clip below
+            e0 = np.where(on, f - F @ x, 0.0)
+            resd = -(g[nu:] + ro * (e0.reshape(T, M).sum(1)))                  # -(d-gradient) = eta - ro sum e
+            for t in range(T):
+                tight[nb + nr + 2 * t] = (x[nu + t] >= pb.d_max) and resd[t] > 0
+                tight[nb + nr + 2 * t + 1] = (x[nu + t] <= dlo) and resd[t] < 0
         key = (on.tobytes(), tight.tobytes())
         if key == prev:
             return x, lam, it, True
@@ -98,7 +107,12 @@ def active_set_solve_kernel_form(pb, H, g, F, f, C, c, x, lam, max_it=8, lane_ch
         for t in range(T):
             up, lo = tight[nb + nr + 2 * t], tight[nb + nr + 2 * t + 1]
             I = np.where(on[t * M:(t + 1) * M])[0] + t * M
-            if up or lo or len(I) == 0:
+            if project_d and (up or lo or len(I) == 0):
+                dfix[t] = x[nu + t]                                           # fixed where it is (on the bound when a row is tight)
+                Fu = F[I][:, :nu]
+                K += ro * Fu.T @ Fu
+                r += ro * Fu.T @ (f[I] + dfix[t])
+            elif up or lo or len(I) == 0:
                 dfix[t] = pb.d_max if (up or len(I) == 0) else dlo          # (no hinge row on: -eta pushes d to its upper bound)
                 Fu = F[I][:, :nu]
                 K += ro * Fu.T @ Fu
@@ -156,6 +170,10 @@ def active_set_solve_kernel_form(pb, H, g, F, f, C, c, x, lam, max_it=8, lane_ch
                 xn[nu + t] = (pb.eta / ro - (f[I] - F[I][:, :nu] @ u).sum()) / len(I)
             else:
                 xn[nu + t] = dfix[t]
+        if project_d:
+            # the d of a free step is CLIPPED to its bounds after the solve (a projected step instead of the exact active-set move:
+            # a fixed d then never has to travel, which is what lets the kernel reuse its d-elimination unchanged)
+            xn[nu:] = np.clip(xn[nu:], dlo, pb.d_max)
         e = np.where(on, f - F @ xn, 0.0)
         res = -(H @ xn + g - ro * F.T @ e)                                     # = C' lam at a KKT point of the guess
         lamn = np.zeros(C.shape[0])
@@ -185,6 +203,18 @@ def active_set_solve_kernel_form(pb, H, g, F, f, C, c, x, lam, max_it=8, lane_ch
                     q = nb + 2 * (j - 2)
                     if tight[q]: lamn[q] = v
                     else: lamn[q + 1] = -v
+        if lane_check is not None:
+            tie = np.zeros(nu); bnd = np.zeros(nu)
+            for a in range(nu):
+                if a >= 2: tie[a] = 1.0 if tight[nb + 2 * (a - 2)] else (-1.0 if tight[nb + 2 * (a - 2) + 1] else 0.0)
+                bnd[a] = 1.0 if tight[2 * a] else (-1.0 if tight[2 * a + 1] else 0.0)
+            lt, lb = lane_level_multipliers(res[:nu], tie, bnd, nu)
+            ref_t = np.zeros(nu); ref_b = np.zeros(nu)
+            for a in range(nu):
+                if a >= 2: ref_t[a] = lamn[nb + 2 * (a - 2)] + lamn[nb + 2 * (a - 2) + 1] if tie[a] > 0 else (-(-lamn[nb + 2 * (a - 2) + 1]) if tie[a] < 0 else 0.0)
+                ref_b[a] = lamn[2 * a] if bnd[a] > 0 else (lamn[2 * a + 1] if bnd[a] < 0 else 0.0)
+            scl = 1.0 + np.abs(lamn).max()
+            lane_check.append(max(np.abs(lt - ref_t).max(), np.abs(lb - ref_b).max()) / scl)
         x, lam = xn, lamn
     return x, lam, max_it, False
 
@@ -253,6 +283,35 @@ def lane_level_reduction(K, r, tie, bnd, acc, spd, nu):
     return rows[:nu], rl[:nu], head[:nu], offvec[:nu], anchored[:nu]
 
 
+def lane_level_multipliers(res, tie, bnd, nu):
+    """Step D lane by lane: res (nu) = -(gradient of the objective without the tight rows) at the new point.  Returns the signed
+    multipliers (>= 0 at a correct guess) of the tie row INTO each variable and of the speed row at the anchoring member."""
+    lane = np.arange(NL)
+    live = lane < nu
+    tie_l = np.zeros(NL); tie_l[:nu] = tie
+    bnd_l = np.zeros(NL); bnd_l[:nu] = bnd
+    flag = (~live) | (tie_l == 0)
+    h = np.where(flag, lane, -1).astype(float)
+    for dist in (2, 4, 8, 16, 32):
+        fp = _bperm(flag.astype(float), lane - dist, 1.0) > 0; hp = _bperm(h, lane - dist, -1.0)
+        h = np.where(flag, h, hp); flag = flag | fp
+    head = h.astype(int)
+    winner = np.full(NL, 1 << 30)
+    for a in range(nu):
+        if bnd_l[a] != 0: winner[head[a]] = min(winner[head[a]], a)
+    mwin = _bperm(winner.astype(float), head, float(1 << 30)).astype(int)
+    anchored = live & (mwin < (1 << 30))
+    val = np.zeros(NL); val[:nu] = res
+    link = (_bperm((tie_l != 0).astype(float), lane + 2) > 0) & live
+    for dist in (2, 4, 8, 16, 32):
+        val, link = val + np.where(link, _bperm(val, lane + dist), 0.0), link & (_bperm(link.astype(float), lane + dist) > 0)
+    beta = np.where(anchored, _bperm(val, head), 0.0)
+    v = val - np.where(anchored & (mwin >= lane), beta, 0.0)
+    lam_tie = np.where(live & (tie_l != 0), tie_l * v, 0.0)
+    lam_bnd = np.where(anchored & (mwin == lane), bnd_l * beta, 0.0)
+    return lam_tie[:nu], lam_bnd[:nu]
+
+
 def gone_l(gone, nu):
     g = np.zeros(NL, bool); g[:nu] = gone
     return g
@@ -285,6 +344,7 @@ def job(arg):
         step = float(np.abs(u - prev_u).max()) if prev_u is not None else 9.0
         if prev is not None and prev["merit"] <= 1e-12 and prev["step"] < 0.1:          # the kernel's warm-start gate
             x, lam, fac, ok = active_set_solve(H, g, F, f, C, c, pb.ro_obs, prev["warm"][0].copy(), prev["warm"][1].copy())
+            xp, lp, facp, okp = active_set_solve_kernel_form(pb, H, g, F, f, C, c, prev["warm"][0].copy(), prev["warm"][1].copy(), project_d=True)
             lchk = []
             xk, lk, fack, okk = active_set_solve_kernel_form(pb, H, g, F, f, C, c, prev["warm"][0].copy(), prev["warm"][1].copy(), lane_check=lchk)
             sw, uw, dw, iw = ci.solve_condensed(pb, warm=prev["warm"])
@@ -295,7 +355,8 @@ def job(arg):
                              ipm_warm=iw["iters_total"], tight=int(((lam + (C @ x - c)) > 0).sum()), k=k,
                              kf_ok=okk, kf_fac=fack, kf_du=float(np.abs(xk[:nu] - x[:nu]).max()) if (ok and okk) else np.nan,
                              kf_dl=float(np.abs(lk - lam).max() / (1.0 + np.abs(lam).max())) if (ok and okk) else np.nan,
-                             lane=max(lchk) if lchk else 0.0, guesses=len(lchk)))
+                             lane=max(lchk) if lchk else 0.0, guesses=len(lchk),
+                             pj_ok=okp, pj_fac=facp, pj_du=float(np.abs(xp[:nu] - x_ref[:nu]).max()) if okp else np.nan))
         info["step"] = step
         prev, prev_u = info, u
     return name, len(pbs), rows
@@ -323,6 +384,9 @@ def main():
                      f"same guesses ({np.mean([r['kf_fac'] == r['fac'] for r in kf]) * 100:.0f} % with the same count), |u - u_exact| max {max(r['kf_du'] for r in kf):.1e}, multipliers of the tight rows within {max(r['kf_dl'] for r in kf):.1e} (relative)")
         lines.append(f"   lane-level form of the reduction (64-lane arrays, gathers and segmented scans: the docstring's steps A and B) against the matrix form, "
                      f"{sum(r['guesses'] for r in rows)} guesses: largest deviation {max(r['lane'] for r in rows):.1e}")
+        pj = [r for r in rows if r["pj_ok"]]
+        lines.append(f"   projected-d variant (d clipped after every solve, a d row tight iff d is on the bound and pushed outward): converged on {len(pj)}, "
+                     f"factorisations mean {np.mean([r['pj_fac'] for r in pj]):.2f}, |u - u_ipm| max {max(r['pj_du'] for r in pj):.1e}")
         bad = [r for r in rows if not r["ok"]]
         if bad:
             lines.append(f"   not converged in 8 guesses: {len(bad)} (warm interior-point iterations there: mean {np.mean([r['ipm_warm'] for r in bad]):.1f})")
