@@ -122,6 +122,10 @@ class Loop:
     timing events: every 4th (the events ride on the dispatches: recording two per launch doubles the host's time to enqueue
     a step)."""
 
+    STREAMS = {}           # device -> the process's chain streams, created once (every Loop of the process reuses them: a second
+                           # set of 20 live streams would push the process past the ~24 hardware queues the device schedules
+                           # without time-slicing, DESIGN.md section 4)
+
     def __init__(self, workload, batch, nfl, dev, rank=0, world=1, dist=None, env=None, graph=False, issue_threads=4,
                  scene_index=None):
         from neupan_amd.scenes import CONFIGS, make_batch
@@ -130,7 +134,10 @@ class Loop:
         self.workload, self.batch, self.nfl, self.dev, self.world = workload, batch, nfl, dev, world
         with environ(env):
             self.pans = [make_gpu_pan(cfg, device=dev) for _ in range(nfl)]
-        self.streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
+        pool = Loop.STREAMS.setdefault(str(dev), [])
+        while len(pool) < nfl:
+            pool.append(torch.cuda.Stream(device=dev))
+        self.streams = pool[:nfl]
         self.args = []
         for j in range(nfl):                    # batch j of this rank: its own scenes
             b = make_batch(cfg, (rank * nfl + j) * batch, batch)
@@ -249,20 +256,31 @@ def short_run(workload, batch, nfl, dev, steps, warmup, env=None, issue_threads=
     return out, lp
 
 
-def parity_leg(lp, scenes, cores, n_ulp=8, n_perm=4, sweep=False):
+_ENSEMBLES = {}
+
+
+def parity_leg(lp, scenes, cores, n_ulp=8, n_perm=4, sweep=False, explain=True):
     """The ensemble verdicts A / C / D of tests/parity_tools.py for the first `scenes` scenes of the loop's batch 0 (CPU oracle;
-    rank 0 only, untimed).  Returns (report, cpu rate, workers, hip deviations, spreads, trace)."""
+    rank 0 only, untimed).  Returns (report, cpu rate, workers, hip deviations, spreads, trace).  The oracle's ensemble of a
+    workload is computed once per process (two tiers of the same workload are judged against the same runs)."""
     from parity_tools import judge, one_step_consistency, one_step_report, run_ensemble
-    base, members, cpu_rate, ncore = run_ensemble(lp.workload, range(scenes), cores, n_ulp=n_ulp, n_perm=n_perm, sweep=sweep)
+    key = (lp.workload, scenes, n_ulp, n_perm)
+    if key not in _ENSEMBLES:
+        _ENSEMBLES[key] = run_ensemble(lp.workload, range(scenes), cores, n_ulp=n_ulp, n_perm=n_perm, sweep=sweep)
+    base, members, cpu_rate, ncore = _ENSEMBLES[key]
     pan = lp.pans[0]
     pan.reset_stop_state()
     tr = pan.forward_batch_trace(*lp.args[0])
     trace_u = tr["trace_u"].cpu().numpy()
     rep, hip, sp = judge(trace_u[:scenes], base, members)
     tp = tr["trace_pts"].cpu().numpy()[:scenes] if tr.get("trace_pts") is not None else None
-    dev, why = one_step_consistency(lp.workload, range(scenes), tr["trace_s"].cpu().numpy()[:scenes], trace_u[:scenes], cores,
-                                    explain=True, trace_pts=tp, trace_merit=tr["trace_qp_info"].cpu().numpy()[:scenes, :, 1])
-    rep["one_step"] = one_step_report(dev, why=why)
+    if explain:
+        dev, why = one_step_consistency(lp.workload, range(scenes), tr["trace_s"].cpu().numpy()[:scenes], trace_u[:scenes], cores,
+                                        explain=True, trace_pts=tp, trace_merit=tr["trace_qp_info"].cpu().numpy()[:scenes, :, 1])
+        rep["one_step"] = one_step_report(dev, why=why)
+    else:
+        rep["one_step"] = one_step_report(one_step_consistency(lp.workload, range(scenes), tr["trace_s"].cpu().numpy()[:scenes],
+                                                               trace_u[:scenes], cores))
     rep["well_posed_frac"] = round(float((sp[:, -1] <= 1e-4).mean()), 4)
     return rep, cpu_rate, ncore, hip, sp, tr
 
@@ -274,7 +292,9 @@ def slim(rep):
             "well_posed_frac")
     out = {k: rep[k] for k in keep if k in rep}
     os_ = rep.get("one_step", {})
-    out["one_step"] = {k: os_[k] for k in ("steps_checked", "max", "p99", "median", "frac_le_tol", "above_tol", "unexplained") if k in os_}
+    out["one_step"] = {k: os_[k] for k in ("steps_checked", "max", "p99", "median", "frac_le_tol", "unexplained", "explained_by") if k in os_}
+    if os_.get("above_tol"):
+        out["one_step"]["worst_above_tol"] = os_["above_tol"][:2]
     return out
 
 
@@ -293,7 +313,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="HIP-graph replay of a step's 21 launches for the planners that carry no "
                                                         "timing events (measured: SLOWER than eager launches with 20 chains in "
                                                         "flight, 513 k vs 656 k plans/s, DESIGN.md section 3.4; default: eager)")
-    ap.add_argument("--inflight", type=int, default=20, help="independent batches (steps) kept in flight, one stream each")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="independent batches (steps) kept in flight, one stream each (0 = 20; 18 with a process group unless the "
+                         "run is a single wave of <= 20 steps)")
     ap.add_argument("--issue-threads", type=int, default=4, help="host threads issuing the steps' launches (0: the main thread alone)")
     ap.add_argument("--workload", default=WORKLOAD,
                     choices=sorted(k for k in __import__("neupan_amd.scenes", fromlist=["CONFIGS"]).CONFIGS),
@@ -331,7 +353,13 @@ def main():
     cfg = CONFIGS[args.workload]
     B = args.batch
     T, K, N = cfg.T, cfg.iter_num, cfg.n_points
-    nfl = max(1, args.inflight)
+    # Chains in flight.  Every chain owns a HIP stream = a hardware queue; the device schedules ~24 of them per process without
+    # time-slicing.  RCCL brings three streams of its own and the gather a fourth: with 20 chains the process sits AT the limit
+    # and every few hundred steps one queue is evicted in mid-kernel for ~10 ms (kernel trace: one select_geo_kernel of 10.8 ms on
+    # one queue while the other 21 run on -- what rounds 2 and 3 reported as "the communicator's passive cost", 11 - 24 % of a
+    # 128-step run, gone with <= 18 chains or once the communicator is destroyed).  A run of <= 20 steps
+    # is ONE wave of chains: 20 chains finish it in one chain latency, 18 need two.
+    nfl = args.inflight if args.inflight > 0 else (20 if (dist is None or args.steps <= 20) else 18)
     lp = Loop(args.workload, B, nfl, dev, rank=rank, world=world, dist=None if os.environ.get("NPA_BENCH_NOGATHER") else dist,
               graph=args.graph, issue_threads=args.issue_threads)
     E = lp.pans[0].E
@@ -591,7 +619,12 @@ def main():
             if env:
                 res["env"] = env
             if with_cpu:
-                res["parity"] = slim(parity_leg(l2, 16, cores, n_ulp=4, n_perm=2)[0])
+                # (the bf16 tier is judged like the others -- it fails A / C / D by design, that is what its entry shows -- without
+                # the per-step explanations: a different selection through rounded distances needs none)
+                res["parity"] = slim(parity_leg(l2, 16, cores, n_ulp=4, n_perm=2, explain=not env)[0])
+                if env:
+                    res["parity"]["note"] = ("LABELLED reduced-precision tier: not the reference's arithmetic; the verdicts are "
+                                             "reported, not expected to hold")
             others[tag] = res
             l2.close()
         ex["other_configs"] = dict(others, note="BASELINE configs[2] (car, reverse gear on half the scenes), configs[3]'s per-GPU shape "

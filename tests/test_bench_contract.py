@@ -13,7 +13,7 @@ def _line(name):
 
 
 def test_default_bench_line_carries_every_contract_field():
-    d = _line("r03_bench.json")
+    d = _line("r04_bench.json")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -37,14 +37,39 @@ def test_default_bench_line_carries_every_contract_field():
     assert 0 < p["well_posed_frac"] <= 1 and p["well_posed_only"]["plans_per_s"] > 0
     assert d["margin_audit"]["violations"] == 0 and d["margin_audit"]["points"] > 0
     assert d["host_issue_ms_per_step"] <= 0.5 * d["ms_per_step"]
+    # round 4: the roofline is priced on interior-point iterations counted in the same run, every single-step deviation
+    # above the tolerance is explained, and the other paths / configurations ride in the driver's line
+    assert r["ipm_iterations_per_launch"] > 0 and "per_iteration" in r["flops_model"] and r["chip_aggregate"]["frac"] > r["frac"]
+    assert p["one_step"]["unexplained"] == 0
+    x = d["extra"]
+    assert {"exact_fp32_keys", "network_keys_1", "network_keys_3"} <= set(x["paths"])
+    for k, v in x["paths"].items():
+        if k != "note":
+            assert v["plans_per_s"] > 0 and 0 < v["dune_executed_mfma"]["frac"] < 1 and v["controls_equal_default_path"] and v["margin_violations"] == 0
+    u = x["uniform_cloud"]
+    assert u["plans_per_s"] > 0 and u["candidates_per_slice"]["share_overflow_to_exact_keys"] == 0 and u["parity"]["one_step"]["unexplained"] == 0
+    oc = {k: v for k, v in x["other_configs"].items() if isinstance(v, dict)}
+    assert len(oc) >= 4 and all(v["plans_per_s"] > 0 and v["margin_violations"] == 0 for v in oc.values())
+    exact = {k: v for k, v in oc.items() if "bf16" not in k}                  # the bf16 tier is labelled as NOT meeting parity
+    assert all(v["parity"]["one_step"]["unexplained"] == 0 and v["parity"]["A_well_posed_all_le_tol"] for v in exact.values())
+    assert any("bf16" in k and not v["parity"]["A_well_posed_all_le_tol"] for k, v in oc.items())
+
+
+def test_driver_flag_line_is_the_same_contract():
+    """What the round driver runs (--steps 20 --warmup 5): one wave of chains, lower by its issue ramp."""
+    d, full = _line("r04_bench_driver_flags.json"), _line("r04_bench.json")
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["metric"] == full["metric"] and d["config"]["workload"] == full["config"]["workload"]
+    assert 0.75 * full["value"] <= d["value"] <= full["value"]
+    t = _line("r04_bench_torchrun1.json")
+    assert t["n_gpus"] == 1 and t["value"] >= 0.9 * full["value"]          # one rank with a live RCCL communicator: within 10 %
 
 
 def test_tracked_pmc_file_matches_the_kernel_sources():
-    """bench.py prices the roofline with a kernel's record of profiles/r03_pmc.json only while the sources THAT kernel is
+    """bench.py prices the roofline with a kernel's record of profiles/r04_pmc.json only while the sources THAT kernel is
     built from are unchanged (bench.kernel_hash): an edit of the dominant kernel without a new counter run would silently
     drop `achieved` / `frac` from the line."""
     import bench
-    pj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))
+    pj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc.json")))
     k = pj["kernels"]["nrmp_qp_kernel"]
     assert k["source_hash"] == bench.kernel_hash("nrmp_qp_kernel")
     assert k["fp64_flops_per_launch"] > 0 and k["hbm_bytes_per_launch"] > 0 and 0 < k["valu_issue_frac"] < 1
