@@ -127,7 +127,14 @@ struct npa_handle {
   size_t n_dune = 0, n_sel = 0, n_qp = 0, n_aset = 0;
   double last_aset_ms = 0.0;             // average of the active-set launches seen by the last npa_profile_read
   long long last_aset_n = 0;
-  int aset_min_batch = 32;               // NPA_QP_ASET_MIN_BATCH: smallest batch that gets the extra active-set launch
+  int aset_min_batch = 32;               // NPA_QP_ASET_MIN_BATCH: smallest batch that gets the extra active-set launch when NPA_QP_ASET=1
+  // a call of very few scenes is bound by the LATENCY of its solves (one wave each, nothing else on the chip), not by wave
+  // slots; measured over 24 scenes one at a time (profiles/r04_latency_breakdown.txt) the active-set launch from PAN iteration
+  // 4 on takes 2.5 % off the mean and 9 % off the median of a single-scene call -- too little to put another code path on the
+  // default single-scene route, so the rule ships switched off: NPA_QP_ASET_SMALL=1 (largest batch it applies to) turns it on,
+  // NPA_QP_ASET_FROM moves its first iteration.
+  bool aset_auto = true, qp_generic = false;
+  int aset_small_batch = 0, aset_from_iter = 4;
 };
 
 extern "C" const char* npa_last_error(void) { return g_err.c_str(); }
@@ -387,6 +394,10 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
   h->sel_debug = getenv("NPA_SEL_DEBUG") != nullptr;
   h->qp_warm = getenv("NPA_QP_COLD") == nullptr;
   P.qp_aset = (getenv("NPA_QP_ASET") != nullptr && atoi(getenv("NPA_QP_ASET")) != 0) ? 1 : 0;
+  h->aset_auto = getenv("NPA_QP_ASET") == nullptr;
+  h->qp_generic = getenv("NPA_QP_GENERIC") != nullptr;
+  if (const char* env = getenv("NPA_QP_ASET_SMALL")) { int v = atoi(env); if (v >= 0) h->aset_small_batch = v; }
+  if (const char* env = getenv("NPA_QP_ASET_FROM")) { int v = atoi(env); if (v >= 1) h->aset_from_iter = v; }
   P.prio_sel = 0; P.prio_qp0 = 3; P.prio_qp1 = 3; P.prio_qp2 = 3; P.prio_it1 = 1 << 30; P.prio_it2 = 1 << 30;
   if (const char* env = getenv("NPA_PRIO")) {
     int v[6];
@@ -970,9 +981,13 @@ extern "C" int npa_forward_iter(npa_handle* h, int k) {
   // the active-set launch in front of the interior-point launch (nrmp_qp.hip, top of the kernel): scenes it finishes are skipped
   // by the launch behind it.  Register-resident T = 10 / M = 10 instantiation only; small batches keep the single launch (a
   // launch boundary costs ~10 us of a latency-bound chain: NPA_QP_ASET_MIN_BATCH, default 32)
-  if (P.qp_aset && h->qp_warm && P.T == 10 && P.M == 10 && batch >= h->aset_min_batch && !getenv("NPA_QP_GENERIC")) {
+  const bool aset_forced = P.qp_aset && batch >= h->aset_min_batch;
+  const bool aset_small = h->aset_auto && batch <= h->aset_small_batch && k >= h->aset_from_iter;
+  if ((aset_forced || aset_small) && h->qp_warm && P.T == 10 && P.M == 10 && !h->qp_generic) {
     EventPair* eva = next_event(h, h->ev_aset, h->n_aset);
-    HIP_TRY(npa_launch_qp(P, batch, 0, cur_s, cur_u, pc->ref_s, pc->ref_us, mu, lam, pts, dist, count, cur_s, cur_u,
+    DevParams Pa = P;
+    Pa.qp_aset = 1;
+    HIP_TRY(npa_launch_qp(Pa, batch, 0, cur_s, cur_u, pc->ref_s, pc->ref_us, mu, lam, pts, dist, count, cur_s, cur_u,
                           cur_d, pc->out_s, pc->out_u, pc->out_d, pc->out_md, pc->out_iters, pc->out_np, flags,
                           pc->state, qp_info, (double*)(ws + L.warm), pc->dune ? ws + L.trig : nullptr,
                           nullptr, nullptr, nullptr, stream, eva ? eva->a : nullptr, eva ? eva->b : nullptr, 1));

@@ -35,6 +35,7 @@
 #include <hip/hip_ext.h>
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -1060,6 +1061,29 @@ __device__ __forceinline__ unsigned key_pass(const DevParams& P, const SliceFram
 }
 
 #define SEL2_TRIP 256                            // points per trip of the key pass (4 per lane)
+// -DNPA_SEL_PROF: s_memtime stamps between the phases of a wave, summed over all waves in npa_sel_prof[] (slot 15 counts
+// the waves); tests/tools/select_phase_cycles.py builds that variant next to the product library and reads it back
+#ifdef NPA_SEL_PROF
+#define SELP_WAVES 4096
+__device__ unsigned long long npa_sel_prof[SELP_WAVES][16];     // one row per workgroup index: no atomics, nothing shared between waves
+extern "C" int npa_dbg_sel_prof(unsigned long long* out16, int reset) {
+  static unsigned long long host[SELP_WAVES][16];
+  if (out16) {
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(npa_sel_prof), sizeof(host)) != hipSuccess) return -1;
+    for (int i = 0; i < 16; ++i) { out16[i] = 0; for (int w = 0; w < SELP_WAVES; ++w) out16[i] += host[w][i]; }
+  }
+  if (reset) {
+    memset(host, 0, sizeof(host));
+    if (hipMemcpyToSymbol(HIP_SYMBOL(npa_sel_prof), host, sizeof(host)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#define SELP_DECL unsigned long long spt_ = __builtin_amdgcn_s_memtime(), sacc_[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long sp0_ = spt_
+#define SELP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); sacc_[i] += n_ - spt_; spt_ = n_; } while (0)
+#else
+#define SELP_DECL
+#define SELP(i)
+#endif
 template <int E, bool BF16 = false>
 __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(E <= 6 ? 4 : 3, E <= 6 ? 4 : 3))) void select_geo_kernel(
     DevParams P, const float* __restrict__ wpack, int n_stride, const float* __restrict__ cur_s,
@@ -1080,6 +1104,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
   float* rows = reinterpret_cast<float*>(dkey);               // [SEL_CAP][ROW_W] (takes over the key area once sel[] stands)
   unsigned* rkey = reinterpret_cast<unsigned*>(rows + SEL_CAP * (NPA_MAX_E + 5));   // [SEL_CAP][2]: (index, exact key)
   const int lane = threadIdx.x, j = lane & 31, hf = lane >> 5;
+  SELP_DECL;
   // workgroup w runs on XCD w % 8 (observed dispatch order; a speed assumption only): scene = 8 * (w / (8 nsl)) + w % 8
   const int w = blockIdx.x, xcd = w & 7, r_ = w >> 3;
   const int bl = (r_ / nsl) * 8 + xcd;
@@ -1096,18 +1121,35 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
     if (lane == 0) count[orow] = 0;
     return;
   }
-  for (int i = lane; i < 11 * 32 + 8 * 32 + 8; i += 64) smem[i] = wpack[WP_VEC + i];
-  for (int i = lane; i < NPA_GEO_BANDS; i += 64) etab[i] = wpack[WP_GEO + i] * margin_scale;
+  // the preamble's loads as ONE batch (written as loops they compiled to a load -> wait -> LDS write per trip: twelve global
+  // round trips in series, 18 % of a wave's life -- profiles/r04_select_phase_cycles.txt)
+  constexpr int NVEC = 11 * 32 + 8 * 32 + 8, NVT = (NVEC + 63) / 64, NGT = (NPA_GEO_BANDS + 63) / 64;
+  float pre_v[NVT], pre_g[NGT];
+#pragma unroll
+  for (int i = 0; i < NVT; ++i) { const int k = lane + 64 * i; pre_v[i] = wpack[WP_VEC + (k < NVEC ? k : NVEC - 1)]; }
+#pragma unroll
+  for (int i = 0; i < NGT; ++i) { const int k = lane + 64 * i; pre_g[i] = wpack[WP_GEO + (k < NPA_GEO_BANDS ? k : NPA_GEO_BANDS - 1)]; }
+  unsigned aud_viol = 0, aud_launches = 0;
+  if (audit) {
+    aud_viol = __hip_atomic_load(audit + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    aud_launches = __hip_atomic_load(audit + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  const float w1 = wpack[WP_W1 + lane];
   SliceFrame F;
   load_frame<E>(P, cur_s, trig, b, t, F);
+#pragma unroll
+  for (int i = 0; i < NVT; ++i) { const int k = lane + 64 * i; if (k < NVEC) smem[k] = pre_v[i]; }
+#pragma unroll
+  for (int i = 0; i < NGT; ++i) { const int k = lane + 64 * i; if (k < NPA_GEO_BANDS) etab[k] = pre_g[i] * margin_scale; }
   const float* px_row = points + (size_t)b * 2 * n_stride;
   const float* py_row = px_row + n_stride;
   const float* vx_row = vel ? vel + (size_t)b * 2 * n_stride : nullptr;
   const float* vy_row = vel ? vx_row + n_stride : nullptr;
   const bool has_vel = vel != nullptr, decim = n_use < n_raw;
   // a violation seen by an earlier launch (or an earlier wave of this one): everything is a candidate from here on
-  const bool distrust = audit && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(audit + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0;
+  const bool distrust = audit && __builtin_amdgcn_readfirstlane((int)aud_viol) != 0;
   const unsigned far_thr = __float_as_uint(P.geo_far);
+  SELP(0);
 
   // ---- key pass: dkey[n] = bits of g(point n) (0xFFFFFFFF behind the slice's end), lane minimum on the way ----------
   const int n_pad = (n_use + SEL2_TRIP - 1) & ~(SEL2_TRIP - 1);
@@ -1121,9 +1163,9 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
     else { if (decim) KP(false, false, true); else KP(false, false, false); }
   }
 #undef KP
-  const float w1 = wpack[WP_W1 + lane];
   const float* wls = wpack + (BF16 ? WP_WB16 : WP_WLS);
   WSYNC();
+  SELP(1);
 
   const int msel = n_use < M ? n_use : M;
   // msel-th smallest of the 64 lane minima: an upper bound of the msel-th smallest key (each of those lanes holds a key
@@ -1158,6 +1200,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
     gs = wave_max_f32(gs);
     thr = gs < 3.0e38f ? __float_as_uint(gs) : 0xFFFFFFFEu;
   }
+  SELP(2);
   // ---- window pass: indices of the candidates, compacted IN PLACE over the keys already scanned ----------------------
   int ntot = 0;
   for (int n0 = 0; n0 < n_pad; n0 += SEL2_TRIP) {
@@ -1175,6 +1218,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
     }
   }
   WSYNC();
+  SELP(3);
   int ncand = ntot, fellback = 0;
   bool overflow = false, all = false;
   int total = 0;
@@ -1210,7 +1254,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
   // carries a frozen host number, and should still audit other waves and other points each time
   bool audit_wave = false;
   if (audit && audit_thresh) {
-    audit_seed += (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(audit + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    audit_seed += (unsigned)__builtin_amdgcn_readfirstlane((int)aud_launches);
     if (blockIdx.x == 0 && lane == 0) atomicAdd(audit + 4, 1u);
     unsigned hsh = (audit_seed * 0x9E3779B1u) ^ ((unsigned)b * 0x85EBCA77u) ^ ((unsigned)t * 0xC2B2AE3Du);
     hsh ^= hsh >> 15; hsh *= 0x2C1B3C6Du; hsh ^= hsh >> 12; hsh *= 0x297A2D39u; hsh ^= hsh >> 15;
@@ -1221,6 +1265,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
   // over the slice, bound check only.  ONE call site of the encoder for all three.
   int viol = 0;
   float worst = 0.f;
+  SELP(4);
 #pragma unroll 1
   for (int stage = overflow ? 0 : 1;;) {
     const int cnt = stage == 0 ? total : (stage == 1 ? ncand : (n_use < 32 ? n_use : 32));
@@ -1260,6 +1305,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
       }
     }
     WSYNC();
+    if (stage == 0) SELP(5); else if (stage == 1) SELP(6); else SELP(7);     // exact keys of a long list / the candidates' rows / audit tile
     if (stage == 2) break;
     if (stage == 1) {
       // lane q speaks for candidate q: rank on the exact (distance, index) key, emit; rows >= msel replicate row 0
@@ -1282,6 +1328,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
           for (int q = msel; q < M; ++q) put(q);
       }
       if (lane == 0) count[orow] = debug ? (msel | ((ntot < 255 ? ntot : 255) << 8) | (fellback << 16)) : msel;
+      SELP(8);
       if (!audit_wave) break;
       stage = 2;
       continue;
@@ -1309,6 +1356,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
     }
     ncand = msel;
     stage = 1;
+    SELP(9);
   }
   if (audit) {
     const unsigned long long vb = __ballot(viol > 0);
@@ -1326,6 +1374,16 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
     }
     if (audit_wave && lane == 0) { atomicAdd(audit + 0, 1u); atomicAdd(audit + 1, (unsigned)(n_use < 32 ? n_use : 32)); }
   }
+  SELP(10);
+#ifdef NPA_SEL_PROF
+  if (lane == 0 && blockIdx.x < SELP_WAVES) {
+    unsigned long long* row = npa_sel_prof[blockIdx.x];
+    row[15] += 1ull;
+    row[14] += (unsigned long long)__builtin_amdgcn_s_memtime() - sp0_;
+#pragma unroll
+    for (int i = 0; i < 11; ++i) row[i] += sacc_[i];
+  }
+#endif
 }
 
 // ---- host-side launchers (called from c_api.hip) --------------------------------------------------

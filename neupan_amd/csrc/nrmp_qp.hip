@@ -588,13 +588,20 @@ void nrmp_qp_kernel(
     int t = i / M, j = i - t * M;
     size_t row = ((size_t)b * (T + 1) + (t + 1)) * M + j;
     double a0 = 0, a1 = 0, fb = 0;
-    if (count[(size_t)b * (T + 1) + t + 1] > 0) {
-      float l0 = lam_sorted[row * 2], l1 = lam_sorted[row * 2 + 1];
-      float tmp = fmaf(l1, pts_sorted[row * 2 + 1], __fmul_rn(l0, pts_sorted[row * 2]));
+    // every load of the row up front and unconditional (the buffers hold a slot for every (scene, slice, j); a slice without
+    // points leaves stale contents there, selected away below): written as `if (count > 0) { ... if (e < E) load }` this was a
+    // chain of 2 + E global round trips per row, most of the set-up phase's time
+    const int cnt_t = count[(size_t)b * (T + 1) + t + 1];
+    const float l0 = lam_sorted[row * 2], l1 = lam_sorted[row * 2 + 1];
+    const float px = pts_sorted[row * 2], py = pts_sorted[row * 2 + 1];
+    float muv[NPA_MAX_E];
+#pragma unroll
+    for (int e = 0; e < NPA_MAX_E; ++e) muv[e] = mu_sorted[row * E + (e < E ? e : 0)];
+    if (cnt_t > 0) {
+      float tmp = fmaf(l1, py, __fmul_rn(l0, px));
       float mh = 0.f;
 #pragma unroll
-      for (int e = 0; e < NPA_MAX_E; ++e)
-        if (e < E) mh = fmaf(mu_sorted[row * E + e], P.h[e], mh);
+      for (int e = 0; e < NPA_MAX_E; ++e) mh = e < E ? fmaf(muv[e], P.h[e], mh) : mh;
       a0 = l0; a1 = l1; fb = (double)__fadd_rn(tmp, mh);
     }
     fa0[i] = a0; fa1[i] = a1;
@@ -1860,8 +1867,16 @@ void nrmp_qp_kernel(
           int t = q / eff, j = q - t * eff;
           size_t row = ((size_t)b * (T + 1) + t) * M + j;
           size_t prow = (size_t)t * M + j;
-          for (int e = 0; e < E; ++e) { double d = (double)mu_sorted[row * E + e] - (double)pmu[prow * E + e]; acc_mu += d * d; }
-          for (int k = 0; k < 2; ++k) { double d = (double)lam_sorted[row * 2 + k] - (double)plam[prow * 2 + k]; acc_lam += d * d; }
+          // (loads first, unconditional: a run-time trip count made every one of them a round trip of its own)
+          float mn[NPA_MAX_E], mo[NPA_MAX_E], ln[2], lo[2];
+#pragma unroll
+          for (int e = 0; e < NPA_MAX_E; ++e) { const int ee = e < E ? e : 0; mn[e] = mu_sorted[row * E + ee]; mo[e] = pmu[prow * E + ee]; }
+#pragma unroll
+          for (int k = 0; k < 2; ++k) { ln[k] = lam_sorted[row * 2 + k]; lo[k] = plam[prow * 2 + k]; }
+#pragma unroll
+          for (int e = 0; e < NPA_MAX_E; ++e) { const double d = (double)mn[e] - (double)mo[e]; acc_mu = e < E ? fma(d, d, acc_mu) : acc_mu; }
+#pragma unroll
+          for (int k = 0; k < 2; ++k) { const double d = (double)ln[k] - (double)lo[k]; acc_lam = fma(d, d, acc_lam); }      // (fused, as the compiler contracted the loop form)
         }
       }
     }
@@ -1873,8 +1888,13 @@ void nrmp_qp_kernel(
     if (have)
       for (int q = lane; q < (T + 1) * M; q += QP_THREADS) {
         size_t row = (size_t)b * (T + 1) * M + q;
-        for (int e = 0; e < E; ++e) pmu[(size_t)q * E + e] = mu_sorted[row * E + e];
-        plam[(size_t)q * 2] = lam_sorted[row * 2]; plam[(size_t)q * 2 + 1] = lam_sorted[row * 2 + 1];
+        float mn[NPA_MAX_E];
+#pragma unroll
+        for (int e = 0; e < NPA_MAX_E; ++e) mn[e] = mu_sorted[row * E + (e < E ? e : 0)];
+        const float ln0 = lam_sorted[row * 2], ln1 = lam_sorted[row * 2 + 1];
+#pragma unroll
+        for (int e = 0; e < NPA_MAX_E; ++e) if (e < E) pmu[(size_t)q * E + e] = mn[e];
+        plam[(size_t)q * 2] = ln0; plam[(size_t)q * 2 + 1] = ln1;
       }
     if (lane == 0) {
       pint[0] = 1;
