@@ -46,6 +46,7 @@ import torch  # noqa: E402
 
 WORKLOAD = "diff_1k_T10_K10"
 BATCH = 256
+BURST_DEFAULT = 0
 # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table (256 CUs x 4 SIMDs, 2.4 GHz)
 PEAK_FP64_VALU_TFLOPS = 78.6
 PEAK_FP32_MFMA_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32: what the exact encoder runs on
@@ -126,6 +127,8 @@ class Loop:
                            # set of 20 live streams would push the process past the ~24 hardware queues the device schedules
                            # without time-slicing)
 
+    BURST = False          # StepLoop(burst=...): set once from the command line, every Loop of the process follows it
+
     def __init__(self, workload, batch, nfl, dev, rank=0, world=1, dist=None, env=None, graph=False, issue_threads=4,
                  scene_index=None):
         from neupan_amd.scenes import CONFIGS, make_batch
@@ -158,7 +161,7 @@ class Loop:
                 self.steps.append(self.pans[j].make_step(*self.args[j], reset_every_step=True,
                                                           graph=(graph and j not in self.timed_idx)))
         torch.cuda.synchronize(dev)
-        self.loop = StepLoop(self.steps, self.streams, self.gatherer, self.cur, threads=issue_threads)
+        self.loop = StepLoop(self.steps, self.streams, self.gatherer, self.cur, threads=issue_threads, burst=Loop.BURST)
 
     def run(self, n):
         return self.loop.run(n)
@@ -317,6 +320,9 @@ def main():
                     help="independent batches (steps) kept in flight, one stream each (0 = 20; 18 with a process group unless the "
                          "run is a single wave of <= 20 steps)")
     ap.add_argument("--issue-threads", type=int, default=4, help="host threads issuing the steps' launches (0: the main thread alone)")
+    ap.add_argument("--burst", type=int, default=BURST_DEFAULT,
+                    help="1: the steps a host thread issues in one round of the chains go out as ONE breadth-first library call "
+                         "(npa_forward_batch_group: staging of every chain, then PAN iteration 0 of every chain, ...); 0: call by call")
     ap.add_argument("--workload", default=WORKLOAD,
                     choices=sorted(k for k in __import__("neupan_amd.scenes", fromlist=["CONFIGS"]).CONFIGS),
                     help="scene configuration (default: the one BASELINE.json's metric is quoted on)")
@@ -360,6 +366,7 @@ def main():
     # 128-step run, gone with <= 18 chains or once the communicator is destroyed).  A run of <= 20 steps
     # is ONE wave of chains: 20 chains finish it in one chain latency, 18 need two.
     nfl = args.inflight if args.inflight > 0 else (20 if (dist is None or args.steps <= 20) else 18)
+    Loop.BURST = bool(args.burst)
     lp = Loop(args.workload, B, nfl, dev, rank=rank, world=world, dist=None if os.environ.get("NPA_BENCH_NOGATHER") else dist,
               graph=args.graph, issue_threads=args.issue_threads)
     E = lp.pans[0].E
@@ -465,7 +472,9 @@ def main():
                                        if os.environ.get("NPA_ROWS_PRECISION") == "bf16" else ""),
                    "scenes_per_gpu": B, "points": N, "T": T, "K": K, "M": cfg.nrmp_max_num,
                    "batches_in_flight": nfl, "schedule": "one HIP stream per batch in flight, one prepared library call per step "
-                                                        "(PAN.make_step), " + ("eager launches" if not args.graph else
+                                                        "(PAN.make_step), " + ("the chains of a round issued breadth-first "
+                                                        "(npa_forward_batch_group), " if lp.loop.groups is not None else "") +
+                                                        ("eager launches" if not args.graph else
                                                         "HIP-graph replay except on the planners that carry timing events") +
                                                         ", gathers on one communication stream",
                    "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "numa_node": numa, "issue_threads": lp.loop.threads,

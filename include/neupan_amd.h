@@ -211,6 +211,30 @@ int npa_forward_begin(npa_handle *h, int batch, int n_stride,
 int npa_forward_iter(npa_handle *h, int k);
 int npa_forward_end(npa_handle *h);
 
+/* A burst of n INDEPENDENT forward calls -- n planners of the reference (one PAN.forward each, pan.py:109-147), one handle, one
+ * stream and one argument set per call -- enqueued BREADTH-FIRST: the staging launch of every call, then PAN iteration 0 of
+ * every call, then iteration 1, ...  The launches and the results are those of n npa_forward_batch_flags calls in a row;
+ * what changes is the order in which the host enqueues them: issued call by call, the last of 20 chains starts ~1.8 ms
+ * after the first (420 launches later) and a short burst is mostly that ramp; issued breadth-first every chain is running
+ * after the first 2 n launches.  The handles must be distinct (a handle plans one batch at a time).  iter_num = PAN iterations
+ * of that call, 1 .. the handle's iter_num (the reference's PAN.iter_num is an attribute its callers may lower between
+ * calls).  On an error the calls already begun are ended and the error is returned; work enqueued before it stays enqueued. */
+typedef struct npa_forward_call {
+  npa_handle *h;
+  int32_t batch, n_stride, iter_num;
+  const float *nom_s, *nom_u, *ref_s, *ref_us, *points, *velocities;
+  const int32_t *n_points;
+  float *out_s, *out_u, *out_d, *out_min_distance;
+  int32_t *out_iters;
+  float *out_nrmp_points;
+  void *workspace;
+  size_t workspace_bytes;
+  void *state;
+  size_t state_bytes;
+  void *stream;
+} npa_forward_call;
+int npa_forward_batch_group(int n, const npa_forward_call *calls, int flags);
+
 /* Stage entry points (used by the parity tests and for profiling one stage alone).
  * npa_dune_stage  = generate_point_flow + DUNE.forward + the top-M gather:
  *   mu_sorted [B][T+1][M][E], lam_sorted [B][T+1][M][2], pts_sorted [B][T+1][M][2],

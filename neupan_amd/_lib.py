@@ -29,6 +29,15 @@ class NpaConfig(C.Structure):
     ]
 
 
+class NpaForwardCall(C.Structure):
+    """npa_forward_call (include/neupan_amd.h): one call of a breadth-first burst, npa_forward_batch_group."""
+    _fields_ = [("h", C.c_void_p), ("batch", C.c_int32), ("n_stride", C.c_int32), ("iter_num", C.c_int32)] + \
+               [(k, C.c_void_p) for k in ("nom_s", "nom_u", "ref_s", "ref_us", "points", "velocities", "n_points", "out_s", "out_u",
+                                          "out_d", "out_min_distance", "out_iters", "out_nrmp_points")] + \
+               [("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("state", C.c_void_p), ("state_bytes", C.c_size_t),
+                ("stream", C.c_void_p)]
+
+
 class NpaDuneWeights(C.Structure):
     _fields_ = [("lin_w", C.c_void_p * 6), ("lin_b", C.c_void_p * 6), ("ln_w", C.c_void_p * 3), ("ln_b", C.c_void_p * 3)]
 
@@ -54,6 +63,7 @@ SYMBOLS = {
     "npa_forward_batch_flags": (_I, [_P, _I, _I] + [_P] * 13 + [_P, _SZ, _P, _SZ, _P, _I]),
     "npa_forward_iter": (_I, [_P, _I]),
     "npa_forward_end": (_I, [_P]),
+    "npa_forward_batch_group": (_I, [_I, C.POINTER(NpaForwardCall), _I]),
     "npa_dune_stage": (_I, [_P, _I, _I] + [_P] * 9 + [_P]),
     "npa_nrmp_stage": (_I, [_P, _I] + [_P] * 13 + [_P]),
     "npa_nrmp_params": (_I, [_P, _I] + [_P] * 8 + [_P]),

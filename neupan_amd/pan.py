@@ -474,7 +474,14 @@ class PAN(torch.nn.Module):
             self._last = last
             self.last_out = out
             return out
+
+        def finish():
+            self._last = last
+            self.last_out = out
+            return out
         step.device_index = idx
+        # what StepGroup needs to issue this step inside a breadth-first burst (npa_forward_batch_group)
+        step.group_call = dict(args=args, flags=flags, iter_num=self.iter_num, validate=validate, finish=finish, device=dev, lib=lib)
         return step
 
     def forward_batch_trace(self, nom_s, nom_u, ref_s, ref_us, points=None, velocities=None, n_points=None):
@@ -830,3 +837,38 @@ def forward_interleaved(planners, inputs, reset_state=False):
             if isinstance(t, torch.Tensor):
                 t.record_stream(cur)
     return outs
+
+
+class StepGroup:
+    """Steps prepared by PAN.make_step (one planner, one stream each), issued as ONE breadth-first library call
+    (npa_forward_batch_group, include/neupan_amd.h): the staging launch of every step, then PAN iteration 0 of every
+    step, ...  The launches and the results are those of calling the steps one after the other; every chain of the burst
+    is running after the first 2 n launches instead of after 21 (n - 1).  `streams[i]` is the stream of steps[i].
+    issue(n) enqueues the first n members (default: all) and returns their output dicts."""
+
+    def __init__(self, steps, streams):
+        from ._lib import NpaForwardCall
+        calls = [getattr(s, "group_call", None) for s in steps]
+        if any(c is None for c in calls):
+            raise NeupanAmdError("StepGroup: every member must be a plain (non-graph) step of PAN.make_step")
+        if len({c["flags"] for c in calls}) != 1 or len({str(c["device"]) for c in calls}) != 1:
+            raise NeupanAmdError("StepGroup: the members must share the reset flag and the device")
+        self.calls, self.flags, self.lib, self.device = calls, calls[0]["flags"], calls[0]["lib"], calls[0]["device"]
+        self.arr = (NpaForwardCall * len(steps))()
+        names = [f[0] for f in NpaForwardCall._fields_]
+        for a, c, st in zip(self.arr, calls, streams):
+            h, B, n_stride, *rest = c["args"]
+            vals = [h, B, n_stride, c["iter_num"], *rest, C.c_void_p(st.cuda_stream)]
+            assert len(vals) == len(names)
+            for k, v in zip(names, vals):
+                setattr(a, k, v.value if isinstance(v, C.c_void_p) else v)
+
+    def issue(self, n=None):
+        n = len(self.calls) if n is None else n
+        for c in self.calls[:n]:
+            c["validate"]()
+        with torch.cuda.device(self.device):
+            rc = self.lib.npa_forward_batch_group(n, self.arr, self.flags)
+        if rc:
+            check(rc, "npa_forward_batch_group")
+        return [c["finish"]() for c in self.calls[:n]]

@@ -187,11 +187,27 @@ class StepLoop:
     releases the GIL, so the launches of different planners proceed in parallel.  threads = 0: plain run_steps.
     streams=None (CPU stand-in planners, tests): the same threading without streams."""
 
-    def __init__(self, steps, streams, gatherer=None, cur=None, threads=0):
+    def __init__(self, steps, streams, gatherer=None, cur=None, threads=0, burst=False, group_cls=None):
         import queue
         self.steps, self.streams, self.gatherer, self.cur = steps, streams, gatherer, cur
         self.nfl = len(steps)
         self.threads = min(int(threads), self.nfl)
+        # burst: the steps a thread issues in one round of the slots go out as ONE breadth-first library call
+        # (neupan_amd.pan.StepGroup -> npa_forward_batch_group): every chain of the round starts within the first two launches
+        # per chain instead of behind the 21 launches of each chain in front of it.  Steps that cannot be grouped (HIP-graph
+        # steps, stand-ins without a group class) keep the call-by-call order.
+        self.groups = None
+        if burst:
+            try:
+                if group_cls is None:
+                    from .pan import StepGroup as group_cls
+                nw = max(self.threads, 1)
+                self.groups = []
+                for w in range(nw):
+                    own = [j for j in range(self.nfl) if j % nw == w]
+                    self.groups.append(group_cls([steps[j] for j in own], [streams[j] for j in own] if streams is not None else None))
+            except Exception:
+                self.groups = None
         self._q = [queue.Queue() for _ in range(self.threads)]
         self._workers = []
         self._err = None
@@ -213,6 +229,35 @@ class StepLoop:
                 self.gatherer.stage(base + i, o["opt_u"])
         return o
 
+    def _issue_rounds(self, w, nw, n, base, outs, evs):
+        """Thread w's share of n steps, round by round: its slots' steps of a round as one breadth-first group call, their
+        controls staged behind them in step order."""
+        for r0 in range(0, n, self.nfl):
+            mine = [i for i in range(r0, min(n, r0 + self.nfl)) if (i % self.nfl) % nw == w]
+            if not mine:
+                continue
+            res = self.groups[w].issue(len(mine))           # (a thread's slots of a round are a prefix of its slot list)
+            for i, o in zip(mine, res):
+                if self.gatherer is not None:
+                    if self.streams is not None:
+                        self.gatherer.stage(base + i, o["opt_u"], self.streams[i % self.nfl])
+                    else:
+                        self.gatherer.stage(base + i, o["opt_u"])
+                outs[i] = o
+                if evs is not None:
+                    evs[i].set()
+
+    def _issue_rounds_one(self, r0, n, base, outs):
+        mine = list(range(r0, min(n, r0 + self.nfl)))
+        res = self.groups[0].issue(len(mine))
+        for i, o in zip(mine, res):
+            if self.gatherer is not None:
+                if self.streams is not None:
+                    self.gatherer.stage(base + i, o["opt_u"], self.streams[i % self.nfl])
+                else:
+                    self.gatherer.stage(base + i, o["opt_u"])
+            outs[i] = o
+
     def _work(self, w):
         while True:
             cmd = self._q[w].get()
@@ -220,6 +265,9 @@ class StepLoop:
                 return
             n, base, outs, evs = cmd
             try:
+                if self.groups is not None:
+                    self._issue_rounds(w, self.threads, n, base, outs, evs)
+                    continue
                 for i in range(n):
                     if (i % self.nfl) % self.threads != w:
                         continue
@@ -231,8 +279,27 @@ class StepLoop:
                     ev.set()
 
     def run(self, n):
-        if self.threads == 0:
+        if self.threads == 0 and self.groups is None:
             return run_steps(n, self.steps, self.streams, self.gatherer, self.cur)
+        if self.threads == 0:                       # the calling thread alone, round by round
+            last = [None] * self.nfl
+            base = self.gatherer.begin(n) if self.gatherer is not None else 0
+            if self.streams is not None:
+                for st in self.streams:
+                    st.wait_stream(self.cur)
+            outs = [None] * n
+            for r0 in range(0, n, self.nfl):
+                self._issue_rounds_one(r0, n, base, outs)
+                for i in range(r0, min(n, r0 + self.nfl)):
+                    o = outs[i]
+                    g = self.gatherer.collect(base + i, o["opt_u"]) if self.gatherer is not None else o["opt_u"]
+                    last[i % self.nfl] = (o, g)
+            if self.streams is not None:
+                for st in self.streams:
+                    self.cur.wait_stream(st)
+            if self.gatherer is not None:
+                self.gatherer.join(self.cur)
+            return last
         last = [None] * self.nfl
         base = self.gatherer.begin(n) if self.gatherer is not None else 0
         if self.streams is not None:

@@ -47,6 +47,37 @@ def test_config_struct_layout_matches_header():
         assert re.search(rf"#define {name} {val}\b", hdr)
 
 
+def test_forward_call_struct_layout_matches_header(tmp_path):
+    """npa_forward_call as gcc lays the header's struct out against the ctypes mirror: size and every field offset."""
+    import shutil
+    import subprocess
+    from neupan_amd._lib import NpaForwardCall
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    names = [f[0] for f in NpaForwardCall._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "neupan_amd.h"\nint main(void) {\n  printf("%zu", sizeof(npa_forward_call));\n' +
+                   "".join(f'  printf(" %zu", offsetof(npa_forward_call, {n}));\n' for n in names) + "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert got[0] == C.sizeof(NpaForwardCall)
+    assert got[1:] == [getattr(NpaForwardCall, n).offset for n in names]
+
+
+def test_group_call_argument_validation_without_gpu(lib):
+    from neupan_amd._lib import NpaForwardCall
+    arr = (NpaForwardCall * 2)()
+    assert lib.npa_forward_batch_group(0, arr, 0) == -1 and lib.npa_forward_batch_group(2, None, 0) == -1
+    assert lib.npa_forward_batch_group(2, arr, 0) == -1            # null handles
+    arr[0].h = arr[1].h = 0x1000
+    arr[0].iter_num = arr[1].iter_num = 1
+    assert lib.npa_forward_batch_group(2, arr, 0) == -1            # the same handle twice (refused before anything is touched)
+    arr[1].h = 0x2000
+    arr[1].iter_num = 0
+    assert lib.npa_forward_batch_group(2, arr, 0) == -1            # iter_num < 1
+
+
 def test_argument_validation_without_gpu(lib):
     from neupan_amd._lib import NpaConfig
     h = C.c_void_p()

@@ -90,7 +90,7 @@ def _value(rank, i):
     return float(10000 * rank + i)
 
 
-def _loop_worker(rank, world, port, inflight, runs, threads, q):
+def _loop_worker(rank, world, port, inflight, runs, threads, q, burst=False):
     """The serving loop (neupan_amd.serve: StepLoop / run_steps + ControlGatherer) with stand-in planners on CPU tensors over
     gloo: the SAME coalesced protocol the GPU runs (staging rows, alternating buffers, flush order, trailing partial group,
     consecutive runs on one gatherer), `threads` issuing threads per rank, and uneven progress: rank 1's planners sleep,
@@ -123,7 +123,18 @@ def _loop_worker(rank, world, port, inflight, runs, threads, q):
             snaps.append((g, rows, self.out[g & 1][:, :, 0, 0, 0].clone()))       # (world, slots): first element of every row
 
     g = Recording(dist, world, device=None, slots=inflight, shape=(B, 2, T))
-    loop = StepLoop([make(j) for j in range(inflight)], None, g, None, threads=threads)
+    class Group:                                   # stand-in of neupan_amd.pan.StepGroup: the first n members, one library call
+        calls = 0
+
+        def __init__(self, steps, streams):
+            self.steps = steps
+
+        def issue(self, n=None):
+            Group.calls += 1
+            return [s() for s in self.steps[:len(self.steps) if n is None else n]]
+
+    loop = StepLoop([make(j) for j in range(inflight)], None, g, None, threads=threads, burst=burst, group_cls=Group)
+    assert (loop.groups is not None) == bool(burst)
     report = []
     for n in runs:
         base = g._next
@@ -140,21 +151,29 @@ def _loop_worker(rank, world, port, inflight, runs, threads, q):
             rows.append((o["index"], tuple(gathered.shape), [float(gathered[r, 0, 0, 0]) for r in range(world)]))
         report.append((base, rows))
     loop.close()
+    if burst:                                      # one group call per (thread, round) that has a step of that thread
+        nw = max(min(threads, inflight), 1)
+        want = sum(sum(1 for w in range(nw) if any((i % inflight) % nw == w for i in range(r0, min(n, r0 + inflight))))
+                   for n in runs for r0 in range(0, n, inflight))
+        assert Group.calls == want, (Group.calls, want)
     q.put((rank, report, [(gg, rows, t.tolist()) for gg, rows, t in snaps], g.issued, g.collectives))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("inflight,runs,threads", [(1, (3,), 0), (4, (10,), 0), (5, (3,), 0), (5, (3, 12, 23), 3), (4, (9, 2, 8), 2)])
-def test_serving_loop_with_two_ranks(inflight, runs, threads):
+@pytest.mark.parametrize("inflight,runs,threads,burst", [(1, (3,), 0, False), (4, (10,), 0, False), (5, (3,), 0, False),
+                                                         (5, (3, 12, 23), 3, False), (4, (9, 2, 8), 2, False),
+                                                         (4, (10, 3), 0, True), (5, (3, 12, 23), 3, True), (6, (4, 20), 2, True)])
+def test_serving_loop_with_two_ranks(inflight, runs, threads, burst):
     """Two ranks over gloo drive the coalesced gather exactly as the GPU loop does: every group's collective carries the
     controls of the SAME steps from both ranks, in rank order; one collective per `inflight` steps plus one per trailing
     partial group; no deadlock with several issuing threads, fewer steps than slots, or a slow rank; consecutive runs on
-    one gatherer start on fresh groups."""
+    one gatherer start on fresh groups.  burst: the steps a thread issues in one round of the slots go out as one group call
+    (StepLoop(burst=True), the breadth-first issue of npa_forward_batch_group) -- same collectives, same contents."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_loop_worker, args=(r, 2, port, inflight, runs, threads, q)) for r in range(2)]
+    procs = [ctx.Process(target=_loop_worker, args=(r, 2, port, inflight, runs, threads, q, burst)) for r in range(2)]
     for p in procs:
         p.start()
     got = {}

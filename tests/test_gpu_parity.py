@@ -888,3 +888,69 @@ def test_prepared_step_and_threaded_issue_equal_forward_batch():
         loop.close()
     # the attributes of the planner follow the prepared step as they follow forward_batch
     assert np.isfinite(float(pans[0].min_distance[0])) and pans[0].audit()["violations"] == 0
+
+
+def test_breadth_first_group_issue_equals_call_by_call():
+    """npa_forward_batch_group (neupan_amd.pan.StepGroup, StepLoop(burst=True)): the chains of a round enqueued breadth-first
+    -- staging of every chain, PAN iteration 0 of every chain, ... -- plan bitwise what the call-by-call order plans, with
+    the main thread alone and with several issuing threads, whole rounds and partial ones; a group with a HIP-graph member
+    is refused (the loop then keeps the call-by-call order); a handle twice in one group is an argument error."""
+    import ctypes as C
+    import torch
+    from gpu_helpers import make_gpu_pan
+    from neupan_amd import _lib
+    from neupan_amd.pan import StepGroup
+    from neupan_amd.serve import StepLoop
+    cfg = CONFIGS["diff_1k_T10_K10"]
+    nfl, B = 5, 24
+    batches = [make_batch(cfg, 9000 + 100 * j, B) for j in range(nfl)]
+    keys = ("nom_s", "nom_u", "ref_s", "ref_us", "points")
+    ref = []
+    for bt in batches:
+        p = make_gpu_pan(cfg)
+        ref.append(p.forward_batch(*[bt[k] for k in keys])["opt_u"].cpu().numpy())
+    dev = torch.device("cuda", 0)
+    pans = [make_gpu_pan(cfg) for _ in range(nfl)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
+    args = [[torch.from_numpy(bt[k]).to(dev) for k in keys] for bt in batches]
+    torch.cuda.synchronize()
+    steps = []
+    for j in range(nfl):
+        with torch.cuda.stream(streams[j]):
+            steps.append(pans[j].make_step(*args[j], reset_every_step=True))
+    torch.cuda.synchronize()
+    cur = torch.cuda.current_stream(dev)
+    for threads in (0, 2):
+        loop = StepLoop(steps, streams, None, cur, threads=threads, burst=True)
+        assert loop.groups is not None
+        for n in (nfl, 2, 3 * nfl + 2):
+            last = loop.run(n)
+            torch.cuda.synchronize()
+            for j in range(min(n, nfl)):
+                o, g = last[j]
+                assert np.array_equal(o["opt_u"].cpu().numpy(), ref[j]), (threads, n, j)
+                assert (o["iters"].cpu().numpy() == cfg.iter_num).all()
+        loop.close()
+    # fewer PAN iterations for one member of a group: that call stops early, the others do not
+    grp = StepGroup(steps[:2], streams[:2])
+    grp.arr[1].iter_num = 1
+    outs = grp.issue()
+    torch.cuda.synchronize()
+    assert np.array_equal(outs[0]["opt_u"].cpu().numpy(), ref[0])
+    assert (outs[1]["iters"].cpu().numpy() == 1).all()
+    grp.arr[1].iter_num = cfg.iter_num + 1                      # more than the handle has: refused, nothing left half-begun
+    with pytest.raises(_lib.NeupanAmdError):
+        grp.issue()
+    grp.arr[1].iter_num = cfg.iter_num
+    grp.arr[1].h = grp.arr[0].h                                 # the same handle twice
+    with pytest.raises(_lib.NeupanAmdError):
+        grp.issue()
+    torch.cuda.synchronize()
+    assert np.array_equal(steps[0]()["opt_u"].cpu().numpy(), ref[0])      # the handles are usable afterwards
+    torch.cuda.synchronize()
+    with torch.cuda.stream(streams[1]):
+        gstep = pans[1].make_step(*args[1], reset_every_step=True, graph=True)
+    torch.cuda.synchronize()
+    loop = StepLoop([steps[0], gstep], streams[:2], None, cur, threads=0, burst=True)
+    assert loop.groups is None
+    loop.close()
