@@ -46,7 +46,7 @@ import torch  # noqa: E402
 
 WORKLOAD = "diff_1k_T10_K10"
 BATCH = 256
-BURST_DEFAULT = 0
+BURST_DEFAULT = 1
 # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table (256 CUs x 4 SIMDs, 2.4 GHz)
 PEAK_FP64_VALU_TFLOPS = 78.6
 PEAK_FP32_MFMA_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32: what the exact encoder runs on
@@ -641,6 +641,19 @@ def main():
                                                 "reference ships no E = 8 checkpoint: ours, trained with its recipe on closed-form labels) in "
                                                 "exact fp32 and in the LABELLED bf16 tier of the rows (v_mfma_f32_32x32x16_bf16; its parity "
                                                 "entry shows what that costs); parity = ensemble verdicts on the first 16 scenes (6 members)")
+        # how far the chip is from full at 20 x 256 scenes in flight: the same loop with more scenes per launch (the chains in
+        # flight are capped by the ~24 hardware queues a process gets, DESIGN.md section 4, so more work in flight means bigger
+        # launches).  NOT the configuration the metric is quoted on -- a ceiling for it.
+        shapes = {}
+        for b_, nf, st_ in ((512, nfl, 96), (1024, nfl, 64), (2048, 12, 36)):
+            res, l2 = short_run(WORKLOAD, b_, nf, dev, st_, st_ // 4, issue_threads=args.issue_threads)
+            shapes[f"{b_}_scenes_per_launch_{nf}_in_flight"] = {k: res[k] for k in ("plans_per_s", "ms_per_step", "steps", "scenes_per_step",
+                                                                                      "batches_in_flight", "select_launch_ms", "qp_launch_ms")}
+            l2.close()
+        ex["launch_shapes"] = dict(shapes, note="the default workload with 2 / 4 / 8 batches of 256 scenes coalesced into one launch chain: "
+                                                "what the two kernels deliver when the chip is given enough independent scenes (a launch "
+                                                "lasts as long as its slowest scene, so at 20 x 256 in flight most wave slots idle behind "
+                                                "tails); the headline value is NOT taken from these")
         ex["seconds"] = round(time.perf_counter() - t_ex, 1)
         line["extra"] = ex
     if rank == 0:

@@ -51,4 +51,10 @@ for sh in "512 10" "1024 5" "128 22"; do
   set -- $sh
   timeout 120 $py bench.py --no-cpu --no-latency --no-extras --batch $1 --inflight $2 --steps $(( 32768 / $1 )) --warmup $(( 8192 / $1 )) > "$out/shape_b$1_f$2.json" 2>/dev/null
 done
+stamp "a burst of 5120 scenes (the driver's 20 steps) as fewer, larger launches; issue order"
+for sh in "512 10 10" "1024 5 5" "1280 4 4"; do
+  set -- $sh
+  timeout 120 $py bench.py --no-cpu --no-latency --no-extras --batch $1 --inflight $2 --steps $3 --warmup 2 > "$out/burst5120_b$1_f$2.json" 2>/dev/null
+done
+timeout 200 $py tests/tools/burst_sweep.py 5 > "$out/${tag}_burst_sweep.txt" 2>/dev/null
 stamp "done"
