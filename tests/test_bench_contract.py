@@ -48,6 +48,9 @@ def test_default_bench_line_carries_every_contract_field():
             assert v["plans_per_s"] > 0 and 0 < v["dune_executed_mfma"]["frac"] < 1 and v["controls_equal_default_path"] and v["margin_violations"] == 0
     u = x["uniform_cloud"]
     assert u["plans_per_s"] > 0 and u["candidates_per_slice"]["share_overflow_to_exact_keys"] == 0 and u["parity"]["one_step"]["unexplained"] == 0
+    sh = {k: v for k, v in x["launch_shapes"].items() if isinstance(v, dict)}     # more scenes per launch: a ceiling, not the headline
+    assert len(sh) >= 3 and all(v["scenes_per_step"] > d["config"]["scenes_per_gpu"] and v["plans_per_s"] > d["value"] for v in sh.values())
+    assert "breadth-first" in d["config"]["schedule"]
     oc = {k: v for k, v in x["other_configs"].items() if isinstance(v, dict)}
     assert len(oc) >= 4 and all(v["plans_per_s"] > 0 and v["margin_violations"] == 0 for v in oc.values())
     exact = {k: v for k, v in oc.items() if "bf16" not in k}                  # the bf16 tier is labelled as NOT meeting parity
