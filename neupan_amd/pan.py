@@ -865,6 +865,14 @@ class StepGroup:
 
     def issue(self, n=None):
         n = len(self.calls) if n is None else n
+        if not 1 <= n <= len(self.calls):
+            raise NeupanAmdError(f"StepGroup.issue: {n} members requested of {len(self.calls)}")
+        # the group entry point's own argument checks, made here with a message (the library returns a bare NPA_E_ARG for them)
+        hs = [self.arr[i].h for i in range(n)]
+        if len(set(hs)) != n or any(not h for h in hs):
+            raise NeupanAmdError("StepGroup.issue: the members of a group must be distinct live handles (one batch at a time per handle)")
+        if any(self.arr[i].iter_num < 1 for i in range(n)):
+            raise NeupanAmdError("StepGroup.issue: iter_num < 1")
         for c in self.calls[:n]:
             c["validate"]()
         with torch.cuda.device(self.device):

@@ -196,18 +196,18 @@ class StepLoop:
         # (neupan_amd.pan.StepGroup -> npa_forward_batch_group): every chain of the round starts within the first two launches
         # per chain instead of behind the 21 launches of each chain in front of it.  Steps that cannot be grouped (HIP-graph
         # steps, stand-ins without a group class) keep the call-by-call order.
-        self.groups = None
+        self.groups, self.burst_refused = None, None
         if burst:
+            if group_cls is None:
+                from .pan import StepGroup as group_cls
+            from ._lib import NeupanAmdError
+            nw = max(self.threads, 1)
             try:
-                if group_cls is None:
-                    from .pan import StepGroup as group_cls
-                nw = max(self.threads, 1)
-                self.groups = []
-                for w in range(nw):
-                    own = [j for j in range(self.nfl) if j % nw == w]
-                    self.groups.append(group_cls([steps[j] for j in own], [streams[j] for j in own] if streams is not None else None))
-            except Exception:
-                self.groups = None
+                self.groups = [group_cls([steps[j] for j in range(self.nfl) if j % nw == w],
+                                         [streams[j] for j in range(self.nfl) if j % nw == w] if streams is not None else None)
+                               for w in range(nw)]
+            except NeupanAmdError as e:          # members that cannot be grouped (HIP-graph steps, mixed flags): call by call
+                self.groups, self.burst_refused = None, str(e)
         self._q = [queue.Queue() for _ in range(self.threads)]
         self._workers = []
         self._err = None
@@ -229,27 +229,13 @@ class StepLoop:
                 self.gatherer.stage(base + i, o["opt_u"])
         return o
 
-    def _issue_rounds(self, w, nw, n, base, outs, evs):
-        """Thread w's share of n steps, round by round: its slots' steps of a round as one breadth-first group call, their
-        controls staged behind them in step order."""
-        for r0 in range(0, n, self.nfl):
-            mine = [i for i in range(r0, min(n, r0 + self.nfl)) if (i % self.nfl) % nw == w]
-            if not mine:
-                continue
-            res = self.groups[w].issue(len(mine))           # (a thread's slots of a round are a prefix of its slot list)
-            for i, o in zip(mine, res):
-                if self.gatherer is not None:
-                    if self.streams is not None:
-                        self.gatherer.stage(base + i, o["opt_u"], self.streams[i % self.nfl])
-                    else:
-                        self.gatherer.stage(base + i, o["opt_u"])
-                outs[i] = o
-                if evs is not None:
-                    evs[i].set()
-
-    def _issue_rounds_one(self, r0, n, base, outs):
-        mine = list(range(r0, min(n, r0 + self.nfl)))
-        res = self.groups[0].issue(len(mine))
+    def _issue_round(self, w, nw, r0, n, base, outs, evs=None):
+        """Thread w's slots of the round that starts at step r0 (a prefix of its slot list) as ONE breadth-first group call;
+        their controls are staged behind them in step order."""
+        mine = [i for i in range(r0, min(n, r0 + self.nfl)) if (i % self.nfl) % nw == w]
+        if not mine:
+            return
+        res = self.groups[w].issue(len(mine))
         for i, o in zip(mine, res):
             if self.gatherer is not None:
                 if self.streams is not None:
@@ -257,6 +243,8 @@ class StepLoop:
                 else:
                     self.gatherer.stage(base + i, o["opt_u"])
             outs[i] = o
+            if evs is not None:
+                evs[i].set()
 
     def _work(self, w):
         while True:
@@ -266,7 +254,8 @@ class StepLoop:
             n, base, outs, evs = cmd
             try:
                 if self.groups is not None:
-                    self._issue_rounds(w, self.threads, n, base, outs, evs)
+                    for r0 in range(0, n, self.nfl):
+                        self._issue_round(w, self.threads, r0, n, base, outs, evs)
                     continue
                 for i in range(n):
                     if (i % self.nfl) % self.threads != w:
@@ -289,7 +278,7 @@ class StepLoop:
                     st.wait_stream(self.cur)
             outs = [None] * n
             for r0 in range(0, n, self.nfl):
-                self._issue_rounds_one(r0, n, base, outs)
+                self._issue_round(0, 1, r0, n, base, outs)
                 for i in range(r0, min(n, r0 + self.nfl)):
                     o = outs[i]
                     g = self.gatherer.collect(base + i, o["opt_u"]) if self.gatherer is not None else o["opt_u"]
