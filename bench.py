@@ -41,6 +41,7 @@ sys.path.insert(0, ROOT)
 # with fewer queues than streams the throughput falls to what that many concurrent chains give).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
+import re  # noqa: E402
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -72,6 +73,54 @@ def source_hash(files=None):
 
 def kernel_hash(kernel):
     return source_hash(KERNEL_SOURCES.get(kernel, None))
+
+
+_ISA = {}
+
+
+def kernel_isa_hash(full_name):
+    """Fingerprint of the MACHINE CODE of one kernel instantiation of the built library (tests/tools/kernel_resources.py:
+    the bytes of its function symbol + its kernel descriptor), looked up by the demangled name a rocprofv3 trace prints for it
+    ("nrmp_qp_kernel<10, 10, false, false, 2, false>").  A counter record stays valid exactly as long as this does -- source
+    edits that compile to the same code (comments, another kernel in the file) keep it, another compiler or register
+    allocation does not.  None when the ROCm LLVM tools are not installed (the source hash then decides)."""
+    if "table" not in _ISA:
+        _ISA["table"] = None
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+            import kernel_resources as kr
+            if kr.tools_available():
+                _ISA["table"] = kr.kernel_isa_hashes()
+        except Exception:
+            _ISA["table"] = None
+    t = _ISA["table"]
+    m = re.match(r"^(?:void )?(\w+)(?:<(.*)>)?$", full_name.strip())
+    if t is None or not m:
+        return None
+    # Itanium mangling of a kernel template whose arguments are ints and bools: _Z<len><name>I(Li<n>E|Lb<0/1>E)*E...
+    name, targs = m.group(1), m.group(2)
+    prefix = f"_Z{len(name)}{name}"
+    if targs is not None:
+        enc = []
+        for a in (x.strip() for x in targs.split(",")):
+            if a in ("true", "false"):
+                enc.append("Lb%dE" % (a == "true"))
+            elif re.fullmatch(r"-?\d+", a):
+                enc.append("Li%sE" % a.replace("-", "n"))
+            else:
+                return None
+        prefix += "I" + "".join(enc) + "E"
+    hits = [h for n, h in t.items() if n.startswith(prefix) and (targs is not None or not n[len(prefix):].startswith("I"))]
+    return hits[0] if len(hits) == 1 else None
+
+
+def record_is_current(short, rec):
+    """Was this kernel's counter record (profiles/*_pmc.json) measured on the code the tree builds?  By machine code when the
+    record carries an isa_hash and the tools are here; by the hash of the kernel's source files otherwise."""
+    isa = kernel_isa_hash(rec.get("kernel", "")) if rec.get("isa_hash") else None
+    if isa is not None:
+        return isa == rec["isa_hash"]
+    return rec.get("source_hash") == kernel_hash(short)
 
 
 def load_pmc(workload):
@@ -429,8 +478,8 @@ def main():
                                   "frac": round(flops * K * args.steps / elapsed / 1e12 / PEAK_FP64_VALU_TFLOPS, 5)}
         roof["pmc"] = {"file": pmc["_file"],
                        "per_kernel": {k: dict({kk: v[kk] for kk in ("valu_insts_per_launch", "valu_issue_frac", "hbm_bytes_per_launch",
-                                                                      "avg_ms_alone", "mfma_busy_frac", "source_hash") if kk in v},
-                                                  current=(v.get("source_hash") == kernel_hash(k)))
+                                                                      "avg_ms_alone", "mfma_busy_frac", "source_hash", "isa_hash") if kk in v},
+                                                  current=record_is_current(k, v))
                                       for k, v in pmc["kernels"].items()}}
     ks = pmc["kernels"].get("select_geo_kernel") if pmc else None
     if ks and sel_ms > 0 and "SQ_INSTS_MFMA" in ks.get("counters", {}):

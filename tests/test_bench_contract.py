@@ -67,12 +67,27 @@ def test_driver_flag_line_is_the_same_contract():
     assert t["n_gpus"] == 1 and t["value"] >= 0.9 * full["value"]          # one rank with a live RCCL communicator: within 10 %
 
 
-def test_tracked_pmc_file_matches_the_kernel_sources():
-    """bench.py prices the roofline with a kernel's record of profiles/r04_pmc.json only while the sources THAT kernel is
-    built from are unchanged (bench.kernel_hash): an edit of the dominant kernel without a new counter run would silently
-    drop `achieved` / `frac` from the line."""
+def test_tracked_pmc_file_matches_the_built_kernels():
+    """bench.py prices the roofline with a kernel's record of profiles/r04_pmc.json only while the code the tree builds IS
+    the code that was measured: by the fingerprint of the kernel's machine code (bench.kernel_isa_hash: function bytes +
+    kernel descriptor of the measured instantiation, read from the built library), or -- where the ROCm LLVM tools are not
+    installed -- by the hash of the source files the kernel is built from.  An edit of the dominant kernel that changes its
+    code without a new counter run fails here; a comment, or another kernel added next to it, does not."""
     import bench
+    from neupan_amd import build
+    build.build(force=False, verbose=False)
     pj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc.json")))
     k = pj["kernels"]["nrmp_qp_kernel"]
-    assert k["source_hash"] == bench.kernel_hash("nrmp_qp_kernel")
+    isa = bench.kernel_isa_hash(k["kernel"])
+    if isa is not None and k.get("isa_hash"):
+        assert k["isa_hash"] == isa
+        assert pj["kernels"]["select_geo_kernel"]["isa_hash"] == bench.kernel_isa_hash(pj["kernels"]["select_geo_kernel"]["kernel"])
+    else:
+        assert k["source_hash"] == bench.kernel_hash("nrmp_qp_kernel")
+    assert bench.record_is_current("nrmp_qp_kernel", k)
     assert k["fp64_flops_per_launch"] > 0 and k["hbm_bytes_per_launch"] > 0 and 0 < k["valu_issue_frac"] < 1
+    # the lookup itself: a template instantiation, a plain kernel, an unknown name
+    if isa is not None:
+        assert bench.kernel_isa_hash("stage_kernel") and bench.kernel_isa_hash("void nrmp_qp_kernel<20, 10, false, true, 2, false>")
+        assert bench.kernel_isa_hash("nrmp_qp_kernel<20, 10, false, true, 2, false>") != isa
+        assert bench.kernel_isa_hash("no_such_kernel<1>") is None

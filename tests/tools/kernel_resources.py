@@ -63,6 +63,59 @@ def kernel_resources(lib=LIB):
     return out
 
 
+def _code_objects(lib, d):
+    """Unbundle every gfx950 code object of the library into directory d; yields their paths."""
+    fat = os.path.join(d, "fat.bin")
+    subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", lib, os.path.join(d, "x")],
+                          stderr=subprocess.DEVNULL)
+    blob = open(fat, "rb").read()
+    starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
+    for i, s in enumerate(starts):
+        part = os.path.join(d, f"h{i}.bin")
+        open(part, "wb").write(blob[s:starts[i + 1] if i + 1 < len(starts) else len(blob)])
+        co = os.path.join(d, f"h{i}.co")
+        r = subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={part}",
+                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], stderr=subprocess.PIPE)
+        if r.returncode == 0 and os.path.exists(co) and os.path.getsize(co) > 0:
+            yield co
+
+
+def kernel_isa_hashes(lib=LIB):
+    """{mangled kernel name: sha256[:16] of the kernel's MACHINE CODE (the bytes of its function symbol in .text) and of its
+    64-byte kernel descriptor (register / LDS allocation, <name>.kd)}.  This is what a counter record is tied to: the counters
+    were measured on these bytes, whatever the source files around them look like (a comment, another kernel added to the
+    file or a refactoring that compiles to the same code leave them valid; another compiler or another register allocation
+    do not)."""
+    import hashlib
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        for co in _code_objects(lib, d):
+            raw = open(co, "rb").read()
+            secs = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "-S", "--wide", co], stdout=subprocess.PIPE, text=True).stdout
+            sec = {}
+            for line in secs.splitlines():
+                m = re.match(r"\s*\[\s*(\d+)\]\s+(\S+)\s+\S+\s+([0-9a-f]+)\s+([0-9a-f]+)\s+([0-9a-f]+)", line)
+                if m:
+                    sec[int(m.group(1))] = (m.group(2), int(m.group(3), 16), int(m.group(4), 16))      # name, address, file offset
+            syms = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "-s", "--wide", co], stdout=subprocess.PIPE, text=True).stdout
+            table = {}
+            for line in syms.splitlines():
+                f = line.split()
+                if len(f) >= 8 and f[0].rstrip(":").isdigit() and f[6].isdigit():
+                    table[f[7]] = (int(f[1], 16), int(f[2]), f[3], int(f[6]))                             # value, size, type, section index
+            for name, (val, size, typ, shndx) in table.items():
+                if typ != "FUNC" or size == 0 or (name + ".kd") not in table or shndx not in sec:
+                    continue
+                _, addr, off = sec[shndx]
+                h = hashlib.sha256(raw[off + val - addr: off + val - addr + size])
+                kv, ks, _, kx = table[name + ".kd"]
+                if kx in sec:
+                    _, ka, ko = sec[kx]
+                    h.update(raw[ko + kv - ka: ko + kv - ka + ks])
+                out[name] = h.hexdigest()[:16]
+    return out
+
+
 def demangle(name):
     try:
         return subprocess.run([os.path.join(LLVM, "llvm-cxxfilt"), name], stdout=subprocess.PIPE, text=True).stdout.strip().split("(")[0]

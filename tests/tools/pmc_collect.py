@@ -11,8 +11,9 @@ duration from the kernel trace of the same pass, and derived figures:
   fp64_flops       = 64 lanes x (ADD_F64 + MUL_F64 + 2 FMA_F64) wave-instructions (an upper bound: lanes may be masked off)
   hbm_bytes        = FETCH_SIZE [KiB] x 1024 (x2 only where the kernel streams 16 B/lane -- none of ours do: the reads are
                      4-B/lane gathers, counted at face value, see the guide's HBM section) + WRITE_SIZE [KiB] x 1024
-Every kernel's record carries `source_hash` = the hash of the source files THAT kernel is built from (bench.kernel_hash):
-bench.py uses a record only while it matches the tree."""
+Every kernel's record carries `isa_hash` = a fingerprint of the machine code of the instantiation that was measured
+(bench.kernel_isa_hash) and `source_hash` = the hash of the source files it is built from (bench.kernel_hash): bench.py marks a
+record current while the built code is the measured code (the source hash decides where the LLVM tools are missing)."""
 import collections, csv, json, os, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -96,7 +97,7 @@ def derive(e, c):
 
 
 def main():
-    from bench import source_hash, kernel_hash, BATCH
+    from bench import source_hash, kernel_hash, kernel_isa_hash, BATCH
     workload = sys.argv[1] if len(sys.argv) > 1 else "diff_1k_T10_K10"
     kern = collections.defaultdict(dict)
     durs = collections.defaultdict(list)
@@ -119,7 +120,8 @@ def main():
            "passes": log, "kernels": {}}
     for k, c in kern.items():
         ms = sum(durs[k]) / max(len(durs[k]), 1)
-        e = {"kernel": names.get(k, k), "avg_ms_alone": ms, "counters": c, "source_hash": kernel_hash(k)}
+        e = {"kernel": names.get(k, k), "avg_ms_alone": ms, "counters": c, "source_hash": kernel_hash(k),
+             "isa_hash": kernel_isa_hash(names.get(k, k))}          # (machine code of the instantiation that was measured)
         if c.get("SQ_ACTIVE_INST_LDS"):
             e["lds_bank_conflict_frac"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_ACTIVE_INST_LDS"]
         gui = c.get("GRBM_GUI_ACTIVE")
