@@ -55,8 +55,9 @@ PEAK_F16_MFMA_TFLOPS = 2500.0       # dense fp16 / bf16 MFMA
 N_SIMD = 1024
 PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r04_pmc.json", "r03_pmc.json")]     # newest first
 # which source files a kernel's counters depend on (a record is "current" only while these are unchanged)
-KERNEL_SOURCES = {"nrmp_qp_kernel": ("nrmp_qp.hip", "pan_common.h"), "select_geo_kernel": ("dune.hip", "pan_common.h"),
-                  "select_kernel": ("dune.hip", "pan_common.h"), "dune_kernel": ("dune.hip", "pan_common.h"),
+_QP_SRC = ("nrmp_qp.hip", "nrmp_qp_device.h", "nrmp_qp_body.inc", "aset_reduce.h", "pan_common.h")
+_DUNE_SRC = ("dune.hip", "dune_device.h", "select_geo_carve.inc", "select_geo_body.inc", "pan_common.h")
+KERNEL_SOURCES = {"nrmp_qp_kernel": _QP_SRC, "select_geo_kernel": _DUNE_SRC, "select_kernel": _DUNE_SRC, "dune_kernel": _DUNE_SRC,
                   "stage_kernel": ("c_api.hip", "pan_common.h")}
 
 
@@ -66,7 +67,7 @@ def source_hash(files=None):
     h = hashlib.sha256()
     d = os.path.join(ROOT, "neupan_amd", "csrc")
     for f in sorted(os.listdir(d)) if files is None else files:
-        if f.endswith((".hip", ".h")):
+        if f.endswith((".hip", ".h", ".inc")):
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -36,1355 +36,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#define DUNE_THREADS 256
-#define DUNE_WAVES 4
-
-#define WSYNC()                                              \
-  do {                                                       \
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   \
-    __builtin_amdgcn_wave_barrier();                         \
-  } while (0)
-
-__device__ __forceinline__ float pair_sum(float x) {
-  // value + value of lane^32 (bitwise identical in both lanes: fp add commutes)
-  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
-__device__ __forceinline__ float tanh_scaled(float y) {
-  // tanh(x) = 1 - 2/(exp(2x)+1) with y = 2*log2(e)*x prepared by the caller (the factor is
-  // folded into the LayerNorm affine vectors on the host); |abs err| <~ 1.5e-7, saturates at +-1
-  float e = __builtin_amdgcn_exp2f(y);
-  return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
-}
-
-__device__ __forceinline__ void load_vec16(const float* v, int hf, float out[16]) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    float4 t = *reinterpret_cast<const float4*>(v + 8 * q + 4 * hf);
-    out[4 * q + 0] = t.x; out[4 * q + 1] = t.y; out[4 * q + 2] = t.z; out[4 * q + 3] = t.w;
-  }
-}
-
-__device__ __forceinline__ f32x16 bias_init(const float* v, int hf) {
-  float b[16];
-  load_vec16(v, hf, b);
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = b[r];
-  return acc;
-}
-
-// LayerNorm(32, eps=1e-5, affine) + tanh on a point's 32 features (16 here, 16 in lane^32)
-__device__ __forceinline__ void ln_tanh(f32x16 acc, const float* g, const float* be, int hf, float a[16]) {
-  float s = 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) s += acc[r];
-  float mean = pair_sum(s) * (1.0f / 32.0f);
-  float q = 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { a[r] = acc[r] - mean; q = fmaf(a[r], a[r], q); }
-  float var = pair_sum(q) * (1.0f / 32.0f);
-  float ve = var + 1e-5f;
-  float rstd = __builtin_amdgcn_rsqf(ve);                 // v_rsq_f32 (1 ulp) + one Newton step
-  rstd = rstd * fmaf(-0.5f * ve * rstd, rstd, 1.5f);
-  // affine vectors fetched four features at a time (keeps the live register set small)
-#pragma unroll
-  for (int qd = 0; qd < 4; ++qd) {
-    float4 gv = *reinterpret_cast<const float4*>(g + 8 * qd + 4 * hf);
-    float4 bv = *reinterpret_cast<const float4*>(be + 8 * qd + 4 * hf);
-    a[4 * qd + 0] = tanh_scaled(fmaf(a[4 * qd + 0] * rstd, gv.x, bv.x));
-    a[4 * qd + 1] = tanh_scaled(fmaf(a[4 * qd + 1] * rstd, gv.y, bv.y));
-    a[4 * qd + 2] = tanh_scaled(fmaf(a[4 * qd + 2] * rstd, gv.z, bv.z));
-    a[4 * qd + 3] = tanh_scaled(fmaf(a[4 * qd + 3] * rstd, gv.w, bv.w));
-  }
-}
-
-__device__ __forceinline__ f32x16 layer32(const float (&w)[16], const float (&a)[16], f32x16 acc) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[r], a[r], acc, 0, 0, 0);
-  return acc;
-}
-
-// ---- fp16x2 split-precision layer (dune_kernel only: distance keys) ------------------------------
-// x = x1 + x2, w = w1 + w2 with fp16 terms (RNE of the running residual: |x - x1 - x2| <= 2^-22 |x|
-// while the terms are normal numbers, which the host-chosen power-of-two scales guarantee for
-// every value that matters), product terms (2,1) (1,2) (1,1); the dropped (2,2) term is <= 2^-22
-// relative.  Each fp16 x fp16 product is exact in the fp32 accumulator.  6 x 32-cycle MFMAs per
-// layer instead of 16 x 64-cycle fp32-input ones.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-
-
-// RELU = true: the split is taken of max(a, 0) (the activation of the Linear->ReLU layers)
-template <bool RELU>
-__device__ __forceinline__ void split2(const float (&a)[16], f16x8 (&x1)[2], f16x8 (&x2)[2]) {
-#pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    f32x2_t v = {a[2 * p], a[2 * p + 1]};
-    if constexpr (RELU) {
-      // integer max on the bit pattern = ReLU in ONE instruction (fmaxf would first canonicalise the
-      // MFMA result with a second v_max; negative floats are negative ints, -0 -> +0)
-      v.x = __int_as_float(max(__float_as_int(v.x), 0));
-      v.y = __int_as_float(max(__float_as_int(v.y), 0));
-    }
-    const f16x2 b1 = __builtin_convertvector(v, f16x2);                 // v_cvt_pk_f16_f32 (RNE)
-    const f32x2_t r1 = v - __builtin_convertvector(b1, f32x2_t);
-    const f16x2 b2 = __builtin_convertvector(r1, f16x2);
-    const int s = p >> 2, q = (2 * p) & 7;
-    x1[s][q] = b1.x; x1[s][q + 1] = b1.y;
-    x2[s][q] = b2.x; x2[s][q + 1] = b2.y;
-  }
-}
-
-// wl: LDS image of one layer's split A-fragments [term 2][step 2][lane 64] x 16 B
-// TERMS = 3: the split product above.  TERMS = 1: leading fp16 terms only (2^-11 relative per factor): two MFMAs and
-// eight conversions per layer; usable because the keys only nominate candidates (select_kernel's margin).
-template <bool RELU, int TERMS>
-__device__ __forceinline__ f32x16 layer32_f16x2(const f16x8* wl, int lane, const float (&a)[16], f32x16 acc) {
-  if constexpr (TERMS == 1) {
-    f16x8 x[2];
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      f16x2 b1 = __builtin_convertvector(f32x2_t{a[2 * p], a[2 * p + 1]}, f16x2);       // v_cvt_pk_f16_f32
-      if constexpr (RELU) b1 = __builtin_elementwise_max(b1, f16x2{(_Float16)0.f, (_Float16)0.f});   // v_pk_max_f16
-      const int s = p >> 2, q = (2 * p) & 7;
-      x[s][q] = b1.x; x[s][q + 1] = b1.y;
-    }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[(0 * 2 + s) * 64 + lane], x[s], acc, 0, 0, 0);
-    return acc;
-  }
-  f16x8 x1[2], x2[2];
-  split2<RELU>(a, x1, x2);
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const f16x8 w1 = wl[(0 * 2 + s) * 64 + lane], w2 = wl[(1 * 2 + s) * 64 + lane];
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2, x1[s], acc, 0, 0, 0);      // small terms first
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, x2[s], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, x1[s], acc, 0, 0, 0);
-  }
-  return acc;
-}
-
-// ---- key path: reassociated encoder (packed fp32 VALU, LayerNorm centring folded into the weights) --
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// acc holds CENTRED pre-activations (mean removed through W_c, b_c): var = sum(acc^2)/32
-__device__ __forceinline__ void ln_tanh_centred(f32x16 acc, const float* g, const float* be, int hf, float eps,
-                                                float out_scale, float a[16]) {
-  f32x2 q2 = {0.f, 0.f};
-#pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const f32x2 v = {acc[2 * p], acc[2 * p + 1]};
-    q2 = __builtin_elementwise_fma(v, v, q2);
-  }
-  const float ve = fmaf(pair_sum(q2.x + q2.y), 1.0f / 32.0f, eps);
-  float rstd = __builtin_amdgcn_rsqf(ve);
-  rstd = rstd * fmaf(-0.5f * ve * rstd, rstd, 1.5f);
-  // out_scale * tanh: out_scale - 2 out_scale / (e + 1)
-  const f32x2 rs = {rstd, rstd}, one = {1.f, 1.f}, osc = {out_scale, out_scale}, mtwo = {-2.f * out_scale, -2.f * out_scale};
-#pragma unroll
-  for (int qd = 0; qd < 4; ++qd) {
-    const float4 gv = *reinterpret_cast<const float4*>(g + 8 * qd + 4 * hf);
-    const float4 bv = *reinterpret_cast<const float4*>(be + 8 * qd + 4 * hf);
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const f32x2 x = {acc[4 * qd + 2 * hh], acc[4 * qd + 2 * hh + 1]};
-      const f32x2 gg = hh ? f32x2{gv.z, gv.w} : f32x2{gv.x, gv.y};
-      const f32x2 bb = hh ? f32x2{bv.z, bv.w} : f32x2{bv.x, bv.y};
-      const f32x2 y = __builtin_elementwise_fma(x * rs, gg, bb);
-      f32x2 e = {__builtin_amdgcn_exp2f(y.x), __builtin_amdgcn_exp2f(y.y)};
-      e = e + one;
-      const f32x2 r = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
-      const f32x2 th = __builtin_elementwise_fma(r, mtwo, osc);
-      a[4 * qd + 2 * hh] = th.x; a[4 * qd + 2 * hh + 1] = th.y;
-    }
-  }
-}
-
-// LDS image of the key path: split fragments, then kvec [5][32], then ksc [8] (pan_common.h)
-template <int E, int TERMS>
-__device__ __forceinline__ void encode_tile_keys(float kw1, const f16x8* wbf, const float* vec, const float* w6,
-                                                 const float* b6, float p0x, float p0y, int lane, float mu[E]) {
-  const int hf = lane >> 5;
-  const float* kvec = reinterpret_cast<const float*>(wbf) + WP_BF_FLOATS;
-  const float* ksc = kvec + 5 * 32;
-  constexpr int LSTR = 2 * 2 * 64;          // fragments per layer
-  float a[16];
-  {
-    f32x16 acc = bias_init(kvec + 0 * 32, hf);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kw1, hf ? p0y : p0x, acc, 0, 0, 0);
-    ln_tanh_centred(acc, vec + V_G1 * 32, vec + V_BE1 * 32, hf, ksc[0], ksc[3], a);
-  }
-  // the ReLU of Linear 2 / Linear 4 is applied inside the split of the following layer
-  {
-    f32x16 acc = layer32_f16x2<false, TERMS>(wbf + 0 * LSTR, lane, a, bias_init(kvec + 1 * 32, hf));
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = acc[r];
-  }
-  {
-    f32x16 acc = layer32_f16x2<true, TERMS>(wbf + 1 * LSTR, lane, a, bias_init(kvec + 2 * 32, hf));
-    ln_tanh_centred(acc, vec + V_G2 * 32, vec + V_BE2 * 32, hf, ksc[1], ksc[4], a);
-  }
-  {
-    f32x16 acc = layer32_f16x2<false, TERMS>(wbf + 2 * LSTR, lane, a, bias_init(kvec + 3 * 32, hf));
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = acc[r];
-  }
-  {
-    f32x16 acc = layer32_f16x2<true, TERMS>(wbf + 3 * LSTR, lane, a, bias_init(kvec + 4 * 32, hf));
-    ln_tanh_centred(acc, vec + V_G3 * 32, vec + V_BE3 * 32, hf, ksc[2], ksc[5], a);
-  }
-  // output layer: two features per packed FMA (rows of Linear 6 as stored for the exact path)
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    float wv[16];
-    load_vec16(w6 + e * 32, hf, wv);
-    f32x2 s2 = {0.f, 0.f};
-#pragma unroll
-    for (int p = 0; p < 8; ++p)
-      s2 = __builtin_elementwise_fma(f32x2{wv[2 * p], wv[2 * p + 1]}, f32x2{a[2 * p], a[2 * p + 1]}, s2);
-    mu[e] = fmaxf(pair_sum(s2.x + s2.y) + b6[e], 0.f);
-  }
-}
-
-struct WaveWeights {
-  float w1;
-  float wl[4][16];
-};
-
-// Encoder for the 32 points of a tile.  p0x/p0y: the point in the robot frame (both lanes of
-// a pair hold both).  Returns mu[e] (e<E) in BOTH lanes of the pair.
-// Exact fp32 MFMA (v_mfma_f32_32x32x2_f32), weights in W.wl; the reference's operation order.
-template <int E>
-__device__ __forceinline__ void encode_tile(const WaveWeights& W, const float* vec, const float* w6, const float* b6,
-                                            float p0x, float p0y, int lane, float mu[E]) {
-  const int hf = lane >> 5;
-  auto layer = [&](int L, const float (&a_)[16], f32x16 acc) -> f32x16 { return layer32(W.wl[L], a_, acc); };
-  float a[16];
-  {
-    f32x16 acc = bias_init(vec + V_B1 * 32, hf);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W.w1, hf ? p0y : p0x, acc, 0, 0, 0);
-    ln_tanh(acc, vec + V_G1 * 32, vec + V_BE1 * 32, hf, a);
-  }
-  {
-    f32x16 acc = layer(0, a, bias_init(vec + V_B2 * 32, hf));
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r], 0.f);
-  }
-  {
-    f32x16 acc = layer(1, a, bias_init(vec + V_B3 * 32, hf));
-    ln_tanh(acc, vec + V_G2 * 32, vec + V_BE2 * 32, hf, a);
-  }
-  {
-    f32x16 acc = layer(2, a, bias_init(vec + V_B4 * 32, hf));
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r], 0.f);
-  }
-  {
-    f32x16 acc = layer(3, a, bias_init(vec + V_B5 * 32, hf));
-    ln_tanh(acc, vec + V_G3 * 32, vec + V_BE3 * 32, hf, a);
-  }
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    float wv[16];
-    load_vec16(w6 + e * 32, hf, wv);
-    float s = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s = fmaf(wv[r], a[r], s);
-    mu[e] = fmaxf(pair_sum(s) + b6[e], 0.f);
-  }
-}
-
-// The same encoder with the weights of the four 32x32 layers STREAMED from the lane-major copy (WP_WLS) instead of held
-// in 64 registers: the next layer's sixteen fragments are requested (four 16-byte loads, L1 / L2 resident: every wave of
-// the chip reads the same 16 KB) before the current layer's sixteen MFMAs start, which take ~1000 cycles.  Same
-// arithmetic in the same order as encode_tile: bitwise the same rows.
-__device__ __forceinline__ void load_layer(const float* __restrict__ wls, int L, int lane, float (&w)[16]) {
-  // (the address passes through an opaque asm: the loads are loop-invariant, and the compiler would otherwise hoist all
-  // four layers out of the tile loop and keep them in 64 registers -- the layout this form exists to avoid)
-  asm volatile("" : "+s"(wls));
-  const float4* p = reinterpret_cast<const float4*>(wls + ((size_t)L * 64 + lane) * 16);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float4 v = p[q];
-    w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
-  }
-}
-template <int E>
-__device__ __forceinline__ void encode_tile_stream(float w1, const float* __restrict__ wls, const float* vec, const float* w6,
-                                                   const float* b6, float p0x, float p0y, int lane, float mu[E]) {
-  const int hf = lane >> 5;
-  float a[16], wa[16], wb[16];
-  // (scheduling barriers between the blocks: left alone the scheduler hoists all four layers' loads to the top -- the
-  // 64 registers this form exists to avoid)
-  load_layer(wls, 0, lane, wa);
-  {
-    f32x16 acc = bias_init(vec + V_B1 * 32, hf);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, hf ? p0y : p0x, acc, 0, 0, 0);
-    ln_tanh(acc, vec + V_G1 * 32, vec + V_BE1 * 32, hf, a);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  load_layer(wls, 1, lane, wb);
-  {
-    f32x16 acc = layer32(wa, a, bias_init(vec + V_B2 * 32, hf));
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r], 0.f);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  load_layer(wls, 2, lane, wa);
-  {
-    f32x16 acc = layer32(wb, a, bias_init(vec + V_B3 * 32, hf));
-    ln_tanh(acc, vec + V_G2 * 32, vec + V_BE2 * 32, hf, a);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  load_layer(wls, 3, lane, wb);
-  {
-    f32x16 acc = layer32(wa, a, bias_init(vec + V_B4 * 32, hf));
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r], 0.f);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  {
-    f32x16 acc = layer32(wb, a, bias_init(vec + V_B5 * 32, hf));
-    ln_tanh(acc, vec + V_G3 * 32, vec + V_BE3 * 32, hf, a);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    float wv[16];
-    load_vec16(w6 + e * 32, hf, wv);
-    float s = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s = fmaf(wv[r], a[r], s);
-    mu[e] = fmaxf(pair_sum(s) + b6[e], 0.f);
-  }
-}
-
-// ---- reduced-precision tier of the ROWS (BASELINE.json configs[4]: "bf16 DUNE on MFMA"; NPA_ROWS_PRECISION=bf16) ------------
-// The four 32x32 layers as TWO v_mfma_f32_32x32x16_bf16 each (weights rounded to bf16 once on the host, activations rounded
-// per layer with v_cvt_pk_bf16_f32, fp32 accumulation) instead of sixteen v_mfma_f32_32x32x2_f32; the 2 -> 32 input layer, the
-// LayerNorms / tanh and the 32 -> E output layer stay fp32 as in encode_tile.  NOT the reference's arithmetic: the rows differ
-// from the exact ones by ~2^-8 relative per layer, a different selection at rank-M ties follows, and the controls leave the
-// 1e-4 band on most scenes (measured distribution: DESIGN.md section 5, tests/test_gpu_parity.py) -- a labelled tier, off by default.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x16 layer32_bf16(const bf16x8* __restrict__ wb, int L, int lane, const float (&a)[16], f32x16 acc) {
-  bf16x8 x[2];
-#pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const bf16x2 b = __builtin_convertvector(f32x2_t{a[2 * p], a[2 * p + 1]}, bf16x2);       // v_cvt_pk_bf16_f32 (RNE)
-    const int s = p >> 2, q = (2 * p) & 7;
-    x[s][q] = b.x; x[s][q + 1] = b.y;
-  }
-#pragma unroll
-  for (int s = 0; s < 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[(L * 2 + s) * 64 + lane], x[s], acc, 0, 0, 0);
-  return acc;
-}
-template <int E>
-__device__ __forceinline__ void encode_tile_bf16(float w1, const float* __restrict__ wb16, const float* vec, const float* w6,
-                                                 const float* b6, float p0x, float p0y, int lane, float mu[E]) {
-  const int hf = lane >> 5;
-  const bf16x8* wb = reinterpret_cast<const bf16x8*>(wb16);
-  float a[16];
-  {
-    f32x16 acc = bias_init(vec + V_B1 * 32, hf);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, hf ? p0y : p0x, acc, 0, 0, 0);
-    ln_tanh(acc, vec + V_G1 * 32, vec + V_BE1 * 32, hf, a);
-  }
-  {
-    f32x16 acc = layer32_bf16(wb, 0, lane, a, bias_init(vec + V_B2 * 32, hf));
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r], 0.f);
-  }
-  {
-    f32x16 acc = layer32_bf16(wb, 1, lane, a, bias_init(vec + V_B3 * 32, hf));
-    ln_tanh(acc, vec + V_G2 * 32, vec + V_BE2 * 32, hf, a);
-  }
-  {
-    f32x16 acc = layer32_bf16(wb, 2, lane, a, bias_init(vec + V_B4 * 32, hf));
-#pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r], 0.f);
-  }
-  {
-    f32x16 acc = layer32_bf16(wb, 3, lane, a, bias_init(vec + V_B5 * 32, hf));
-    ln_tanh(acc, vec + V_G3 * 32, vec + V_BE3 * 32, hf, a);
-  }
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    float wv[16];
-    load_vec16(w6 + e * 32, hf, wv);
-    float s = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s = fmaf(wv[r], a[r], s);
-    mu[e] = fmaxf(pair_sum(s) + b6[e], 0.f);
-  }
-}
-
-__device__ __forceinline__ unsigned ordered_key(float d) {
-  // monotone float -> uint map; NaN sorts last
-  if (d != d) return 0xFFFFFFFEu;
-  unsigned b = __float_as_uint(d);
-  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-
-template <int CTRL>
-__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
-  unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xF, 0xF, false);
-  unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xF, 0xF, false);
-  return ((unsigned long long)hi << 32) | lo;
-}
-__device__ __forceinline__ unsigned long long umin64(unsigned long long a, unsigned long long b) { return a < b ? a : b; }
-__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l) {
-  unsigned lo = __builtin_amdgcn_readlane((unsigned)v, l), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), l);
-  return ((unsigned long long)hi << 32) | lo;
-}
-// full-wave min of a 64-bit key (DPP inside each 16-lane row, then 4 readlanes); uniform result
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-  v = umin64(v, dpp_u64<0xB1>(v));
-  v = umin64(v, dpp_u64<0x4E>(v));
-  v = umin64(v, dpp_u64<0x141>(v));
-  v = umin64(v, dpp_u64<0x140>(v));
-  return umin64(umin64(readlane_u64(v, 0), readlane_u64(v, 16)), umin64(readlane_u64(v, 32), readlane_u64(v, 48)));
-}
-
-struct SliceFrame {
-  float c, s, tx, ty;         // rotation (fp32 cos/sin of theta) and translation of the robot
-  float tstep;                // (float)t
-  float rg[2][NPA_MAX_E];     // (-R) @ G^T          (dune.py:89)
-};
-
-// source column of logical point n after decimation (util/__init__.py:300: linspace->int)
-__device__ __forceinline__ int src_index(int n, int n_raw, int n_use) {
-  if (n_use >= n_raw) return n;
-  if (n == n_use - 1) return n_raw - 1;
-  double step = (double)(n_raw - 1) / (double)(n_use - 1);
-  return (int)((double)n * step);
-}
-
-// frame of a slice: robot pose at horizon step t, (-R)G^T
-template <int E>
-__device__ __forceinline__ void load_frame(const DevParams& P, const float* __restrict__ cur_s,
-                                           const float* __restrict__ trig, int b, int t, SliceFrame& F) {
-  // cos / sin come from the table written together with cur_s (stage_kernel, the QP's write-out, trig_kernel): the
-  // fp64 libm evaluation costs ~250 slow VALU instructions, which a wave of dune_kernel would otherwise pay for
-  // every work ticket (nearly every ticket of a wave lands in a new slice)
-  const int T = P.T;
-  const float* s = cur_s + (size_t)b * 3 * (T + 1);
-  F.tx = s[t];
-  F.ty = s[(T + 1) + t];
-  F.c = trig[((size_t)b * (T + 1) + t) * 2];
-  F.s = trig[((size_t)b * (T + 1) + t) * 2 + 1];
-  F.tstep = (float)t;
-#pragma unroll
-  for (int e = 0; e < E; ++e) {     // (-R) @ G^T, R = [[c,-s],[s,c]]
-    F.rg[0][e] = fmaf(-F.c, P.G[e][0], __fmul_rn(F.s, P.G[e][1]));
-    F.rg[1][e] = fmaf(-F.s, P.G[e][0], -__fmul_rn(F.c, P.G[e][1]));
-  }
-  // the frame is wave-uniform: park it in SGPRs, the VGPR budget (128) is tight
-  auto uni = [](float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); };
-  F.c = uni(F.c); F.s = uni(F.s); F.tx = uni(F.tx); F.ty = uni(F.ty); F.tstep = uni(F.tstep);
-#pragma unroll
-  for (int e = 0; e < E; ++e) { F.rg[0][e] = uni(F.rg[0][e]); F.rg[1][e] = uni(F.rg[1][e]); }
-}
-
-// one point (two lanes) through point flow + encoder + lam/distance
-template <int E, int SPLIT>      // 0: exact fp32 encoder; 3 / 1: key path with that many fp16 product terms
-__device__ __forceinline__ void point_features(const DevParams& P, const SliceFrame& F, const WaveWeights& W,
-                                               const f16x8* wbf, const float* vec, const float* w6, const float* b6,
-                                               const float* px_row, const float* py_row, const float* vx_row,
-                                               const float* vy_row, int src, int lane, float mu[E], float& gx,
-                                               float& gy, float& lx, float& ly, float& dist) {
-  // pan.py:182  receding_obs_points = obs_points + i * (point_velocities * dt)
-  gx = px_row[src];
-  gy = py_row[src];
-  if (vx_row) {
-    gx = __fadd_rn(gx, __fmul_rn(F.tstep, __fmul_rn(vx_row[src], P.dt32)));
-    gy = __fadd_rn(gy, __fmul_rn(F.tstep, __fmul_rn(vy_row[src], P.dt32)));
-  }
-  // pan.py:210  p0 = R.T @ (obs_points - trans)
-  float dx = __fsub_rn(gx, F.tx), dy = __fsub_rn(gy, F.ty);
-  float p0x = fmaf(F.c, dx, __fmul_rn(F.s, dy));
-  float p0y = fmaf(F.c, dy, -__fmul_rn(F.s, dx));
-  if constexpr (SPLIT != 0) encode_tile_keys<E, SPLIT>(W.w1, wbf, vec, w6, b6, p0x, p0y, lane, mu);   // W.w1 = centred fragment
-  else encode_tile<E>(W, vec, w6, b6, p0x, p0y, lane, mu);
-  lx = 0.f; ly = 0.f; dist = 0.f;
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    lx = fmaf(F.rg[0][e], mu[e], lx);                                  // dune.py:89
-    ly = fmaf(F.rg[1][e], mu[e], ly);
-    float tmp = __fsub_rn(fmaf(P.G[e][0], p0x, __fmul_rn(P.G[e][1], p0y)), P.h[e]);   // dune.py:121
-    dist = fmaf(mu[e], tmp, dist);                                     // dune.py:124
-  }
-}
-
-// point_features with the streamed-weight encoder (exact rows; same operation order); BF16: the reduced-precision tier,
-// wls then points at the bf16 fragments (WP_WB16)
-template <int E, bool BF16 = false>
-__device__ __forceinline__ void point_features_stream(const DevParams& P, const SliceFrame& F, float w1, const float* __restrict__ wls,
-                                                      const float* vec, const float* w6, const float* b6, const float* px_row,
-                                                      const float* py_row, const float* vx_row, const float* vy_row, int src,
-                                                      int lane, float mu[E], float& gx, float& gy, float& lx, float& ly,
-                                                      float& dist, float& p0x, float& p0y) {
-  gx = px_row[src];
-  gy = py_row[src];
-  if (vx_row) {
-    gx = __fadd_rn(gx, __fmul_rn(F.tstep, __fmul_rn(vx_row[src], P.dt32)));
-    gy = __fadd_rn(gy, __fmul_rn(F.tstep, __fmul_rn(vy_row[src], P.dt32)));
-  }
-  float dx = __fsub_rn(gx, F.tx), dy = __fsub_rn(gy, F.ty);
-  p0x = fmaf(F.c, dx, __fmul_rn(F.s, dy));
-  p0y = fmaf(F.c, dy, -__fmul_rn(F.s, dx));
-  if constexpr (BF16) encode_tile_bf16<E>(w1, wls, vec, w6, b6, p0x, p0y, lane, mu);
-  else encode_tile_stream<E>(w1, wls, vec, w6, b6, p0x, p0y, lane, mu);
-  lx = 0.f; ly = 0.f; dist = 0.f;
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    lx = fmaf(F.rg[0][e], mu[e], lx);
-    ly = fmaf(F.rg[1][e], mu[e], ly);
-    float tmp = __fsub_rn(fmaf(P.G[e][0], p0x, __fmul_rn(P.G[e][1], p0y)), P.h[e]);
-    dist = fmaf(mu[e], tmp, dist);
-  }
-}
-
-__device__ __forceinline__ void load_weights(const float* __restrict__ wpack, int lane, WaveWeights& W) {
-  W.w1 = wpack[WP_W1 + lane];
-#pragma unroll
-  for (int l = 0; l < 4; ++l)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) W.wl[l][r] = wpack[WP_WL + (l * 16 + r) * 64 + lane];
-}
-
-// ---- launch 1: distance key of every point of every slice -----------------------------------------
-// tile id -> (scene, slice, tile in slice); tiles_per_slice = key_stride/32
-// WAVES = waves per workgroup.  4: five workgroups per CU (<= 96 VGPRs).  16: ONE workgroup per CU,
-// 4 waves per SIMD at <= 72 VGPRs and a single LDS copy of the weight fragments, which leaves room
-// (216 VGPRs per SIMD, 130 KB LDS) for a QP workgroup of another batch to be co-resident.
-template <int E, int SPLIT, int WAVES>
-__global__ __attribute__((amdgpu_flat_work_group_size(64 * WAVES, 64 * WAVES), amdgpu_waves_per_eu(WAVES >= 8 ? 7 : 4)))
-void dune_kernel(
-    DevParams P, const float* __restrict__ wpack, int n_stride, const float* __restrict__ cur_s,
-    const float* __restrict__ points, const float* __restrict__ vel, const int* __restrict__ n_points,
-    const int* __restrict__ flags, unsigned* __restrict__ gkeys, int key_stride, int scene0, int nscene, int t0,
-    int chunk, const float* __restrict__ trig) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ int wg_ticket_s;
-  int* wg_ticket = &wg_ticket_s;
-  if (threadIdx.x == 0) wg_ticket_s = 0;
-  float* vec = smem;                       // [11][32]
-  float* w6 = vec + 11 * 32;               // [8][32]
-  float* b6 = w6 + 8 * 32;                 // [8]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 31, hf = lane >> 5;
-  const int T = P.T;
-
-  for (int i = tid; i < 11 * 32 + 8 * 32 + 8; i += 64 * WAVES) smem[i] = wpack[WP_VEC + i];
-  WaveWeights W;
-  const f16x8* wbf = nullptr;
-  if constexpr (SPLIT != 0) {
-    float* wb = b6 + 8;                     // 16-byte aligned: (11*32 + 8*32 + 8) floats precede it
-    for (int i = tid; i < WP_KEY_LDS_FLOATS; i += 64 * WAVES) wb[i] = wpack[WP_BF + i];
-    wbf = reinterpret_cast<const f16x8*>(wb);
-    W.w1 = wpack[WP_KW1 + lane];
-  } else {
-    load_weights(wpack, lane, W);
-  }
-  __syncthreads();                          // the only workgroup barrier: vectors / fragments staged
-
-  const int nsl = T + 1 - t0;
-  const int tps = key_stride >> 5;                          // tiles per slice
-  const int total = nscene * nsl * tps;                     // < 2^31: checked by the launcher
-  // Work distribution: the tile stream is cut into equal contiguous ranges, one per workgroup; inside
-  // a workgroup the waves (one per SIMD) draw `chunk`-tile tickets from an LDS counter.  A purely
-  // static split per wave is balanced only while the kernel has the chip to itself: a QP wave of
-  // another batch in flight slows the DUNE waves on its SIMD by ~1.3x, and every launch would wait
-  // for those.  (Tickets from a global counter were measured: same-address device-scope atomics
-  // serialise at ~20 ns each, far too slow for 10^4 tickets per launch.)
-  const int wg_lo = (int)((long long)total * blockIdx.x / gridDim.x);
-  const int wg_hi = (int)((long long)total * (blockIdx.x + 1) / gridDim.x);
-  int g = 0, hi = 0, sl = 0, tile = 0;
-  int cur_sl = -1, n_raw = 0, n_use = 0, t = 0;
-  bool skip = false;
-  SliceFrame F;
-  const float *px_row = nullptr, *py_row = nullptr, *vx_row = nullptr, *vy_row = nullptr;
-  unsigned* key_row = nullptr;
-#pragma unroll 1
-  for (;; ++g, ++tile) {
-    if (g >= hi) {                                          // next ticket: locate it in the stream
-      int c = 0;
-      if (lane == 0) c = atomicAdd(wg_ticket, chunk);
-      g = wg_lo + __builtin_amdgcn_readfirstlane(c);
-      if (g >= wg_hi) break;
-      hi = g + chunk < wg_hi ? g + chunk : wg_hi;
-      sl = (int)((unsigned)g / (unsigned)tps);
-      tile = g - sl * tps;
-    } else if (tile == tps) {                               // ran into the next slice
-      tile = 0;
-      ++sl;
-    }
-    if (sl != cur_sl) {                                     // wave-uniform: a few times per workgroup range
-      cur_sl = sl;
-      const int bl = (int)((unsigned)sl / (unsigned)nsl), b = bl + scene0;
-      t = sl - bl * nsl + t0;
-      n_raw = n_points ? n_points[b] : n_stride;
-      n_raw = n_raw < 0 ? 0 : (n_raw > n_stride ? n_stride : n_raw);      // the documented contract, enforced
-      n_use = n_raw < P.dune_max_num ? n_raw : P.dune_max_num;
-      skip = (flags && flags[b * 4 + 0]) || n_use <= 0;     // converged scene (pan.py:144-145) / no points
-      if (!skip) {
-        load_frame<E>(P, cur_s, trig, b, t, F);
-        px_row = points + (size_t)b * 2 * n_stride;
-        py_row = px_row + n_stride;
-        vx_row = vel ? vel + (size_t)b * 2 * n_stride : nullptr;
-        vy_row = vel ? vx_row + n_stride : nullptr;
-        key_row = gkeys + ((size_t)b * (T + 1) + t) * key_stride;
-      }
-    }
-    if (skip || tile * 32 >= n_use) continue;
-    const int n = tile * 32 + j;
-    const int nc = n < n_use ? n : n_use - 1;
-    float mu[E], gx, gy, lx, ly, dist;
-    point_features<E, SPLIT>(P, F, W, wbf, vec, w6, b6, px_row, py_row, vx_row, vy_row, src_index(nc, n_raw, n_use),
-                             lane, mu, gx, gy, lx, ly, dist);
-    if (hf == 0 && n < n_use) key_row[n] = ordered_key(dist);
-  }
-}
-
-// ---- geometric distance of a robot-frame point to the robot polygon (0 inside) ---------------------------
-// min over the edges of the point-segment distance: ~12 VALU instructions per edge.  Only ever used as a KEY.
-template <int E>
-__device__ __forceinline__ float geo_dist(const DevParams& P, float x, float y) {
-  if (P.geo_rect) {                          // wave-uniform: distance to an axis-aligned box, ~8 instructions
-    const float dx = fmaxf(fabsf(x - P.rcx) - P.rhx, 0.f), dy = fmaxf(fabsf(y - P.rcy) - P.rhy, 0.f);
-    return __builtin_sqrtf(fmaf(dx, dx, dy * dy));
-  }
-  float best = 3.0e38f;
-  bool inside = true;
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const float rx = x - P.pvx[e], ry = y - P.pvy[e];
-    inside = inside && (fmaf(P.pdy[e], rx, -(P.pdx[e] * ry)) <= 0.f);     // G_e . p - h_e with G_e = (dy, -dx)
-    float t = fmaf(rx, P.pdx[e], ry * P.pdy[e]) * P.pil[e];
-    t = fminf(fmaxf(t, 0.f), 1.f);
-    const float qx = fmaf(-t, P.pdx[e], rx), qy = fmaf(-t, P.pdy[e], ry);
-    best = fminf(best, fmaf(qx, qx, qy * qy));
-  }
-  return inside ? 0.f : __builtin_sqrtf(best);
-}
-
-// ---- launch 2: the M nearest of a slice, one wave per slice -----------------------------------------
-// GEO = true: the slice's distance keys are computed HERE from the robot polygon (no dune_kernel launch, no key
-// buffer): key = closed-form distance g of the point, candidates = every point that the measured bound
-// |network distance - g| <= margin[band(g)] cannot exclude from the M nearest (below).  GEO = false: keys read from
-// gkeys (dune_kernel: reduced-precision or exact network distances).
-// LDS per slice stays < 9 KB at 1000 points so that all (T+1) slices of a CU's scenes are resident.
-#define SEL_CAP 64                               // candidates the final exact ranking holds (two 32-point tiles)
-template <int E, bool GEO>
-// (four waves per SIMD -- 128 VGPRs -- up to six edges; the wider rows of E = 7, 8 spill there and stay at three)
-__global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(E <= 6 ? 4 : 3, E <= 6 ? 4 : 3))) void select_kernel(
-    DevParams P, const float* __restrict__ wpack, int n_stride, const float* __restrict__ cur_s,
-    const float* __restrict__ points, const float* __restrict__ vel, const int* __restrict__ n_points,
-    const int* __restrict__ flags, const unsigned* __restrict__ gkeys, int key_stride,
-    float* __restrict__ mu_sorted, float* __restrict__ lam_sorted, float* __restrict__ pts_sorted,
-    float* __restrict__ dist_sorted, int* __restrict__ count, int scene0, int t0, int approx_keys, float e0,
-    unsigned* __restrict__ stats, const float* __restrict__ trig) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* vec = smem;                       // [11][32]
-  float* w6 = vec + 11 * 32;               // [8][32]
-  float* b6 = w6 + 8 * 32;                 // [8]
-  float* etab = b6 + 8;                    // [NPA_GEO_BANDS] margin per distance band (GEO)
-  int* sel = reinterpret_cast<int*>(etab + NPA_GEO_BANDS);   // [SEL_CAP]: the candidates of this slice
-  unsigned* skey = reinterpret_cast<unsigned*>(sel + SEL_CAP);   // [NPA_MAX_M] keys of the msel extracted entries
-  int* lst = reinterpret_cast<int*>(skey + NPA_MAX_M);        // [64]: short list of the first extraction
-  constexpr int ROW_W = E + 5;                                // mu[E], lam[2], point[2], distance
-  unsigned* dkey = reinterpret_cast<unsigned*>(lst + 64);     // [n_use] keys; later the candidate list + their exact keys
-  // the exact rows of the final candidates take over the key area once the candidates stand in sel[] (the launcher
-  // sizes the area for whichever is larger)
-  float* rows = reinterpret_cast<float*>(dkey);               // [SEL_CAP][ROW_W]
-  unsigned* rkey = reinterpret_cast<unsigned*>(rows + SEL_CAP * (NPA_MAX_E + 5));   // [SEL_CAP][2]: (index, exact key)
-  const int t = blockIdx.x + t0, b = blockIdx.y + scene0, lane = threadIdx.x;
-  const int j = lane & 31, hf = lane >> 5;
-  const int T = P.T, M = P.M;
-  if (flags && flags[b * 4 + 0]) return;
-  int n_raw = n_points ? n_points[b] : n_stride;
-  n_raw = n_raw < 0 ? 0 : (n_raw > n_stride ? n_stride : n_raw);      // the documented contract, enforced
-  const int n_use = n_raw < P.dune_max_num ? n_raw : P.dune_max_num;
-  const size_t orow = (size_t)b * (T + 1) + t;
-  if (n_use <= 0) {
-    if (lane == 0) count[orow] = 0;
-    return;
-  }
-  for (int i = lane; i < 11 * 32 + 8 * 32 + 8; i += 64) smem[i] = wpack[WP_VEC + i];
-  if constexpr (GEO)
-    for (int i = lane; i < NPA_GEO_BANDS; i += 64) etab[i] = wpack[WP_GEO + i];
-  SliceFrame F;
-  load_frame<E>(P, cur_s, trig, b, t, F);
-  const float* px_row = points + (size_t)b * 2 * n_stride;
-  const float* py_row = px_row + n_stride;
-  const float* vx_row = vel ? vel + (size_t)b * 2 * n_stride : nullptr;
-  const float* vy_row = vel ? vx_row + n_stride : nullptr;
-  if constexpr (GEO) {
-    // Keys of every point of the slice.  Four points per lane and trip, their loads issued together: one point per
-    // trip made the pass a chain of n_use / 64 dependent memory round trips -- the longest stretch of this wave's life.
-    constexpr int KU = 4;
-    auto key_of = [&](float gx, float gy, float vx, float vy) -> unsigned {     // the point flow of point_features
-      if (vx_row) {
-        gx = __fadd_rn(gx, __fmul_rn(F.tstep, __fmul_rn(vx, P.dt32)));
-        gy = __fadd_rn(gy, __fmul_rn(F.tstep, __fmul_rn(vy, P.dt32)));
-      }
-      const float dx = __fsub_rn(gx, F.tx), dy = __fsub_rn(gy, F.ty);
-      const float p0x = fmaf(F.c, dx, __fmul_rn(F.s, dy)), p0y = fmaf(F.c, dy, -__fmul_rn(F.s, dx));
-      const bool calibrated = fmaxf(fabsf(p0x), fabsf(p0y)) <= P.geo_rcal;     // false for NaN / inf too
-      return calibrated ? __float_as_uint(geo_dist<E>(P, p0x, p0y)) : NPA_GEO_KEY_FAR;
-    };
-    for (int n0 = lane; n0 < n_use; n0 += 64 * KU) {
-      float gx[KU], gy[KU], vx[KU], vy[KU];
-#pragma unroll
-      for (int u = 0; u < KU; ++u) {
-        const int n = n0 + 64 * u;
-        const int src = src_index(n < n_use ? n : n_use - 1, n_raw, n_use);     // (clamped: a valid address, value unused)
-        gx[u] = px_row[src]; gy[u] = py_row[src];
-        vx[u] = vx_row ? vx_row[src] : 0.f; vy[u] = vy_row ? vy_row[src] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < KU; ++u) {
-        const int n = n0 + 64 * u;
-        if (n < n_use) dkey[n] = key_of(gx[u], gy[u], vx[u], vy[u]);
-      }
-    }
-  } else {
-    const unsigned* gk = gkeys + orow * key_stride;
-    for (int n = lane; n < n_use; n += 64) dkey[n] = gk[n];
-  }
-  WaveWeights W;
-  load_weights(wpack, lane, W);
-  WSYNC();
-
-  const int msel = n_use < M ? n_use : M;
-  unsigned last_key = 0;
-  auto extract = [&]() {                      // the msel smallest (key, index) pairs -> sel[0..msel), skey[0..msel)
-    for (int m = 0; m < msel; ++m) {
-      unsigned long long best = ~0ull;
-      for (int n = lane; n < n_use; n += 64) best = umin64(best, ((unsigned long long)dkey[n] << 32) | (unsigned)n);
-      best = wave_min_u64(best);
-      const int idx = (int)(best & 0xFFFFFFFFu);
-      last_key = (unsigned)(best >> 32);
-      if (lane == 0) { sel[m] = idx; skey[m] = last_key; dkey[idx] = 0xFFFFFFFFu; }
-      WSYNC();
-    }
-  };
-  // First extraction without msel full passes: the msel-th smallest of the 64 per-lane minima bounds the msel-th
-  // smallest key from above (each of those lanes holds a key that small), found by bisection on its bits (one
-  // compare + scalar popcount per bit); one more pass lists the keys up to that bound -- msel plus a few for
-  // unstructured data -- and the list is ranked in registers.  Long lists (heavy ties) take the plain loop.
-  auto extract_short = [&]() -> bool {
-    unsigned lmin = 0xFFFFFFFFu;
-    for (int n = lane; n < n_use; n += 64) lmin = min(lmin, dkey[n]);
-    unsigned bound = 0;
-    for (int bit = 31; bit >= 0; --bit) {
-      const unsigned trial = bound | ((1u << bit) - 1u);
-      if (__popcll(__ballot(lmin <= trial)) < msel) bound |= 1u << bit;
-    }
-    int L = 0;
-    for (int n0 = 0; n0 < n_use; n0 += 64) {
-      const int n = n0 + lane;
-      const bool hit = n < n_use && dkey[n] <= bound;
-      const unsigned long long bal = __ballot(hit);
-      const int pos = L + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
-      if (hit && pos < 64) lst[pos] = n;
-      L += __popcll(bal);
-    }
-    if (L > 64 || L < msel) return false;
-    WSYNC();
-    const int idx = lane < L ? lst[lane] : 0;
-    const unsigned long long v = lane < L ? (((unsigned long long)dkey[idx] << 32) | (unsigned)idx) : ~0ull;
-    int rk = 0;
-    for (int i = 0; i < L; ++i) rk += readlane_u64(v, i) < v ? 1 : 0;
-    if (lane < L && rk < msel) { sel[rk] = idx; skey[rk] = (unsigned)(v >> 32); dkey[idx] = 0xFFFFFFFFu; }
-    const unsigned long long lastb = __ballot(lane < L && rk == msel - 1);
-    last_key = (unsigned)(readlane_u64(v, (int)__builtin_ctzll(lastb)) >> 32);
-    WSYNC();
-    return true;
-  };
-  if (!extract_short()) extract();
-  // The keys decide only WHO is a candidate; the candidates are re-encoded exactly below and ranked on the exact
-  // (distance, index) key, so the emitted rows are those of an exact-key selection PROVIDED no true member of the
-  // msel nearest is left out:
-  //  * network keys (GEO = false, approx_keys): |key - exact| <= e = e0 (1 + |d|), e0 a multiple of the key error
-  //    measured for this checkpoint (key_calib_kernel): every point with key <= key_M + 2e is a candidate;
-  //  * geometric keys: exact in [g - m(g), g + m(g)], m = margin[band(g)] measured for this checkpoint
-  //    (geo_calib_kernel).  U = max over the msel smallest-g points of g + m(g) bounds the msel-th smallest EXACT
-  //    distance from above (those msel points all lie below it), so a point with g - m(g) > U cannot be among the
-  //    msel nearest.  Points outside the calibrated square (key FAR) are always candidates.
-  int ncand = msel, fellback = 0;
-  bool widen = false;
-  unsigned thr = 0;
-  float U = 0.f;
-  if constexpr (GEO) {
-    widen = n_use > msel;
-    float hi = -1.f;
-    if (lane < msel) {
-      const unsigned k = skey[lane];
-      const float g = __uint_as_float(k);
-      hi = (k == NPA_GEO_KEY_FAR) ? __builtin_inff() : g + etab[npa_geo_band(g)];
-    }
-    for (int i = 0; i < msel; ++i) U = fmaxf(U, __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hi), i)));
-  } else {
-    widen = approx_keys && msel == M && n_use > M && last_key < 0xFFFFFFFEu;
-    if (widen) {
-      const float dM = __uint_as_float((last_key & 0x80000000u) ? (last_key & 0x7FFFFFFFu) : ~last_key);
-      thr = ordered_key(dM + 2.0f * e0 * (1.0f + fabsf(dM)));
-    }
-  }
-  bool overflow = false, all = false;
-  int total = 0, extra = 0;
-  if (widen) {
-    // compact the indices of the points inside the window IN PLACE over the keys already scanned (slot <= index)
-    for (int n0 = 0; n0 < n_use; n0 += 64) {
-      const int n = n0 + lane;
-      bool hit = false;
-      if (n < n_use) {
-        const unsigned k = dkey[n];                             // extracted entries are 0xFFFFFFFF
-        if constexpr (GEO) {
-          const float g = __uint_as_float(k);
-          hit = k != 0xFFFFFFFFu && (k == NPA_GEO_KEY_FAR || g - etab[npa_geo_band(g)] <= U);
-        } else {
-          hit = k <= thr;
-        }
-      }
-      const unsigned long long bal = __ballot(hit);
-      const int pos = extra + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
-      if (hit) dkey[pos] = (unsigned)n;                         // points besides the msel extracted ones
-      extra += __popcll(bal);
-    }
-    WSYNC();
-    if (msel + extra <= SEL_CAP) {                              // the usual case: everything fits the final ranking
-      if (lane < extra) sel[msel + lane] = (int)dkey[lane];
-      ncand = msel + extra;
-      WSYNC();
-    } else {
-      // more candidates than the final ranking holds (many points within the margin of the M-th nearest: a wall at
-      // constant distance, a cluster of exact zeros inside the robot): exact keys for the candidates -- stored behind
-      // the list -- or, when the list takes more than half the slice, for the whole slice; then the msel smallest again
-      overflow = true;
-      fellback = 1;
-      all = 2 * extra + msel > n_use;
-      total = all ? n_use : msel + extra;
-    }
-  }
-  unsigned* ckey = dkey + extra;                                // [total] exact keys of the candidates (compact form)
-  auto cand_index = [&](int q) { return all ? q : (q < msel ? sel[q] : (int)dkey[q - msel]); };
-  // Exact re-encoding.  Phase 0 (overflow only): exact KEYS of the long candidate list, then the msel smallest of
-  // them become the candidates.  Phase 1: the final candidates (<= SEL_CAP, two tiles at most) with their ROWS
-  // parked in LDS; they are ranked on the exact (distance, index) key and the msel nearest are emitted as sorted
-  // rows.  ONE call site of the encoder for both (its 65 weight registers + 16 accumulators leave no room for a
-  // second inlined copy inside 128 VGPRs).
-#pragma unroll 1
-  for (int phase = overflow ? 0 : 1;; phase = 1) {
-    const int cnt = phase == 0 ? total : ncand;
-#pragma unroll 1
-    for (int q0 = 0; q0 < cnt; q0 += 32) {
-      const int q = q0 + j, qc = q < cnt ? q : cnt - 1;
-      const int idx = phase == 0 ? cand_index(qc) : sel[qc];
-      float mu[E], gx, gy, lx, ly, dist;
-      point_features<E, 0>(P, F, W, nullptr, vec, w6, b6, px_row, py_row, vx_row, vy_row,
-                           src_index(idx, n_raw, n_use), lane, mu, gx, gy, lx, ly, dist);
-      if (hf == 0 && q < cnt) {
-        const unsigned k = ordered_key(dist);
-        if (phase == 0) {
-          if (all) dkey[idx] = k;
-          else ckey[q] = k;
-        } else {
-          float* r = rows + q * ROW_W;
-#pragma unroll
-          for (int e = 0; e < E; ++e) r[e] = mu[e];
-          r[E] = lx; r[E + 1] = ly; r[E + 2] = gx; r[E + 3] = gy; r[E + 4] = dist;
-          rkey[2 * q] = (unsigned)idx; rkey[2 * q + 1] = k;
-        }
-      }
-    }
-    WSYNC();
-    if (phase == 1) break;
-    if (stats && lane == 0) atomicAdd(stats, (unsigned)((total + 31) / 32));
-    if (all) {
-      extract();
-    } else {
-      // the msel smallest exact (key, index) pairs among the candidates; lane m keeps the m-th winner
-      int mywin = 0;
-      for (int m2 = 0; m2 < msel; ++m2) {
-        unsigned long long best = ~0ull;
-        int bq = -1;
-        for (int q = lane; q < total; q += 64) {
-          const unsigned long long v = ((unsigned long long)ckey[q] << 32) | (unsigned)cand_index(q);
-          if (v < best) { best = v; bq = q; }
-        }
-        const unsigned long long win = wave_min_u64(best);
-        if (best == win && bq >= 0) ckey[bq] = 0xFFFFFFFFu;     // (key, index) pairs are distinct: one lane retires it
-        if (lane == m2) mywin = (int)(win & 0xFFFFFFFFu);
-        WSYNC();
-      }
-      if (lane < msel) sel[lane] = mywin;                       // sel[] was read through cand_index until here
-      WSYNC();
-    }
-    ncand = msel;
-  }
-  // lane q speaks for candidate q: rank on the exact (distance, index) key, emit; rows >= msel replicate row 0
-  const bool mine = lane < ncand;
-  const unsigned long long kx = mine ? (((unsigned long long)rkey[2 * lane + 1] << 32) | rkey[2 * lane]) : ~0ull;
-  int rank = 0;
-  for (int i = 0; i < ncand; ++i) rank += readlane_u64(kx, i) < kx ? 1 : 0;
-  if (mine && rank < msel) {
-    const float* r = rows + lane * ROW_W;
-    auto put = [&](int q) {
-      const size_t o = orow * M + q;
-#pragma unroll
-      for (int e = 0; e < E; ++e) mu_sorted[o * E + e] = r[e];
-      lam_sorted[o * 2 + 0] = r[E]; lam_sorted[o * 2 + 1] = r[E + 1];
-      pts_sorted[o * 2 + 0] = r[E + 2]; pts_sorted[o * 2 + 1] = r[E + 3];
-      dist_sorted[o] = r[E + 4];
-    };
-    put(rank);
-    if (rank == 0)                          // the nearest row also fills rows >= msel: the padding rule of nrmp.py:258-259
-      for (int q = msel; q < M; ++q) put(q);
-  }
-  if (lane == 0) count[orow] = approx_keys == 2 ? (msel | (ncand << 8) | (fellback << 16)) : msel;
-}
-
-// ---- launch 2, geometric keys, second form --------------------------------------------------------------------
-// Same contract as select_kernel<E, true> (one wave per slice, keys from the closed-form distance g to the robot polygon,
-// every point the measured bound |network distance - g| <= margin[band(g)] cannot exclude from the M nearest becomes a
-// candidate, candidates re-encoded exactly and ranked on the exact (distance, index) key), built around what the first
-// form's instruction census showed:
-//  * key pass: strided buffer loads (32-bit offsets + immediates, out-of-range lanes read 0: no 64-bit address
-//    arithmetic, no clamping), v_sqrt_f32 instead of the correctly rounded sqrt expansion (the key only nominates), the
-//    lane minimum folded in: ~21 VALU instructions per point instead of ~60;
-//  * no exact extraction of the M smallest keys: the M-th smallest of the 64 lane minima (bisection) bounds the M-th
-//    smallest key, U = max over the lanes at or below it of g + m(g) bounds the M-th smallest EXACT distance, and the
-//    per-band rule g - m(band(g)) <= U is folded into ONE threshold g* = max over bands of min(band end, U + m(band)):
-//    the window pass is a compare per key, four keys per lane and trip (ds_read_b128);
-//  * points at or beyond g_far = (calibrated half extent - robot radius), NaN and inf keys are always candidates;
-//  * blockIdx -> (scene, slice) puts all slices of a scene on ONE XCD (workgroup w runs on XCD w % 8): the scene's
-//    cloud is fetched into one L2 instead of up to eight;
-//  * no register spills (tests/test_abi.py reads the code object).
-// Run-time audit of the bound the candidates rest on (the margin is measured, not proven):
-//  * every exactly encoded candidate is checked: |exact distance - g| <= margin[band(g)], violations counted;
-//  * a hash-selected fraction of the waves (audit_thresh / 2^32) encodes one extra tile of 32 points spread over the slice
-//    -- mostly NON-candidates -- and checks the same bound on them;
-//  * once the violation counter is non-zero every wave treats ALL points as candidates (exact keys for the whole slice:
-//    slow and right) until the host has looked (npa_audit_read) -- a wrong margin cannot keep producing wrong plans;
-//  * the violation count is mirrored into pinned host memory (npa_audit_peek: no device synchronisation to poll it).
-__device__ __forceinline__ float dpp_f32_b1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false)); }
-__device__ __forceinline__ float wave_max_f32(float v) {
-  v = fmaxf(v, dpp_f32_b1(v));
-  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false)));
-  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false)));
-  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false)));
-  auto rl = [&](int l) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l)); };
-  return fmaxf(fmaxf(rl(0), rl(16)), fmaxf(rl(32), rl(48)));
-}
-// geometric key of a robot-frame point: v_sqrt_f32 (1 ulp) -- nominates only.  RECT: the axis-aligned box form.
-template <int E, bool RECT>
-__device__ __forceinline__ float geo_key_t(const DevParams& P, float x, float y) {
-  if constexpr (RECT) {
-    const float dx = fmaxf(fabsf(x - P.rcx) - P.rhx, 0.f), dy = fmaxf(fabsf(y - P.rcy) - P.rhy, 0.f);
-    return __builtin_amdgcn_sqrtf(fmaf(dx, dx, dy * dy));
-  } else {
-    float best = 3.0e38f;
-    bool inside = true;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const float rx = x - P.pvx[e], ry = y - P.pvy[e];
-      inside = inside && (fmaf(P.pdy[e], rx, -(P.pdx[e] * ry)) <= 0.f);
-      float t = fmaf(rx, P.pdx[e], ry * P.pdy[e]) * P.pil[e];
-      t = fminf(fmaxf(t, 0.f), 1.f);
-      const float qx = fmaf(-t, P.pdx[e], rx), qy = fmaf(-t, P.pdy[e], ry);
-      best = fminf(best, fmaf(qx, qx, qy * qy));
-    }
-    return inside ? 0.f : __builtin_amdgcn_sqrtf(best);
-  }
-}
-template <int E>
-__device__ __forceinline__ float geo_key(const DevParams& P, float x, float y) {
-  return P.geo_rect ? geo_key_t<E, true>(P, x, y) : geo_key_t<E, false>(P, x, y);
-}
-
-#define SEL2_TRIP 256                            // points per trip of the key pass (4 per lane)
-// key pass of select_geo_kernel: dkey[n] = bits of g(point n) (0xFFFFFFFF behind the slice's end); returns the lane's
-// smallest key.  The wave-uniform cases (box or polygon, moving points, decimation) are template parameters: inside
-// the loop they were branches on spilled scalars plus both arms of the point flow.
-template <int E, bool RECT, bool VEL, bool DEC>
-__device__ __forceinline__ unsigned key_pass(const DevParams& P, const SliceFrame& F, const float* px_row, const float* py_row,
-                                             const float* vx_row, const float* vy_row, unsigned* dkey, int n_raw, int n_use,
-                                             int n_pad, int lane) {
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(px_row), 0, n_raw * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(py_row), 0, n_raw * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rvx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(VEL ? vx_row : px_row), 0, n_raw * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rvy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(VEL ? vy_row : py_row), 0, n_raw * 4, 0x00020000);
-  const float tdt = F.tstep;
-  unsigned lmin = 0xFFFFFFFFu;
-  for (int n0 = 0; n0 < n_pad; n0 += SEL2_TRIP) {
-    float gx[4], gy[4], vx[4], vy[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int n = n0 + lane + 64 * u;
-      unsigned off = (unsigned)n * 4u;                 // (reads behind n_raw return 0: the key is discarded below)
-      if constexpr (DEC) off = (unsigned)src_index(n < n_use ? n : n_use - 1, n_raw, n_use) * 4u;
-      gx[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
-      gy[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, off, 0, 0));
-      if constexpr (VEL) {
-        vx[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rvx, off, 0, 0));
-        vy[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rvy, off, 0, 0));
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int n = n0 + lane + 64 * u;
-      float x = gx[u], y = gy[u];
-      if constexpr (VEL) {      // pan.py:182 (the reference's rounding order: the kept rows recompute it the same way)
-        x = __fadd_rn(x, __fmul_rn(tdt, __fmul_rn(vx[u], P.dt32)));
-        y = __fadd_rn(y, __fmul_rn(tdt, __fmul_rn(vy[u], P.dt32)));
-      }
-      const float dx = x - F.tx, dy = y - F.ty;
-      const float p0x = fmaf(F.c, dx, F.s * dy), p0y = fmaf(F.c, dy, -(F.s * dx));
-      unsigned k = __float_as_uint(geo_key_t<E, RECT>(P, p0x, p0y));
-      k = n < n_use ? k : 0xFFFFFFFFu;
-      dkey[n] = k;
-      lmin = min(lmin, k);
-    }
-  }
-  return lmin;
-}
-
-#define SEL2_TRIP 256                            // points per trip of the key pass (4 per lane)
-// -DNPA_SEL_PROF: s_memtime stamps between the phases of a wave, summed over all waves in npa_sel_prof[] (slot 15 counts
-// the waves); tests/tools/select_phase_cycles.py builds that variant next to the product library and reads it back
-#ifdef NPA_SEL_PROF
-#define SELP_WAVES 4096
-__device__ unsigned long long npa_sel_prof[SELP_WAVES][16];     // one row per workgroup index: no atomics, nothing shared between waves
-extern "C" int npa_dbg_sel_prof(unsigned long long* out16, int reset) {
-  static unsigned long long host[SELP_WAVES][16];
-  if (out16) {
-    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(npa_sel_prof), sizeof(host)) != hipSuccess) return -1;
-    for (int i = 0; i < 16; ++i) { out16[i] = 0; for (int w = 0; w < SELP_WAVES; ++w) out16[i] += host[w][i]; }
-  }
-  if (reset) {
-    memset(host, 0, sizeof(host));
-    if (hipMemcpyToSymbol(HIP_SYMBOL(npa_sel_prof), host, sizeof(host)) != hipSuccess) return -1;
-  }
-  return 0;
-}
-#define SELP_DECL unsigned long long spt_ = __builtin_amdgcn_s_memtime(), sacc_[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long sp0_ = spt_
-#define SELP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); sacc_[i] += n_ - spt_; spt_ = n_; } while (0)
-#else
-#define SELP_DECL
-#define SELP(i)
-#endif
-template <int E, bool BF16 = false>
-__global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(E <= 6 ? 4 : 3, E <= 6 ? 4 : 3))) void select_geo_kernel(
-    DevParams P, const float* __restrict__ wpack, int n_stride, const float* __restrict__ cur_s,
-    const float* __restrict__ points, const float* __restrict__ vel, const int* __restrict__ n_points,
-    const int* __restrict__ flags, float* __restrict__ mu_sorted, float* __restrict__ lam_sorted,
-    float* __restrict__ pts_sorted, float* __restrict__ dist_sorted, int* __restrict__ count, int scene0, int t0, int nsl,
-    int nscene, int debug, unsigned* __restrict__ stats, const float* __restrict__ trig, unsigned* __restrict__ audit,
-    unsigned audit_thresh, unsigned audit_seed, float margin_scale) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* vec = smem;                       // [11][32]
-  float* w6 = vec + 11 * 32;               // [8][32]
-  float* b6 = w6 + 8 * 32;                 // [8]
-  float* etab = b6 + 8;                    // [NPA_GEO_BANDS] margin per distance band
-  int* sel = reinterpret_cast<int*>(etab + NPA_GEO_BANDS);   // [SEL_CAP]: the candidates of the final ranking
-  unsigned* skey = reinterpret_cast<unsigned*>(sel + SEL_CAP);   // [NPA_MAX_M] scratch of extract()
-  constexpr int ROW_W = E + 5;                                // mu[E], lam[2], point[2], distance
-  unsigned* dkey = reinterpret_cast<unsigned*>(skey + NPA_MAX_M);   // [n_use padded to SEL2_TRIP] keys; then the candidate list
-  float* rows = reinterpret_cast<float*>(dkey);               // [SEL_CAP][ROW_W] (takes over the key area once sel[] stands)
-  unsigned* rkey = reinterpret_cast<unsigned*>(rows + SEL_CAP * (NPA_MAX_E + 5));   // [SEL_CAP][2]: (index, exact key)
-  const int lane = threadIdx.x, j = lane & 31, hf = lane >> 5;
-  SELP_DECL;
-  // workgroup w runs on XCD w % 8 (observed dispatch order; a speed assumption only): scene = 8 * (w / (8 nsl)) + w % 8
-  const int w = blockIdx.x, xcd = w & 7, r_ = w >> 3;
-  const int bl = (r_ / nsl) * 8 + xcd;
-  if (bl >= nscene) return;
-  const int t = r_ % nsl + t0, b = bl + scene0;
-  const int T = P.T, M = P.M;
-  if (flags && flags[b * 4 + 0]) return;
-  npa_setprio(P.prio_sel);
-  int n_raw = n_points ? n_points[b] : n_stride;
-  n_raw = n_raw < 0 ? 0 : (n_raw > n_stride ? n_stride : n_raw);
-  const int n_use = n_raw < P.dune_max_num ? n_raw : P.dune_max_num;
-  const size_t orow = (size_t)b * (T + 1) + t;
-  if (n_use <= 0) {
-    if (lane == 0) count[orow] = 0;
-    return;
-  }
-  // the preamble's loads as ONE batch (written as loops they compiled to a load -> wait -> LDS write per trip: twelve global
-  // round trips in series, 18 % of a wave's life -- profiles/r04_select_phase_cycles.txt)
-  constexpr int NVEC = 11 * 32 + 8 * 32 + 8, NVT = (NVEC + 63) / 64, NGT = (NPA_GEO_BANDS + 63) / 64;
-  float pre_v[NVT], pre_g[NGT];
-#pragma unroll
-  for (int i = 0; i < NVT; ++i) { const int k = lane + 64 * i; pre_v[i] = wpack[WP_VEC + (k < NVEC ? k : NVEC - 1)]; }
-#pragma unroll
-  for (int i = 0; i < NGT; ++i) { const int k = lane + 64 * i; pre_g[i] = wpack[WP_GEO + (k < NPA_GEO_BANDS ? k : NPA_GEO_BANDS - 1)]; }
-  unsigned aud_viol = 0, aud_launches = 0;
-  if (audit) {
-    aud_viol = __hip_atomic_load(audit + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    aud_launches = __hip_atomic_load(audit + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  const float w1 = wpack[WP_W1 + lane];
-  SliceFrame F;
-  load_frame<E>(P, cur_s, trig, b, t, F);
-#pragma unroll
-  for (int i = 0; i < NVT; ++i) { const int k = lane + 64 * i; if (k < NVEC) smem[k] = pre_v[i]; }
-#pragma unroll
-  for (int i = 0; i < NGT; ++i) { const int k = lane + 64 * i; if (k < NPA_GEO_BANDS) etab[k] = pre_g[i] * margin_scale; }
-  const float* px_row = points + (size_t)b * 2 * n_stride;
-  const float* py_row = px_row + n_stride;
-  const float* vx_row = vel ? vel + (size_t)b * 2 * n_stride : nullptr;
-  const float* vy_row = vel ? vx_row + n_stride : nullptr;
-  const bool has_vel = vel != nullptr, decim = n_use < n_raw;
-  // a violation seen by an earlier launch (or an earlier wave of this one): everything is a candidate from here on
-  const bool distrust = audit && __builtin_amdgcn_readfirstlane((int)aud_viol) != 0;
-  const unsigned far_thr = __float_as_uint(P.geo_far);
-  SELP(0);
-
-  // ---- key pass: dkey[n] = bits of g(point n) (0xFFFFFFFF behind the slice's end), lane minimum on the way ----------
-  const int n_pad = (n_use + SEL2_TRIP - 1) & ~(SEL2_TRIP - 1);
-  unsigned lmin;
-#define KP(R_, V_, D_) lmin = key_pass<E, R_, V_, D_>(P, F, px_row, py_row, vx_row, vy_row, dkey, n_raw, n_use, n_pad, lane)
-  if (P.geo_rect && E == 4) {
-    if (has_vel) { if (decim) KP(true, true, true); else KP(true, true, false); }
-    else { if (decim) KP(true, false, true); else KP(true, false, false); }
-  } else {
-    if (has_vel) { if (decim) KP(false, true, true); else KP(false, true, false); }
-    else { if (decim) KP(false, false, true); else KP(false, false, false); }
-  }
-#undef KP
-  const float* wls = wpack + (BF16 ? WP_WB16 : WP_WLS);
-  WSYNC();
-  SELP(1);
-
-  const int msel = n_use < M ? n_use : M;
-  // msel-th smallest of the 64 lane minima: an upper bound of the msel-th smallest key (each of those lanes holds a key
-  // that small; consecutive points sit in different lanes, so a run of near points -- a scan of one obstacle -- does not
-  // loosen it).  Fewer than msel lanes with a point (tiny slices): the bound is 0xFFFFFFFF and everything is a candidate.
-  unsigned bound = 0;
-  for (int bit = 31; bit >= 0; --bit) {
-    const unsigned trial = bound | ((1u << bit) - 1u);
-    if (__popcll(__ballot(lmin <= trial)) < msel) bound |= 1u << bit;
-  }
-  float hi = 0.f;
-  if (lmin <= bound) {
-    const float g = __uint_as_float(lmin);
-    hi = (lmin >= far_thr) ? __builtin_inff() : g + etab[npa_geo_band(g)];       // (NaN keys are >= far_thr as bits)
-  }
-  const float U = wave_max_f32(hi);
-  // one threshold for the window: a point of band b is a candidate iff g <= U + m[b]; g* = the largest such g over the
-  // bands below g_far (a superset of the per-band rule: a band's points between U + m[b] and g* come along)
-  unsigned thr = 0xFFFFFFFEu;
-  if (!distrust && U < 3.0e38f) {
-    float gs = 0.f;
-#pragma unroll
-    for (int rep = 0; rep < 2; ++rep) {
-      const int bnd = lane + 64 * rep;
-      if (bnd < NPA_GEO_BANDS) {
-        const float lo_b = __uint_as_float((unsigned)(bnd + (0x3E800000u >> 20)) << 20) - 0.25f;
-        const float hi_b = bnd == NPA_GEO_BANDS - 1 ? P.geo_far : __uint_as_float((unsigned)(bnd + 1 + (0x3E800000u >> 20)) << 20) - 0.25f;
-        const float reach = U + etab[bnd];
-        if (lo_b < P.geo_far && lo_b <= reach) gs = fmaxf(gs, fminf(hi_b, reach));
-      }
-    }
-    gs = wave_max_f32(gs);
-    thr = gs < 3.0e38f ? __float_as_uint(gs) : 0xFFFFFFFEu;
-  }
-  SELP(2);
-  // ---- window pass: indices of the candidates, compacted IN PLACE over the keys already scanned ----------------------
-  int ntot = 0;
-  for (int n0 = 0; n0 < n_pad; n0 += SEL2_TRIP) {
-    const uint4 k4 = *reinterpret_cast<const uint4*>(dkey + n0 + 4 * lane);
-    const unsigned kk[4] = {k4.x, k4.y, k4.z, k4.w};
-    bool hit[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) hit[u] = kk[u] <= thr || (kk[u] - far_thr) < (0xFFFFFFFFu - far_thr);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const unsigned long long bal = __ballot(hit[u]);
-      const int pos = ntot + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
-      if (hit[u]) dkey[pos] = (unsigned)(n0 + 4 * lane + u);
-      ntot += __popcll(bal);
-    }
-  }
-  WSYNC();
-  SELP(3);
-  int ncand = ntot, fellback = 0;
-  bool overflow = false, all = false;
-  int total = 0;
-  if (ntot <= SEL_CAP && ntot >= msel) {
-    if (lane < ntot) sel[lane] = (int)dkey[lane];
-    WSYNC();
-  } else if (ntot < msel) {
-    // cannot happen while the threshold covers the nominating lanes' own minima (it does, by construction); if it ever
-    // did, exact keys for the whole slice are the answer, not fewer rows than promised
-    overflow = true; fellback = 1; all = true; total = n_use;
-  } else {
-    // more candidates than the final ranking holds (a wall at constant distance, a blob inside the robot, a distrusted
-    // margin): exact keys for the list -- stored behind it -- or, when it takes more than half the slice, for every point
-    overflow = true;
-    fellback = 1;
-    all = 2 * ntot > n_use;
-    total = all ? n_use : ntot;
-  }
-  unsigned* ckey = dkey + ntot;
-  auto cand_index = [&](int q) { return all ? q : (int)dkey[q]; };
-  auto extract = [&]() {                      // the msel smallest (key, index) pairs of dkey[0..n_use) -> sel[0..msel)
-    for (int m = 0; m < msel; ++m) {
-      unsigned long long best = ~0ull;
-      for (int n = lane; n < n_use; n += 64) best = umin64(best, ((unsigned long long)dkey[n] << 32) | (unsigned)n);
-      best = wave_min_u64(best);
-      const int idx = (int)(best & 0xFFFFFFFFu);
-      if (lane == 0) { sel[m] = idx; skey[m] = (unsigned)(best >> 32); dkey[idx] = 0xFFFFFFFFu; }
-      WSYNC();
-    }
-  };
-  // which waves run the extra audit tile: a hash of (launch, scene, slice).  The launch number is the host's sequence
-  // number plus a device-side count of launches (audit[4], bumped by workgroup 0): a launch replayed from a HIP graph
-  // carries a frozen host number, and should still audit other waves and other points each time
-  bool audit_wave = false;
-  if (audit && audit_thresh) {
-    audit_seed += (unsigned)__builtin_amdgcn_readfirstlane((int)aud_launches);
-    if (blockIdx.x == 0 && lane == 0) atomicAdd(audit + 4, 1u);
-    unsigned hsh = (audit_seed * 0x9E3779B1u) ^ ((unsigned)b * 0x85EBCA77u) ^ ((unsigned)t * 0xC2B2AE3Du);
-    hsh ^= hsh >> 15; hsh *= 0x2C1B3C6Du; hsh ^= hsh >> 12; hsh *= 0x297A2D39u; hsh ^= hsh >> 15;
-    audit_wave = hsh < audit_thresh || audit_thresh == 0xFFFFFFFFu;
-  }
-  // Stage 0 (overflow only): exact KEYS of the long list, the msel smallest become the candidates.  Stage 1: the final
-  // candidates (<= SEL_CAP) with their ROWS parked in LDS, ranked and emitted.  Stage 2 (audit waves): 32 points spread
-  // over the slice, bound check only.  ONE call site of the encoder for all three.
-  int viol = 0;
-  float worst = 0.f;
-  SELP(4);
-#pragma unroll 1
-  for (int stage = overflow ? 0 : 1;;) {
-    const int cnt = stage == 0 ? total : (stage == 1 ? ncand : (n_use < 32 ? n_use : 32));
-#pragma unroll 1
-    for (int q0 = 0; q0 < cnt; q0 += 32) {
-      const int q = q0 + j, qc = q < cnt ? q : cnt - 1;
-      int idx;
-      if (stage == 0) idx = cand_index(qc);
-      else if (stage == 1) idx = sel[qc];
-      else {                                  // audit tile: 32 points n_use / 32 apart, the phase moves with the launch
-        const int step = n_use >> 5;
-        idx = step > 0 ? qc * step + (int)((audit_seed + (unsigned)t) % (unsigned)step) : qc;
-      }
-      float mu[E], gx, gy, lx, ly, dist, p0x, p0y;
-      point_features_stream<E, BF16>(P, F, w1, wls, vec, w6, b6, px_row, py_row, vx_row, vy_row,
-                               src_index(idx, n_raw, n_use), lane, mu, gx, gy, lx, ly, dist, p0x, p0y);
-      if (stage != 0 && audit) {
-        // the bound the candidates rest on, checked on every exactly encoded point: |exact - g| <= margin[band(g)]
-        const float g = geo_key<E>(P, p0x, p0y);
-        const float ex = fabsf(dist - g) - etab[npa_geo_band(g)];
-        const bool bad = hf == 0 && q < cnt && g < P.geo_far && ex > 0.f;          // (NaN distance: ex is NaN, not counted here;
-        viol += bad ? 1 : 0;                                                       //  a NaN row is a broken checkpoint, not a key matter)
-        worst = bad ? fmaxf(worst, ex) : worst;
-      }
-      if (hf == 0 && q < cnt) {
-        const unsigned k = ordered_key(dist);
-        if (stage == 0) {
-          if (all) dkey[idx] = k;
-          else ckey[q] = k;
-        } else if (stage == 1) {
-          float* r = rows + q * ROW_W;
-#pragma unroll
-          for (int e = 0; e < E; ++e) r[e] = mu[e];
-          r[E] = lx; r[E + 1] = ly; r[E + 2] = gx; r[E + 3] = gy; r[E + 4] = dist;
-          rkey[2 * q] = (unsigned)idx; rkey[2 * q + 1] = k;
-        }
-      }
-    }
-    WSYNC();
-    if (stage == 0) SELP(5); else if (stage == 1) SELP(6); else SELP(7);     // exact keys of a long list / the candidates' rows / audit tile
-    if (stage == 2) break;
-    if (stage == 1) {
-      // lane q speaks for candidate q: rank on the exact (distance, index) key, emit; rows >= msel replicate row 0
-      const bool mine = lane < ncand;
-      const unsigned long long kx = mine ? (((unsigned long long)rkey[2 * lane + 1] << 32) | rkey[2 * lane]) : ~0ull;
-      int rank = 0;
-      for (int i = 0; i < ncand; ++i) rank += readlane_u64(kx, i) < kx ? 1 : 0;
-      if (mine && rank < msel) {
-        const float* r = rows + lane * ROW_W;
-        auto put = [&](int q) {
-          const size_t o = orow * M + q;
-#pragma unroll
-          for (int e = 0; e < E; ++e) mu_sorted[o * E + e] = r[e];
-          lam_sorted[o * 2 + 0] = r[E]; lam_sorted[o * 2 + 1] = r[E + 1];
-          pts_sorted[o * 2 + 0] = r[E + 2]; pts_sorted[o * 2 + 1] = r[E + 3];
-          dist_sorted[o] = r[E + 4];
-        };
-        put(rank);
-        if (rank == 0)                          // the nearest row also fills rows >= msel: the padding rule of nrmp.py:258-259
-          for (int q = msel; q < M; ++q) put(q);
-      }
-      if (lane == 0) count[orow] = debug ? (msel | ((ntot < 255 ? ntot : 255) << 8) | (fellback << 16)) : msel;
-      SELP(8);
-      if (!audit_wave) break;
-      stage = 2;
-      continue;
-    }
-    if (stats && lane == 0) atomicAdd(stats, (unsigned)((total + 31) / 32));
-    if (all) {
-      extract();
-    } else {
-      // the msel smallest exact (key, index) pairs among the candidates; lane m keeps the m-th winner
-      int mywin = 0;
-      for (int m2 = 0; m2 < msel; ++m2) {
-        unsigned long long best = ~0ull;
-        int bq = -1;
-        for (int q = lane; q < total; q += 64) {
-          const unsigned long long v = ((unsigned long long)ckey[q] << 32) | (unsigned)cand_index(q);
-          if (v < best) { best = v; bq = q; }
-        }
-        const unsigned long long win = wave_min_u64(best);
-        if (best == win && bq >= 0) ckey[bq] = 0xFFFFFFFFu;     // (key, index) pairs are distinct: one lane retires it
-        if (lane == m2) mywin = (int)(win & 0xFFFFFFFFu);
-        WSYNC();
-      }
-      if (lane < msel) sel[lane] = mywin;                       // the list was read through cand_index until here
-      WSYNC();
-    }
-    ncand = msel;
-    stage = 1;
-    SELP(9);
-  }
-  if (audit) {
-    const unsigned long long vb = __ballot(viol > 0);
-    if (vb != 0ull) {                          // rare: the counters are touched only then (and by audit waves)
-      int v = viol;
-      float wv = worst;
-      for (int o = 32; o > 0; o >>= 1) { v += __shfl_xor(v, o, 64); wv = fmaxf(wv, __shfl_xor(wv, o, 64)); }
-      if (lane == 0) {
-        atomicAdd(audit + 2, (unsigned)v); atomicMax(audit + 3, __float_as_uint(wv));
-        // mirror for the host: words 6, 7 of the block hold a pointer to a pinned, host-mapped counter (or null).  The owner
-        // polls it without synchronising the device (npa_audit_peek); only this rare path ever writes across the bus
-        unsigned* hp = *reinterpret_cast<unsigned* const*>(audit + 6);
-        if (hp) __hip_atomic_fetch_add(hp, (unsigned)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
-    if (audit_wave && lane == 0) { atomicAdd(audit + 0, 1u); atomicAdd(audit + 1, (unsigned)(n_use < 32 ? n_use : 32)); }
-  }
-  SELP(10);
-#ifdef NPA_SEL_PROF
-  if (lane == 0 && blockIdx.x < SELP_WAVES) {
-    unsigned long long* row = npa_sel_prof[blockIdx.x];
-    row[15] += 1ull;
-    row[14] += (unsigned long long)__builtin_amdgcn_s_memtime() - sp0_;
-#pragma unroll
-    for (int i = 0; i < 11; ++i) row[i] += sacc_[i];
-  }
-#endif
-}
+#include "dune_device.h"
 
 // ---- host-side launchers (called from c_api.hip) --------------------------------------------------
 // t0 = first horizon slice to evaluate: slice 0 does not depend on the iterate (s(0) is pinned,
