@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libneupan_amd.so")
-SOURCES = ["dune.hip", "nrmp_qp.hip", "frontend.hip", "dune_labels.hip", "aset_reduce.hip", "c_api.hip", "serve_group.hip"]
+SOURCES = ["dune.hip", "nrmp_qp.hip", "frontend.hip", "dune_labels.hip", "aset_reduce.hip", "c_api.hip", "serve_group.hip", "pan_scene.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
          "-Wno-unused-result", "-Wno-unused-value"]
 

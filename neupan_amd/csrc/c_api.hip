@@ -135,6 +135,10 @@ struct npa_handle {
   // NPA_QP_ASET_FROM moves its first iteration.
   bool aset_auto = true, qp_generic = false;
   int aset_small_batch = 0, aset_from_iter = 4;
+  // NPA_SCENE_KERNEL=1: forward calls of at least scene_min_batch scenes run as ONE launch in which a wave keeps its scene for
+  // all K iterations (pan_scene.hip; opt-in: measured, not the default).  NPA_SCENE_MIN_BATCH moves the threshold.
+  bool scene_kernel = false;
+  int scene_min_batch = 64;
 };
 
 extern "C" const char* npa_last_error(void) { return g_err.c_str(); }
@@ -396,6 +400,8 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
   P.qp_aset = (getenv("NPA_QP_ASET") != nullptr && atoi(getenv("NPA_QP_ASET")) != 0) ? 1 : 0;
   h->aset_auto = getenv("NPA_QP_ASET") == nullptr;
   h->qp_generic = getenv("NPA_QP_GENERIC") != nullptr;
+  h->scene_kernel = getenv("NPA_SCENE_KERNEL") != nullptr && atoi(getenv("NPA_SCENE_KERNEL")) != 0;
+  if (const char* env = getenv("NPA_SCENE_MIN_BATCH")) { int v = atoi(env); if (v >= 1) h->scene_min_batch = v; }
   if (const char* env = getenv("NPA_QP_ASET_SMALL")) { int v = atoi(env); if (v >= 0) h->aset_small_batch = v; }
   if (const char* env = getenv("NPA_QP_ASET_FROM")) { int v = atoi(env); if (v >= 1) h->aset_from_iter = v; }
   P.prio_sel = 0; P.prio_qp0 = 3; P.prio_qp1 = 3; P.prio_qp2 = 3; P.prio_it1 = 1 << 30; P.prio_it2 = 1 << 30;
@@ -1012,6 +1018,55 @@ extern "C" int npa_forward_end(npa_handle* h) {
   return NPA_OK;
 }
 
+// ---- the whole forward call as one launch (pan_scene.hip), opt-in -----------------------------------------------------
+extern "C" int npa_pan_scene_supported(int E, int T, int M);
+extern "C" hipError_t npa_launch_pan_scene(const DevParams& P, const float* wpack, int batch, int n_stride, const float* points,
+                                           const float* vel, const int* n_points, float* cur_s, float* cur_u, float* cur_d,
+                                           const float* ref_s, const float* ref_us, float* mu, float* lam, float* pts,
+                                           float* dist, int* count, float* out_s, float* out_u, float* out_d, float* out_md,
+                                           int* out_iters, float* out_np, int* flags, float* state, double* qp_info,
+                                           double* warm, float* trig, int iters, int debug, unsigned* stats, unsigned* audit,
+                                           unsigned audit_thresh, unsigned audit_seed, float margin_scale, hipStream_t stream,
+                                           hipEvent_t ev_start, hipEvent_t ev_stop);
+// the pending call (begun) qualifies: the default selection (geometric keys, exact rows) and the register-resident interior-
+// point solve, nothing that needs a launch of its own between the two
+static bool scene_kernel_applies(npa_handle* h) {
+  const PendingCall& pc = h->pc;
+  const DevParams& P = h->P;
+  return h->scene_kernel && pc.active && pc.dune && pc.batch >= h->scene_min_batch && h->key_terms == 4 && !h->select_v1 &&
+         !h->rows_bf16 && !h->qp_generic && !P.qp_aset && !(h->aset_auto && pc.batch <= h->aset_small_batch) && pc.out_d &&
+         npa_pan_scene_supported(P.E, P.T, P.M) && (P.T != 20 || getenv("NPA_QP_NOSCAN_WIDE") == nullptr);
+}
+static int forward_scene_launch(npa_handle* h, int iters) {
+  std::lock_guard<std::mutex> lock(h->mu);
+  PendingCall* pc = &h->pc;
+  const DevParams& P = h->P;
+  const int batch = pc->batch;
+  const ScratchLayout L = npa_scratch_layout(batch, P.T, mdim(P), P.E, kstride(h));
+  float* ws = pc->ws;
+  EventPair* ev = next_event(h, h->ev_qp, h->n_qp);       // (profile: the one launch is booked under the solve's events)
+  const unsigned seq = h->launch_seq;
+  h->launch_seq += (unsigned)iters;
+  HIP_TRY(npa_launch_pan_scene(P, h->wpack, batch, pc->n_stride, pc->points, pc->velocities, pc->n_points, ws + L.cur_s,
+                               ws + L.cur_u, ws + L.cur_d, pc->ref_s, pc->ref_us, ws + L.mu, ws + L.lam, ws + L.pts, ws + L.dist,
+                               (int*)(ws + L.count), pc->out_s, pc->out_u, pc->out_d, pc->out_md, pc->out_iters, pc->out_np,
+                               (int*)(ws + L.flags), pc->state, (double*)(ws + L.qp_info),
+                               h->qp_warm ? (double*)(ws + L.warm) : nullptr, ws + L.trig, iters, h->sel_debug, h->sel_stats_dev,
+                               h->audit_dev, h->audit_thresh, seq, h->margin_scale, pc->stream, ev ? ev->a : nullptr,
+                               ev ? ev->b : nullptr));
+  return NPA_OK;
+}
+
+extern "C" int npa_forward_scene(npa_handle* h, int iters) {
+  if (!h) return fail(NPA_E_ARG, "npa_forward_scene: null handle");
+  if (!h->pc.active) return fail(NPA_E_ARG, "npa_forward_scene: no forward in progress on this handle");
+  if (iters <= 0) iters = h->P.K;
+  if (iters > h->P.K) return fail(NPA_E_ARG, "npa_forward_scene: more iterations than the handle's iter_num");
+  if (!scene_kernel_applies(h)) return 0;
+  const int rc = forward_scene_launch(h, iters);
+  return rc == NPA_OK ? 1 : rc;
+}
+
 extern "C" int npa_forward_batch_flags(npa_handle* h, int batch, int n_stride, const float* nom_s, const float* nom_u,
                                        const float* ref_s, const float* ref_us, const float* points,
                                        const float* velocities, const int32_t* n_points, float* out_s, float* out_u,
@@ -1023,6 +1078,9 @@ extern "C" int npa_forward_batch_flags(npa_handle* h, int batch, int n_stride, c
                              out_u, out_d, out_min_distance, out_iters, out_nrmp_points, workspace, workspace_bytes,
                              state, state_bytes, stream_, flags);
   if (rc != NPA_OK) return rc;
+  rc = npa_forward_scene(h, 0);              // 1: the whole loop went out as one launch (opt-in, pan_scene.hip); 0: not this call
+  if (rc < 0) { npa_forward_end(h); return rc; }
+  if (rc == 1) return npa_forward_end(h);
   for (int k = 0; k < h->P.K; ++k) {
     rc = npa_forward_iter(h, k);
     if (rc != NPA_OK) { npa_forward_end(h); return rc; }

@@ -366,7 +366,10 @@ class PAN(torch.nn.Module):
         lib, h = self._lib, self._h
         with torch.cuda.device(self.device):
             try:
-                for k in range(self.iter_num):
+                whole = lib.npa_forward_scene(h, 0)      # 1: the loop went out as one launch (NPA_SCENE_KERNEL=1 and the call qualifies)
+                if whole < 0:
+                    check(whole, "npa_forward_scene")
+                for k in range(0 if whole == 1 else self.iter_num):
                     rc = lib.npa_forward_iter(h, k)
                     if rc:
                         check(rc, "npa_forward_iter")

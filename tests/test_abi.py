@@ -150,6 +150,12 @@ def test_hot_kernels_have_no_spills_and_no_scratch():
     # it is an experiment on record, not the shipped path)
     qp = {n: r for n, r in res.items() if "nrmp_qp_kernel" in n and "Lb1EEv" not in n}
     assert len(qp) >= 4
+    # the opt-in scene kernel (csrc/pan_scene.hip): one wave per SIMD, and NOTHING spilled -- its 256-register build spills
+    # 54 registers and faults on the GPU; a change that brings the spill back must not ship
+    sc = [r for n, r in res.items() if n.startswith("_Z16pan_scene_kernel")]
+    assert len(sc) >= 3
+    for r in sc:
+        assert r["vgpr_spill"] == 0 and r["scratch"] == 0 and r["vgpr"] + r["agpr"] <= 512, r
     for n, r in qp.items():
         assert r["vgpr_spill"] == 0 and r["scratch"] == 0, (n, r)
         assert r["vgpr"] + r["agpr"] <= 256, (n, r)             # two waves per SIMD
