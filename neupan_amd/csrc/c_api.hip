@@ -137,7 +137,7 @@ struct npa_handle {
   int aset_small_batch = 0, aset_from_iter = 4;
   // NPA_SCENE_KERNEL=1: forward calls of at least scene_min_batch scenes run as ONE launch in which a wave keeps its scene for
   // all K iterations (pan_scene.hip; opt-in: measured, not the default).  NPA_SCENE_MIN_BATCH moves the threshold.
-  bool scene_kernel = false;
+  bool scene_kernel = false, qp_scan_wide = true;          // (qp_scan_wide: NPA_QP_NOSCAN_WIDE unset, the T = 20 instantiation the scene kernel holds)
   int scene_min_batch = 64;
 };
 
@@ -402,6 +402,7 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
   h->qp_generic = getenv("NPA_QP_GENERIC") != nullptr;
   h->scene_kernel = getenv("NPA_SCENE_KERNEL") != nullptr && atoi(getenv("NPA_SCENE_KERNEL")) != 0;
   if (const char* env = getenv("NPA_SCENE_MIN_BATCH")) { int v = atoi(env); if (v >= 1) h->scene_min_batch = v; }
+  h->qp_scan_wide = getenv("NPA_QP_NOSCAN_WIDE") == nullptr;
   if (const char* env = getenv("NPA_QP_ASET_SMALL")) { int v = atoi(env); if (v >= 0) h->aset_small_batch = v; }
   if (const char* env = getenv("NPA_QP_ASET_FROM")) { int v = atoi(env); if (v >= 1) h->aset_from_iter = v; }
   P.prio_sel = 0; P.prio_qp0 = 3; P.prio_qp1 = 3; P.prio_qp2 = 3; P.prio_it1 = 1 << 30; P.prio_it2 = 1 << 30;
@@ -1035,7 +1036,7 @@ static bool scene_kernel_applies(npa_handle* h) {
   const DevParams& P = h->P;
   return h->scene_kernel && pc.active && pc.dune && pc.batch >= h->scene_min_batch && h->key_terms == 4 && !h->select_v1 &&
          !h->rows_bf16 && !h->qp_generic && !P.qp_aset && !(h->aset_auto && pc.batch <= h->aset_small_batch) && pc.out_d &&
-         npa_pan_scene_supported(P.E, P.T, P.M) && (P.T != 20 || getenv("NPA_QP_NOSCAN_WIDE") == nullptr);
+         npa_pan_scene_supported(P.E, P.T, P.M) && (P.T != 20 || h->qp_scan_wide);
 }
 static int forward_scene_launch(npa_handle* h, int iters) {
   std::lock_guard<std::mutex> lock(h->mu);

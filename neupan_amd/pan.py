@@ -150,6 +150,9 @@ class PAN(torch.nn.Module):
                                  "there is no CPU fallback")
         self.device = torch.device(device if device is not None else "cuda")
         self._lib = _lib.load()
+        # (the library reads its knobs when the handle is created; this one also decides whether forward_batch asks for the
+        # one-launch form at all, csrc/pan_scene.hip)
+        self._scene_kernel = os.environ.get("NPA_SCENE_KERNEL", "0") not in ("", "0")
 
         G = np.asarray(robot.G, dtype=np.float32)
         h = np.asarray(robot.h, dtype=np.float32).reshape(-1)
@@ -366,7 +369,8 @@ class PAN(torch.nn.Module):
         lib, h = self._lib, self._h
         with torch.cuda.device(self.device):
             try:
-                whole = lib.npa_forward_scene(h, 0)      # 1: the loop went out as one launch (NPA_SCENE_KERNEL=1 and the call qualifies)
+                # 1: the loop went out as one launch (a handle created with NPA_SCENE_KERNEL=1, and the call qualifies)
+                whole = lib.npa_forward_scene(h, 0) if self._scene_kernel else 0
                 if whole < 0:
                     check(whole, "npa_forward_scene")
                 for k in range(0 if whole == 1 else self.iter_num):
