@@ -29,6 +29,13 @@ extern "C" hipError_t npa_launch_select_geo(const DevParams& P, const float* wpa
                                             unsigned* stats, int debug, unsigned* audit, unsigned audit_thresh,
                                             unsigned audit_seed, float margin_scale, int rows_bf16, hipStream_t stream,
                                             hipEvent_t ev_start, hipEvent_t ev_stop);
+extern "C" int npa_select_scene_supported(int E, int T);
+extern "C" hipError_t npa_launch_select_scene(const DevParams& P, const float* wpack, int batch, int scene0, int t0, int n_stride,
+                                              const float* cur_s, const float* points, const float* vel, const int* n_points,
+                                              const int* flags, const float* trig, float* mu_sorted, float* lam_sorted,
+                                              float* pts_sorted, float* dist_sorted, int* count, unsigned* stats, int debug,
+                                              unsigned* audit, unsigned audit_thresh, unsigned audit_seed, float margin_scale,
+                                              hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);
 extern "C" hipError_t npa_launch_select(const DevParams& P, const float* wpack, int batch, int scene0, int t0,
                                         int n_stride, const float* cur_s, const float* points, const float* vel,
                                         const int* n_points, const int* flags, const unsigned* gkeys,
@@ -137,6 +144,7 @@ struct npa_handle {
   int aset_small_batch = 0, aset_from_iter = 4;
   // NPA_SCENE_KERNEL=1: forward calls of at least scene_min_batch scenes run as ONE launch in which a wave keeps its scene for
   // all K iterations (pan_scene.hip; opt-in: measured, not the default).  NPA_SCENE_MIN_BATCH moves the threshold.
+  bool select_scene = false;             // NPA_SELECT_SCENE=1: the selection stage with one wave per scene and shared passes (select_scene.h)
   bool scene_kernel = false, qp_scan_wide = true;          // (qp_scan_wide: NPA_QP_NOSCAN_WIDE unset, the T = 20 instantiation the scene kernel holds)
   int scene_min_batch = 64;
 };
@@ -401,6 +409,7 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
   h->aset_auto = getenv("NPA_QP_ASET") == nullptr;
   h->qp_generic = getenv("NPA_QP_GENERIC") != nullptr;
   h->scene_kernel = getenv("NPA_SCENE_KERNEL") != nullptr && atoi(getenv("NPA_SCENE_KERNEL")) != 0;
+  h->select_scene = getenv("NPA_SELECT_SCENE") != nullptr && atoi(getenv("NPA_SELECT_SCENE")) != 0;
   if (const char* env = getenv("NPA_SCENE_MIN_BATCH")) { int v = atoi(env); if (v >= 1) h->scene_min_batch = v; }
   h->qp_scan_wide = getenv("NPA_QP_NOSCAN_WIDE") == nullptr;
   if (const char* env = getenv("NPA_QP_ASET_SMALL")) { int v = atoi(env); if (v >= 0) h->aset_small_batch = v; }
@@ -540,8 +549,10 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
     }
     h->key_safety = safety;
     if (!geo_ok && e == hipSuccess && forced != 0 && forced != 4) e = calibrate_network_keys(h, forced);
-    if (e == hipSuccess) e = hipMalloc(&h->sel_stats_dev, sizeof(unsigned));
-    if (e == hipSuccess) e = hipMemset(h->sel_stats_dev, 0, sizeof(unsigned));
+    // word 0: overflow tiles of the selection (key policy); words 1, 2: slices the scene-wide selection handed to the per-slice
+    // body / took itself (select_scene.h, NPA_SELECT_SCENE=1; npa_dbg_select_stats)
+    if (e == hipSuccess) e = hipMalloc(&h->sel_stats_dev, 4 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(h->sel_stats_dev, 0, 4 * sizeof(unsigned));
     if (e == hipSuccess) e = hipHostMalloc(&h->sel_stats_host, sizeof(unsigned), hipHostMallocDefault);
     if (e == hipSuccess) *h->sel_stats_host = 0;
     if (e == hipSuccess) e = hipMalloc(&h->audit_dev, 8 * sizeof(unsigned));       // [4]: launches seen (device side)
@@ -787,7 +798,12 @@ extern "C" int npa_dune_stage(npa_handle* h, int batch, int n_stride, const floa
     HIP_TRY(npa_launch_encode(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr,
                               (unsigned*)h->stage_cand, trig, h->n_cu, 5, h->key_terms, (hipStream_t)stream,
                               nullptr, nullptr));
-  if (geo && !h->select_v1)
+  if (geo && !h->select_v1 && h->select_scene && !h->rows_bf16 && npa_select_scene_supported(h->P.E, h->P.T))
+    HIP_TRY(npa_launch_select_scene(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr, trig,
+                                    mu_sorted, lam_sorted, pts_sorted, dist_sorted, count, h->sel_stats_dev, h->sel_debug,
+                                    h->audit_dev, h->audit_thresh, h->launch_seq++, h->margin_scale, (hipStream_t)stream,
+                                    nullptr, nullptr));
+  else if (geo && !h->select_v1)
     HIP_TRY(npa_launch_select_geo(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr, trig,
                                   mu_sorted, lam_sorted, pts_sorted, dist_sorted, count, h->sel_stats_dev, h->sel_debug,
                                   h->rows_bf16 ? nullptr : h->audit_dev, h->audit_thresh, h->launch_seq++, h->margin_scale,
@@ -975,7 +991,12 @@ extern "C" int npa_forward_iter(npa_handle* h, int k) {
                                 ev ? ev->a : nullptr, ev ? ev->b : nullptr));
     }
     EventPair* evs = next_event(h, h->ev_sel, h->n_sel);
-    if (geo && !h->select_v1)
+    if (geo && !h->select_v1 && h->select_scene && !h->rows_bf16 && npa_select_scene_supported(P.E, P.T))
+      HIP_TRY(npa_launch_select_scene(P, h->wpack, batch, 0, t0, pc->n_stride, cur_s, pc->points, pc->velocities, pc->n_points,
+                                      flags, ws + L.trig, mu, lam, pts, dist, count, h->sel_stats_dev, h->sel_debug, h->audit_dev,
+                                      h->audit_thresh, h->launch_seq++, h->margin_scale, stream, evs ? evs->a : nullptr,
+                                      evs ? evs->b : nullptr));
+    else if (geo && !h->select_v1)
       HIP_TRY(npa_launch_select_geo(P, h->wpack, batch, 0, t0, pc->n_stride, cur_s, pc->points, pc->velocities, pc->n_points,
                                     flags, ws + L.trig, mu, lam, pts, dist, count, h->sel_stats_dev, h->sel_debug,
                                     h->rows_bf16 ? nullptr : h->audit_dev, h->audit_thresh, h->launch_seq++, h->margin_scale,
@@ -1055,6 +1076,15 @@ static int forward_scene_launch(npa_handle* h, int iters) {
                                h->qp_warm ? (double*)(ws + L.warm) : nullptr, ws + L.trig, iters, h->sel_debug, h->sel_stats_dev,
                                h->audit_dev, h->audit_thresh, seq, h->margin_scale, pc->stream, ev ? ev->a : nullptr,
                                ev ? ev->b : nullptr));
+  return NPA_OK;
+}
+
+// (diagnostics, not in the header: words 1, 2 of the selection's statistics -- slices the scene-wide selection handed to the
+// per-slice body / finished itself since the handle was created; synchronises the device)
+extern "C" int npa_dbg_select_stats(npa_handle* h, unsigned out[4]) {
+  if (!h || !out || !h->sel_stats_dev) return NPA_E_ARG;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, h->sel_stats_dev, 4 * sizeof(unsigned), hipMemcpyDeviceToHost));
   return NPA_OK;
 }
 

@@ -55,6 +55,68 @@ __device__ __forceinline__ void select_geo_scene(
 #include "select_geo_body.inc"
 }
 
+#include "select_scene.h"
+
+// All slices t_first .. TT of scene b on the calling wave: the shared-pass fast path (select_scene.h) for the slices it can
+// take, the per-slice body for the rest (more candidates than the ranking holds, fewer points than rows, a distrusted margin,
+// the slices that owe an audit tile, debug statistics).
+template <int E, int TT>
+__device__ __forceinline__ void select_scene(
+    const DevParams& P, const float* wpack, int n_stride, const float* cur_s, const float* points, const float* vel,
+    const int* n_points, const int* flags, float* mu_sorted, float* lam_sorted, float* pts_sorted, float* dist_sorted, int* count,
+    int debug, unsigned* stats, const float* trig, unsigned* audit, unsigned audit_thresh, unsigned audit_seed, float margin_scale,
+    const int b, const int t_first) {
+  if (flags && __builtin_amdgcn_readfirstlane(__hip_atomic_load(flags + b * 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) return;
+  npa_setprio(P.prio_sel);
+  const int lane = threadIdx.x;
+  const unsigned todo = ((1u << (TT + 1)) - 1u) & ~((1u << t_first) - 1u);
+  unsigned slow = 0;
+  if (debug) slow = todo;
+  else {
+    if (audit && audit_thresh) {             // the slices whose wave would run an audit tile (select_geo_body.inc's hash): per-slice body
+      const unsigned seed = audit_seed + (unsigned)__builtin_amdgcn_readfirstlane(
+                                             (int)__hip_atomic_load(audit + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll 1
+      for (int t = t_first; t <= TT; ++t) {
+        unsigned hsh = (seed * 0x9E3779B1u) ^ ((unsigned)b * 0x85EBCA77u) ^ ((unsigned)t * 0xC2B2AE3Du);
+        hsh ^= hsh >> 15; hsh *= 0x2C1B3C6Du; hsh ^= hsh >> 12; hsh *= 0x297A2D39u; hsh ^= hsh >> 15;
+        if (hsh < audit_thresh || audit_thresh == 0xFFFFFFFFu) slow |= 1u << t;
+      }
+    }
+    unsigned left;
+    if (P.geo_rect && E == 4)
+      left = select_scene_fast<E, TT, true>(P, wpack, n_stride, cur_s, points, vel, n_points, mu_sorted, lam_sorted, pts_sorted,
+                                            dist_sorted, count, trig, audit, margin_scale, b, t_first, slow, lane);
+    else
+      left = select_scene_fast<E, TT, false>(P, wpack, n_stride, cur_s, points, vel, n_points, mu_sorted, lam_sorted, pts_sorted,
+                                             dist_sorted, count, trig, audit, margin_scale, b, t_first, slow, lane);
+    slow |= left;
+    if (stats && lane == 0) {                 // (words 1, 2 of the statistics: slices for the per-slice body / finished here)
+      if (slow & todo) atomicAdd(stats + 1, (unsigned)__popc(slow & todo));
+      atomicAdd(stats + 2, (unsigned)__popc(todo & ~slow));
+    }
+  }
+  slow &= todo;
+#pragma unroll 1
+  for (int t = t_first; t <= TT; ++t)
+    if (slow >> t & 1u)
+      select_geo_scene<E, false>(P, wpack, n_stride, cur_s, points, vel, n_points, flags, mu_sorted, lam_sorted, pts_sorted,
+                                 dist_sorted, count, debug, stats, trig, audit, audit_thresh, audit_seed, margin_scale, b, t);
+}
+
+// the selection stage with one wave per SCENE (npa_launch_select_scene: NPA_SELECT_SCENE=1 instead of select_geo_kernel)
+template <int E, int TT>
+__global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(3, 4)))
+void select_scene_kernel(
+    DevParams P, const float* wpack, int n_stride, const float* cur_s, const float* points, const float* vel, const int* n_points,
+    const int* flags, float* mu_sorted, float* lam_sorted, float* pts_sorted, float* dist_sorted, int* count, int scene0, int t0,
+    int nscene, int debug, unsigned* stats, const float* trig, unsigned* audit, unsigned audit_thresh, unsigned audit_seed,
+    float margin_scale) {
+  if ((int)blockIdx.x >= nscene) return;
+  select_scene<E, TT>(P, wpack, n_stride, cur_s, points, vel, n_points, flags, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count,
+                      debug, stats, trig, audit, audit_thresh, audit_seed, margin_scale, (int)blockIdx.x + scene0, t0);
+}
+
 // the NRMP step of one scene on the calling wave (the body of nrmp_qp_kernel; `return` leaves the step)
 template <int TT, int MM, bool BWD, bool SCANW, int WV, bool ASET_T>
 __device__ __forceinline__ void nrmp_qp_scene(
@@ -167,5 +229,48 @@ extern "C" hipError_t npa_launch_pan_scene(const DevParams& P, const float* wpac
   else if (P.E == 8 && P.T == 10) SCENE_LAUNCH(8, 10, 10, false);
   else SCENE_LAUNCH(4, 20, 10, true);
 #undef SCENE_LAUNCH
+  return hipGetLastError();
+}
+
+// ---- the selection stage alone, one wave per scene (same contract and arguments as npa_launch_select_geo) ----------------
+static size_t scene_select_lds(const DevParams& P, int n_stride) {
+  int n_use_max = n_stride < P.dune_max_num ? n_stride : P.dune_max_num;
+  if (n_use_max < 1) n_use_max = 1;
+  const size_t n_pad = ((size_t)n_use_max + SEL2_TRIP - 1) / SEL2_TRIP * SEL2_TRIP;
+  const size_t key_area = std::max<size_t>(n_pad * sizeof(unsigned), SEL_CAP * (NPA_MAX_E + 5 + 2) * sizeof(float));
+  const size_t slice_body = (11 * 32 + 8 * 32 + 8 + NPA_GEO_BANDS) * sizeof(float) + (SEL_CAP + NPA_MAX_M) * sizeof(int) +
+                            (key_area + 15) / 16 * 16;
+  const size_t ns = (size_t)P.T + 1;
+  const size_t fast = (11 * 32 + 8 * 32 + 8 + NPA_GEO_BANDS) * sizeof(float) + ns * 16 + ns * SCN_CAP * 2 +
+                      SCN_CHUNK * (NPA_MAX_E + 5) * sizeof(float) + SCN_CHUNK * 2 * sizeof(unsigned) + 2 * ns * sizeof(int);
+  return (std::max(slice_body, fast) + 15) / 16 * 16;
+}
+extern "C" int npa_select_scene_supported(int E, int T) { return ((E == 4 || E == 8) && T == 10) || (E == 4 && T == 20) ? 1 : 0; }
+extern "C" hipError_t npa_launch_select_scene(const DevParams& P, const float* wpack, int batch, int scene0, int t0, int n_stride,
+                                              const float* cur_s, const float* points, const float* vel, const int* n_points,
+                                              const int* flags, const float* trig, float* mu_sorted, float* lam_sorted,
+                                              float* pts_sorted, float* dist_sorted, int* count, unsigned* stats, int debug,
+                                              unsigned* audit, unsigned audit_thresh, unsigned audit_seed, float margin_scale,
+                                              hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  if (!npa_select_scene_supported(P.E, P.T)) return hipErrorInvalidValue;
+  const size_t shmem = scene_select_lds(P, n_stride);
+#define SSEL_LAUNCH(EE, TT_)                                                                                           \
+  do {                                                                                                                 \
+    static NpaDeviceOnce big_lds;                                                                                      \
+    int dev_ = 0;                                                                                                      \
+    if (shmem > 60 * 1024 && big_lds.need(&dev_)) {                                                                    \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(select_scene_kernel<EE, TT_>),                 \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                     \
+      if (e_ != hipSuccess) return e_;                                                                                 \
+      big_lds.done(dev_);                                                                                              \
+    }                                                                                                                  \
+    hipExtLaunchKernelGGL((select_scene_kernel<EE, TT_>), dim3(batch), dim3(64), shmem, stream, ev_start, ev_stop, 0, P, wpack, \
+                          n_stride, cur_s, points, vel, n_points, flags, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count, \
+                          scene0, t0, batch, debug, stats, trig, audit, audit_thresh, audit_seed, margin_scale);       \
+  } while (0)
+  if (P.E == 4 && P.T == 10) SSEL_LAUNCH(4, 10);
+  else if (P.E == 8 && P.T == 10) SSEL_LAUNCH(8, 10);
+  else SSEL_LAUNCH(4, 20);
+#undef SSEL_LAUNCH
   return hipGetLastError();
 }

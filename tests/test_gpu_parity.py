@@ -1018,3 +1018,51 @@ def test_scene_kernel_agrees_with_the_two_launch_path(cfgname, B, over):
     close(ref, res[0], (cfgname, "group member 0")); close(ref, res[1], (cfgname, "group member 1"))
     assert np.array_equal(res[0]["opt_u"].cpu().numpy(), res[1]["opt_u"].cpu().numpy())     # (the same code on the same inputs)
     assert one.audit()["violations"] == 0
+
+
+@pytest.mark.parametrize("cfgname,B", [("diff_1k_T10_K10", 96), ("dyna_4k_T10_K10", 24), ("acker_2k_T20_K15", 24), ("poly8_5k_T10_K10", 12)])
+def test_scene_wide_selection_equals_the_per_slice_selection(cfgname, B):
+    """NPA_SELECT_SCENE=1 (csrc/select_scene.h, opt-in): the selection stage with ONE wave per scene -- the keys of all slices per
+    point in one pass, the candidates of all slices in a second one, the exact encoder over candidates of several slices packed
+    into full tiles (the frame a per-lane operand), the per-slice body for what it does not take -- against select_geo_kernel
+    (one wave per slice).  The nomination differs, the rows may not: any superset of the true nearest M ranked on the exact
+    (distance, index) keys gives the same rows, bitwise -- on random clouds, moving points, the car's 21 slices, the 8-edge
+    polygon, walls / blobs (more candidates than the ranking holds: per-slice body), ragged and empty clouds, and through a
+    whole forward call."""
+    import ctypes as C
+    from gpu_helpers import make_gpu_pan, wall_batch
+    cfg = CONFIGS[cfgname]
+    old = make_gpu_pan(cfg)
+    new = _with_env({"NPA_SELECT_SCENE": "1"}, lambda: make_gpu_pan(cfg))
+    batch = make_batch(cfg, 3000, B)
+    f = new._lib.npa_dbg_select_stats
+    f.restype, f.argtypes = C.c_int, [C.c_void_p, C.POINTER(C.c_uint)]
+
+    def stats():                                   # (slices for the per-slice body, slices the fast path finished) so far
+        st = (C.c_uint * 4)()
+        assert f(new._h, st) == 0
+        return int(st[1]), int(st[2])
+    s0 = stats()                                   # (the create-time self-test ran the stage too)
+    r, e = _stage_np(new, batch), _stage_np(old, batch)
+    for k in ("mu", "lam", "pts", "dist", "count"):
+        assert np.array_equal(r[k], e[k]), k
+    s1 = stats()
+    slow, fast = s1[0] - s0[0], s1[1] - s0[1]
+    assert slow + fast == B * (cfg.T + 1) and fast > 0          # every slice went one way or the other; the fast path is used
+    if cfgname == "diff_1k_T10_K10":
+        assert fast >= 0.9 * B * (cfg.T + 1)
+        wb = wall_batch(cfg, 32)
+        r, e = _stage_np(new, wb, n_points=wb["n_points"]), _stage_np(old, wb, n_points=wb["n_points"])
+        for k in ("mu", "lam", "pts", "dist", "count"):
+            assert np.array_equal(r[k], e[k]), ("walls", k)
+        rb = make_batch(cfg, 3100, 9)
+        n_pts = np.array([0, 1, 5, 63, 64, 65, 255, 256, 257], dtype=np.int32)
+        r, e = _stage_np(new, rb, n_points=n_pts), _stage_np(old, rb, n_points=n_pts)
+        assert np.array_equal(r["count"], e["count"])
+        for k in ("mu", "lam", "pts", "dist"):
+            assert np.array_equal(r[k][1:], e[k][1:]), ("ragged", k)
+    args = [batch[k] for k in ("nom_s", "nom_u", "ref_s", "ref_us", "points")] + [batch.get("velocities")]
+    a, b = old.forward_batch(*args), new.forward_batch(*args)
+    for k in ("opt_s", "opt_u", "opt_d", "min_distance", "iters", "nrmp_points"):
+        assert np.array_equal(a[k].cpu().numpy(), b[k].cpu().numpy(), equal_nan=True), ("forward", k)
+    assert new.audit()["violations"] == 0
