@@ -156,6 +156,11 @@ def test_hot_kernels_have_no_spills_and_no_scratch():
     assert len(sc) >= 3
     for r in sc:
         assert r["vgpr_spill"] == 0 and r["scratch"] == 0 and r["vgpr"] + r["agpr"] <= 512, r
+    # the opt-in scene-wide selection (csrc/select_scene.h): three waves per SIMD, nothing spilled
+    ss = [r for n, r in res.items() if n.startswith("_Z19select_scene_kernel")]
+    assert len(ss) >= 3
+    for r in ss:
+        assert r["vgpr_spill"] == 0 and r["scratch"] == 0 and r["vgpr"] + r["agpr"] <= 168, r
     for n, r in qp.items():
         assert r["vgpr_spill"] == 0 and r["scratch"] == 0, (n, r)
         assert r["vgpr"] + r["agpr"] <= 256, (n, r)             # two waves per SIMD
