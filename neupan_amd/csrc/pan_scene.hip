@@ -11,13 +11,15 @@
 // capped by the hardware-queue budget.  Here nothing waits for another scene: a wave runs
 //     for k < K:  for t in slices: select(b, t);   solve(b);   stop?
 // on its own scene and retires; the dispatcher refills its slot from the launches queued behind.  The bodies are the very
-// statements of select_geo_kernel and nrmp_qp_kernel (textual includes), so the rows, the controls and the stop decisions are
-// bitwise those of the two-launch path (tests/test_gpu_parity.py::test_scene_kernel_equals_two_launch_path).
+// statements of select_geo_kernel and nrmp_qp_kernel (textual includes): rows, distances and iteration counts equal those of
+// the two-launch path, the controls agree to rounding (another kernel around the same statements is other machine code: a
+// solve may end a last bit away) -- tests/test_gpu_parity.py::test_scene_kernel_agrees_with_the_two_launch_path.
 //
-// What it costs: the T slices of an iteration run one after the other on ONE wave (the two-launch form spreads them over T
-// waves), and that wave holds the QP's 239 registers while it selects.  The selection body is latency-bound per slice
-// (profiles/r04_select_phase_cycles.txt), so this form is a stepping stone: its pay-off needs a selection that walks the
-// slices of a scene with shared passes.
+// What it costs, measured (profiles/r04_scene_kernel.txt): the T slices of an iteration run one after the other on ONE wave
+// (the two-launch form spreads them over T waves), and the two bodies together want 310 registers -- one wave per SIMD:
+// 387 k plans/s against 763 k.  A stepping stone: its pay-off needs the selection of select_scene.h made fast and a build
+// that fits two waves per SIMD.  This file also holds the selection stage with one wave per scene as a
+// launch of its own (select_scene_kernel, NPA_SELECT_SCENE=1).
 #include "pan_common.h"
 #include "aset_reduce.h"
 #include <hip/hip_ext.h>
