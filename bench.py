@@ -3,27 +3,36 @@
 1 GPU (per rank), batch = 256 synthetic scenes, diff robot, 1000 obstacle points, T = 10,
 K = 10 PAN iterations (iter_threshold = 0 so that exactly K run), fp32 DUNE + fp64 QP.
 
-    python bench.py [--gpus N --steps K --warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+    python bench.py [--gpus N --steps K --warmup W]          # N > 1 without a launcher: re-executes itself under
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \      torch.distributed.run
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the hot path (one forward call: K x {selection, QP}) over one batch of 256 scenes per
 rank, inputs already resident in HBM; with N > 1 ranks every rank plans its own 256 scenes (weak scaling, no
 data-path collective) and the control outputs are all-gathered over RCCL inside the timed region.  Like any
-serving loop the bench keeps `--inflight` independent batches in flight, each on its own HIP stream:
-consecutive steps are different batches of 256 scenes, and the latency-bound kernels of one batch fill the
-SIMDs the others leave idle.  Every step still executes its full K iterations inside the timed region;
-`--inflight 1` gives the strictly sequential number (also reported: single-scene latency).  Rank 0 prints ONE
-JSON line.
+serving loop the bench keeps `--inflight` independent batches in flight; `--chains C` of them (default 4) form
+one launch chain each: the steps of a chain are issued as ONE library call (npa_forward_batch_group) on ONE
+stream and every stage of theirs runs as one merged launch over all their scenes (blockIdx.y = the step).
+Every step still executes its full K iterations inside the timed region, on its own 256 scenes, its own
+buffers and its own planner state; `--chains 0` gives one stream and one launch chain per step (round 4's
+schedule), `--inflight 1` the strictly sequential number.
 
-Besides the headline the line carries (rank 0, one GPU, unless --no-extras):
+OUTPUT: the LAST stdout line is ONE compact JSON record (<= 6 KB: the contract fields, `roofline`,
+`cpu_baseline`, the parity verdicts and one figure per extra leg); the full record (per-scene listings, PMC
+dump, CPU sweep, notes) goes to bench_full.json next to this file (NPA_BENCH_FULL=path moves it).
+
+Besides the headline the record carries (rank 0, one GPU, unless --no-extras):
   extra.paths          the SAME loop with the un-pruned / fallback selections: exact fp32 network keys over every point
                        (NPA_DUNE_FP32KEYS=1: SURVEY 8(d)'s literal "encoder on every obstacle point x horizon step"), network
-                       keys with single / split fp16 products (NPA_KEY_TERMS=1 / 3: what a checkpoint that fails the
-                       calibration gate gets), each with the encoder's executed MFMA rate against its peak;
+                       keys with single / split fp16 products (NPA_KEY_TERMS=1 / 3), each with the encoder's executed MFMA
+                       rate against its peak (per launch and aggregated over the region);
   extra.uniform_cloud  SURVEY 8(d)'s uniform cloud (workload uniform_1k_T10_K10): throughput, candidates per slice, parity;
   extra.other_configs  BASELINE configs[2], [3], [4] (acker 2k T=20 K=15; 4000 moving points, 1024 scenes per step; 8-edge
-                       hull 5000 points in exact fp32 AND in the labelled bf16 tier): throughput + a 16-scene parity verdict.
+                       hull 5000 points in exact fp32 AND in the labelled bf16 tier): throughput + a 16-scene parity verdict;
+  extra.early_exit     the default loop with the reference's default iter_threshold = 0.1 (pan.py:243): plans/s and the
+                       executed PAN iterations (mean / max), SURVEY 8(d)'s second run;
+  extra.h2d_inclusive  the default loop with every step's inputs uploaded from pinned host memory on the step's own stream
+                       (the reference re-uploads the cloud every step, neupan.py:123-127): the PCIe-inclusive rate -- never `value`.
 """
 import argparse
 import contextlib
@@ -48,6 +57,7 @@ import torch  # noqa: E402
 WORKLOAD = "diff_1k_T10_K10"
 BATCH = 256
 BURST_DEFAULT = 1
+CHAINS_DEFAULT = 4
 # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table (256 CUs x 4 SIMDs, 2.4 GHz)
 PEAK_FP64_VALU_TFLOPS = 78.6
 PEAK_FP32_MFMA_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32: what the exact encoder runs on
@@ -178,19 +188,27 @@ class Loop:
                            # without time-slicing)
 
     BURST = False          # StepLoop(burst=...): set once from the command line, every Loop of the process follows it
+    CHAINS = 0             # > 0: the batches in flight form this many launch chains -- the steps of a chain share ONE stream, are
+                           # issued as one group call and run every stage as one merged launch (npa_forward_batch_group)
 
     def __init__(self, workload, batch, nfl, dev, rank=0, world=1, dist=None, env=None, graph=False, issue_threads=4,
-                 scene_index=None):
+                 scene_index=None, chains=None, over=None, h2d=False):
         from neupan_amd.scenes import CONFIGS, make_batch
         from neupan_amd.serve import ControlGatherer, StepLoop
         self.cfg = cfg = CONFIGS[workload]
         self.workload, self.batch, self.nfl, self.dev, self.world = workload, batch, nfl, dev, world
+        self.early = bool(over) and over.get("iter_threshold", 0.0) > 0
         with environ(env):
-            self.pans = [make_gpu_pan(cfg, device=dev) for _ in range(nfl)]
+            self.pans = [make_gpu_pan(cfg, device=dev, **(over or {})) for _ in range(nfl)]
+        chains = Loop.CHAINS if chains is None else chains
+        self.chains = chains = min(chains, nfl) if (chains > 0 and Loop.BURST and not graph) else 0
+        user_threads = issue_threads
+        if chains:
+            issue_threads = chains              # one issuing thread per chain (slot j belongs to thread j % threads)
         pool = Loop.STREAMS.setdefault(str(dev), [])
-        while len(pool) < nfl:
+        while len(pool) < (chains or nfl):
             pool.append(torch.cuda.Stream(device=dev))
-        self.streams = pool[:nfl]
+        self.streams = [pool[j % chains] for j in range(nfl)] if chains else pool[:nfl]
         self.args = []
         for j in range(nfl):                    # batch j of this rank: its own scenes
             b = make_batch(cfg, (rank * nfl + j) * batch, batch)
@@ -211,6 +229,28 @@ class Loop:
                 self.steps.append(self.pans[j].make_step(*self.args[j], reset_every_step=True,
                                                           graph=(graph and j not in self.timed_idx)))
         torch.cuda.synchronize(dev)
+        if chains and nfl >= 2:
+            # the library decides whether the steps of a chain can share launches (geometric keys, a register-resident QP,
+            # one configuration): if not -- network-key paths, other polygon sizes -- every step keeps a stream of its own
+            from neupan_amd.pan import StepGroup
+            mine = [j for j in range(nfl) if j % chains == 0]
+            if len(mine) < 2 or not StepGroup([self.steps[j] for j in mine], [self.streams[j] for j in mine]).merged():
+                self.chains = chains = 0
+                while len(pool) < nfl:
+                    pool.append(torch.cuda.Stream(device=dev))
+                self.streams = pool[:nfl]
+                issue_threads = user_threads
+        self.h2d_bytes = 0
+        if h2d:
+            # every step's inputs come from pinned host memory, uploaded on the step's own stream in front of the step (what
+            # a host caller of the reference does per control cycle, neupan.py:123-127); the device tensors the step reads
+            # are the ones it captured
+            self.host = []
+            for j in range(nfl):
+                pairs = [(t, t.cpu().pin_memory()) for t in self.args[j] if t is not None]
+                self.host.append(pairs)
+                self.steps[j].pre_issue = (lambda pr: (lambda: [d.copy_(h_, non_blocking=True) for d, h_ in pr]))(pairs)
+            self.h2d_bytes = sum(h_.numel() * h_.element_size() for _, h_ in self.host[0])
         self.loop = StepLoop(self.steps, self.streams, self.gatherer, self.cur, threads=issue_threads, burst=Loop.BURST)
 
     def run(self, n):
@@ -242,9 +282,13 @@ class Loop:
         nl = sum(q["launches"] for q in profs)
         avg = lambda key: sum(q[key] * q["launches"] for q in profs) / max(nl, 1)
         K = self.cfg.iter_num
+        its = []
         for o, g in (x for x in last if x is not None):
-            assert (o["iters"].cpu().numpy() == K).all(), "every scene must run exactly K PAN iterations inside the timed region"
+            it = o["iters"].cpu().numpy()
+            its.append(it)
+            assert self.early or (it == K).all(), "every scene must run exactly K PAN iterations inside the timed region"
             assert g.numel() == self.world * self.batch * 2 * self.cfg.T
+        self.last_iters = np.concatenate(its) if its else None
         na = sum(q.get("aset_launches", 0) for q in profs)
         return dict(elapsed=elapsed, t_issue=t_issue, last=last,
                     prof={"launches": nl, "dune_ms": avg("dune_ms"), "select_ms": avg("select_ms"), "nrmp_ms": avg("nrmp_ms"),
@@ -276,10 +320,12 @@ class Loop:
         torch.cuda.empty_cache()
 
 
-def dune_mfma_rate(km, cfg, batch, dune_ms):
+def dune_mfma_rate(km, cfg, batch, dune_ms, steps=None, elapsed=None):
     """Executed matrix work of the encoder per second against the peak of the MFMA it runs on (SURVEY 8(d)'s roofline, priced
     on what is EXECUTED).  Network keys: dune_kernel encodes every point of every slice -- per 32-point tile four 32x32x32
-    layers (262 144 flop; 3x with split products) on fp16 MFMA, or on fp32 MFMA with NPA_DUNE_FP32KEYS."""
+    layers (262 144 flop; 3x with split products) on fp16 MFMA, or on fp32 MFMA with NPA_DUNE_FP32KEYS.  `tflops` / `frac`:
+    over the duration of ONE launch while the other chains' kernels co-run; `aggregate_*`: every encoder launch of the timed
+    region over its wall time (steps x K launches / elapsed) -- the chip's rate."""
     T, K, N = cfg.T, cfg.iter_num, cfg.n_points
     if km["key_terms"] == 4 or dune_ms <= 0:
         return None
@@ -288,21 +334,25 @@ def dune_mfma_rate(km, cfg, batch, dune_ms):
     per_tile = {0: 262144 + 4096, 1: 262144 + 4096, 3: 3 * 262144 + 4096}[km["key_terms"]]
     peak = PEAK_FP32_MFMA_TFLOPS if km["key_terms"] == 0 else PEAK_F16_MFMA_TFLOPS
     ex = tiles * per_tile / (dune_ms * 1e-3) / 1e12
-    return {"kernel": "dune_kernel", "launch_ms": round(dune_ms, 4), "tflops": round(ex, 2), "peak": peak,
-            "frac": round(ex / peak, 4), "points_encoded_per_launch": int(tiles * 32),
-            "mfma": "v_mfma_f32_32x32x2_f32" if km["key_terms"] == 0 else "v_mfma_f32_32x32x16_f16"}
+    out = {"kernel": "dune_kernel", "launch_ms": round(dune_ms, 4), "tflops": round(ex, 2), "peak": peak,
+           "frac": round(ex / peak, 4), "points_encoded_per_launch": int(tiles * 32),
+           "mfma": "v_mfma_f32_32x32x2_f32" if km["key_terms"] == 0 else "v_mfma_f32_32x32x16_f16"}
+    if steps and elapsed:
+        agg = tiles * per_tile * K * steps / elapsed / 1e12
+        out["aggregate_tflops"], out["aggregate_frac"] = round(agg, 2), round(agg / peak, 4)
+    return out
 
 
-def short_run(workload, batch, nfl, dev, steps, warmup, env=None, issue_threads=4):
+def short_run(workload, batch, nfl, dev, steps, warmup, env=None, issue_threads=4, **loop_kw):
     """One more timed loop (GPU only) on another workload / another path of the library."""
-    lp = Loop(workload, batch, nfl, dev, env=env, issue_threads=issue_threads)
+    lp = Loop(workload, batch, nfl, dev, env=env, issue_threads=issue_threads, **loop_kw)
     r = lp.timed(steps, warmup)
     km = lp.pans[0].key_mode()
     out = {"plans_per_s": round(batch * steps / r["elapsed"], 1), "ms_per_step": round(1e3 * r["elapsed"] / steps, 4),
-           "steps": steps, "scenes_per_step": batch, "batches_in_flight": nfl, "key_terms": km["key_terms"],
+           "steps": steps, "scenes_per_step": batch, "batches_in_flight": nfl, "chains": lp.chains, "key_terms": km["key_terms"],
            "select_launch_ms": round(r["prof"]["select_ms"], 4), "qp_launch_ms": round(r["prof"]["nrmp_ms"], 4),
            "dune_launch_ms": round(r["prof"]["dune_ms"], 4)}
-    mf = dune_mfma_rate(km, lp.cfg, batch, r["prof"]["dune_ms"])
+    mf = dune_mfma_rate(km, lp.cfg, batch, r["prof"]["dune_ms"], steps, r["elapsed"])
     if mf:
         out["dune_executed_mfma"] = mf
     out["margin_violations"] = lp.audit()["violations"]
@@ -351,11 +401,162 @@ def slim(rep):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher around it: the same command again under torch.distributed.run, one rank
+    per GPU (what the round driver does itself for N > 1; a bare call should not die in argument handling)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+def dry_run(args):
+    """--dry-run: the launch / rendezvous / timing / printing protocol of the bench without a GPU (gloo, a numpy stand-in for
+    the step): barrier + K steps + barrier, MAX over the ranks, ONE line from rank 0.  tests/test_bench_contract.py drives it
+    with two ranks through self_launch -- the N > 1 path the driver's SCALE run takes."""
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if "RANK" in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    a = np.ones((64, 64), dtype=np.float32)
+
+    def step():
+        return float((a @ a).sum())
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    if rank == 0:
+        print(json.dumps({"metric": "MPC plans/sec (node), diff robot, 1k pts, T=10, K=10; ctrl L2 vs ref", "value": round(args.batch * world * args.steps / elapsed, 1),
+                          "unit": "plans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
+                          "config": {"workload": "DRY RUN: no GPU work, the launch and timing protocol only"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+COMPACT_LIMIT = 6144
+
+
+def _verdicts(par):
+    """A / C / D of a parity report as scalars."""
+    if not par:
+        return None
+    os_ = par.get("one_step", {})
+    return {"scenes": par.get("scenes"), "members": par.get("ensemble_members"), "median": _r(par.get("ctrl_l2_vs_oracle_median")),
+            "well_posed": par.get("scenes_well_posed"), "max_well_posed": _r(par.get("max_over_well_posed")),
+            "A": par.get("A_well_posed_all_le_tol"), "C": par.get("C_le_1e-5_until_ensemble_diverges"),
+            "D_frac_le_tol": os_.get("frac_le_tol"), "D_unexplained": os_.get("unexplained"), "D_stalled": os_.get("stalled"),
+            "D_max": _r(os_.get("max"))}
+
+
+def _r(x, n=4):
+    if x is None or isinstance(x, (bool, int, str)):
+        return x
+    try:
+        return float(f"{float(x):.{n}g}")
+    except Exception:
+        return x
+
+
+def compact(line, full_path):
+    """The record the driver parses: <= COMPACT_LIMIT bytes, every contract key, scalars only below them."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    out = {k: line[k] for k in keep}
+    c = line["config"]
+    out["config"] = {k: c[k] for k in ("workload", "scenes_per_gpu", "points", "T", "K", "M", "batches_in_flight", "chains",
+                                       "issue_threads", "parallelism") if k in c}
+    r = line["roofline"]
+    ro = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "scenes_per_launch",
+                                "select_launch_ms", "launches_timed", "ipm_iterations_per_launch", "flops_per_launch", "frac_alone",
+                                "valu_issue_frac_alone", "lds_bank_conflict_frac", "algorithmic_bytes_per_launch")}
+    if r.get("chip_aggregate"):
+        ro["chip_aggregate"] = r["chip_aggregate"]
+    if r.get("pmc"):
+        pk = r["pmc"].get("per_kernel", {})
+        ro["pmc"] = {"file": r["pmc"].get("file"), "current": {k: v.get("current") for k, v in pk.items()}}
+    if r.get("select"):
+        ro["select"] = {k: r["select"].get(k) for k in ("kernel", "launch_ms", "mfma_tflops", "mfma_peak", "mfma_frac", "traffic",
+                                                        "algorithmic_bytes_per_launch")}
+    out["roofline"] = ro
+    if "cpu_baseline" in line:
+        cb = line["cpu_baseline"]
+        out["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                               "sample": cb.get("sample_short", cb["sample"][:160]), "cgroup_cpu_quota": cb.get("cgroup_cpu_quota")}
+    if "parity" in line:
+        p = line["parity"]
+        v = _verdicts(p)
+        v["frac_le_1e-4"] = p.get("frac_le_1e-4")
+        v["max"] = _r(p.get("max"))
+        g = p.get("gpu_last_qp") or {}
+        v["gpu_last_qp"] = {k: _r(g[k]) for k in list(g)[:6] if not isinstance(g[k], (dict, list, str))}
+        if p.get("well_posed_only"):
+            v["well_posed_only_plans_per_s"] = p["well_posed_only"].get("plans_per_s")
+        out["parity"] = v
+    for k in ("latency_B1_ms",):
+        if k in line:
+            out[k] = {kk: vv for kk, vv in line[k].items() if kk != "note"}
+    out["host_issue_ms_per_step"] = line.get("host_issue_ms_per_step")
+    if "margin_audit" in line:
+        out["margin_audit"] = {k: line["margin_audit"][k] for k in ("points", "violations")}
+    x = line.get("extra")
+    if x:
+        e = {}
+        if "paths" in x:
+            e["paths"] = {k: {"plans_per_s": v["plans_per_s"], "same_controls": v.get("controls_equal_default_path"),
+                              "mfma_tflops_aggregate": (v.get("dune_executed_mfma") or {}).get("aggregate_tflops"),
+                              "mfma_frac_aggregate": (v.get("dune_executed_mfma") or {}).get("aggregate_frac")}
+                          for k, v in x["paths"].items() if isinstance(v, dict)}
+        if "uniform_cloud" in x:
+            u = x["uniform_cloud"]
+            e["uniform_cloud"] = {"plans_per_s": u["plans_per_s"], "parity": _verdicts(u.get("parity"))}
+        if "other_configs" in x:
+            e["other_configs"] = {k: {"plans_per_s": v["plans_per_s"], "parity": _verdicts(v.get("parity"))}
+                                  for k, v in x["other_configs"].items() if isinstance(v, dict)}
+        if "launch_shapes" in x:
+            e["launch_shapes"] = {k: v["plans_per_s"] for k, v in x["launch_shapes"].items() if isinstance(v, dict)}
+        for k in ("early_exit", "h2d_inclusive"):
+            if k in x:
+                e[k] = {kk: vv for kk, vv in x[k].items() if kk != "note"}
+        e["seconds"] = x.get("seconds")
+        out["extra"] = e
+    out["full_record"] = full_path
+    # never above the limit: drop the least essential parts first
+    for drop in (("extra", "launch_shapes"), ("extra", "paths"), ("parity", "gpu_last_qp"), ("roofline", "pmc"), ("extra", "other_configs"),
+                 ("extra", None)):
+        if len(json.dumps(out)) <= COMPACT_LIMIT:
+            break
+        a, b = drop
+        if a in out and (b is None or b in out[a]):
+            if b is None:
+                del out[a]
+            else:
+                del out[a][b]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128)
-    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=120)            # (whole rounds of the 20 batches in flight)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--cpu-scenes", type=int, default=0,
                     help="scenes of the first batch planned by the CPU oracle + its ensemble (rank 0, N=1); 0 = 256 on a host "
                          "with >= 64 cores, else 96")
@@ -373,18 +574,25 @@ def main():
     ap.add_argument("--burst", type=int, default=BURST_DEFAULT,
                     help="1: the steps a host thread issues in one round of the chains go out as ONE breadth-first library call "
                          "(npa_forward_batch_group: staging of every chain, then PAN iteration 0 of every chain, ...); 0: call by call")
+    ap.add_argument("--chains", type=int, default=CHAINS_DEFAULT,
+                    help="launch chains the batches in flight form: the steps of a chain share one stream and run every stage as ONE "
+                         "merged launch (npa_forward_batch_group); 0: one stream and one launch chain per step (round 4's schedule)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: the launch / rendezvous / timing protocol only (gloo)")
     ap.add_argument("--workload", default=WORKLOAD,
                     choices=sorted(k for k in __import__("neupan_amd.scenes", fromlist=["CONFIGS"]).CONFIGS),
                     help="scene configuration (default: the one BASELINE.json's metric is quoted on)")
     ap.add_argument("--batch", type=int, default=BATCH, help="scenes per step and GPU")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args.gpus)                  # (does not return)
+    if args.dry_run:
+        return dry_run(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -415,8 +623,10 @@ def main():
     # one queue while the other 21 run on -- what rounds 2 and 3 reported as "the communicator's passive cost", 11 - 24 % of a
     # 128-step run, gone with <= 18 chains or once the communicator is destroyed).  A run of <= 20 steps
     # is ONE wave of chains: 20 chains finish it in one chain latency, 18 need two.
-    nfl = args.inflight if args.inflight > 0 else (20 if (dist is None or args.steps <= 20) else 18)
+    # With merged launches (--chains C > 0) the chains, not the steps, own the streams: C queues whatever --inflight is.
+    nfl = args.inflight if args.inflight > 0 else (20 if (dist is None or args.steps <= 20 or args.chains > 0) else 18)
     Loop.BURST = bool(args.burst)
+    Loop.CHAINS = max(0, args.chains)
     lp = Loop(args.workload, B, nfl, dev, rank=rank, world=world, dist=None if os.environ.get("NPA_BENCH_NOGATHER") else dist,
               graph=args.graph, issue_threads=args.issue_threads)
     E = lp.pans[0].E
@@ -451,47 +661,59 @@ def main():
     # un-pruned selections, roofline.select for the default one.
     pmc = load_pmc(args.workload)
     its = lp.qp_iterations()
-    its_per_launch = float(np.mean([s for s, _ in its]))
+    # steps that share a launch (merged chains): the members of a chain, <= 8 per run (a full round of the slots; a trailing
+    # partial round has shorter runs -- the default step counts are whole rounds)
+    mem = (nfl + lp.chains - 1) // lp.chains if lp.chains else 1
+    mem = (mem + ((mem + 7) // 8) - 1) // ((mem + 7) // 8)
+    spl = B * mem                               # scenes per launch
+    its_per_launch = float(np.mean([s for s, _ in its])) * mem      # (batch 0's count stands for its chain mates)
     qp_ms, sel_ms, dune_ms = prof["nrmp_ms"], prof["select_ms"], prof["dune_ms"]
-    roof = {"bound": "valu", "kernel": f"nrmp_qp_kernel<{T},{cfg.nrmp_max_num}>", "unit": "TFLOP/s", "peak": PEAK_FP64_VALU_TFLOPS,
-            "launch_ms": round(qp_ms, 4), "launches_timed": prof["launches"], "select_launch_ms": round(sel_ms, 4),
-            "dune_launch_ms": round(dune_ms, 4), "aset_launch_ms": round(prof.get("aset_ms", 0.0), 4),
-            "aset_launches_timed": prof.get("aset_launches", 0), "key_mode": km, "achieved": None, "frac": None, "traffic": None,
+    qp_name = "nrmp_qp_group_kernel" if lp.chains else "nrmp_qp_kernel"
+    sel_name = "select_geo_group_kernel" if lp.chains else "select_geo_kernel"
+    roof = {"bound": "valu", "kernel": f"{qp_name}<{T},{cfg.nrmp_max_num}>", "unit": "TFLOP/s", "peak": PEAK_FP64_VALU_TFLOPS,
+            "launch_ms": round(qp_ms, 4), "scenes_per_launch": spl, "launches_timed": prof["launches"], "select_launch_ms": round(sel_ms, 4),
+            "dune_launch_ms": round(dune_ms, 4), "key_mode": km, "achieved": None, "frac": None, "traffic": None,
             "ipm_iterations_per_launch": round(its_per_launch, 1),
             "ipm_iterations_by_pan_iteration": [[int(s), int(m)] for s, m in its]}
-    kq = pmc["kernels"].get("nrmp_qp_kernel") if pmc else None
+    kq = (pmc["kernels"].get(qp_name) or pmc["kernels"].get("nrmp_qp_kernel")) if pmc else None
     if kq:
+        kq_spl = kq.get("scenes_per_launch", pmc["scenes_per_launch"])
         model = pmc.get("qp_flops_model")
         if model:
-            flops = model["per_iteration"] * its_per_launch + model["per_solve"] * B
+            flops = model["per_iteration"] * its_per_launch + model["per_solve"] * spl
             roof["flops_model"] = dict(model, units="fp64 flop per interior-point iteration of one scene / per solve")
         else:                                   # (a record without the two-point fit: its launch average, scaled to this batch)
-            flops = kq["fp64_flops_per_launch"] * B / pmc["scenes_per_launch"]
+            flops = kq["fp64_flops_per_launch"] * spl / kq_spl
         roof["achieved"] = round(flops / (qp_ms * 1e-3) / 1e12, 4) if qp_ms > 0 else None
         roof["frac"] = round(roof["achieved"] / PEAK_FP64_VALU_TFLOPS, 5) if roof["achieved"] else None
         roof["flops_per_launch"] = int(flops)
-        roof["traffic"] = int(kq["hbm_bytes_per_launch"] * B / pmc["scenes_per_launch"])
+        roof["traffic"] = int(kq["hbm_bytes_per_launch"] * spl / kq_spl)
+        # algorithmic bytes of the QP launch: the rows it consumes (T+1 slices x M x (E + 5) floats + counts), the nominal in
+        # and out, the references and the outputs -- what a fused loop would still have to move is far less
+        roof["algorithmic_bytes_per_launch"] = int(spl * 4 * ((T + 1) * cfg.nrmp_max_num * (E + 5) + (T + 1) + 4 * (3 * (T + 1) + 2 * T) + 3 * T))
         roof["valu_issue_frac_alone"] = kq.get("valu_issue_frac")
-        roof["frac_alone"] = round(flops / (kq["avg_ms_alone"] * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS, 5) if kq.get("avg_ms_alone") else None
+        roof["frac_alone"] = (round(flops * (kq_spl / spl) / (kq["avg_ms_alone"] * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS, 5)
+                              if kq.get("avg_ms_alone") else None)
         roof["lds_bank_conflict_frac"] = kq.get("lds_bank_conflict_frac")
         # the chip's fp64 rate over the whole timed region: every QP launch of every chain / wall time
-        roof["chip_aggregate"] = {"tflops": round(flops * K * args.steps / elapsed / 1e12, 3),
-                                  "frac": round(flops * K * args.steps / elapsed / 1e12 / PEAK_FP64_VALU_TFLOPS, 5)}
+        agg = flops / mem * K * args.steps / elapsed / 1e12
+        roof["chip_aggregate"] = {"tflops": round(agg, 3), "frac": round(agg / PEAK_FP64_VALU_TFLOPS, 5)}
         roof["pmc"] = {"file": pmc["_file"],
                        "per_kernel": {k: dict({kk: v[kk] for kk in ("valu_insts_per_launch", "valu_issue_frac", "hbm_bytes_per_launch",
                                                                       "avg_ms_alone", "mfma_busy_frac", "source_hash", "isa_hash") if kk in v},
                                                   current=record_is_current(k, v))
                                       for k, v in pmc["kernels"].items()}}
-    ks = pmc["kernels"].get("select_geo_kernel") if pmc else None
+    ks = (pmc["kernels"].get(sel_name) or pmc["kernels"].get("select_geo_kernel")) if pmc else None
     if ks and sel_ms > 0 and "SQ_INSTS_MFMA" in ks.get("counters", {}):
         # the exact encoder's matrix work: executed v_mfma_f32_32x32x2_f32 (4096 flop each) over the fp32-MFMA peak
-        mf = ks["counters"]["SQ_INSTS_MFMA"] * 4096.0 * B / pmc["scenes_per_launch"]
-        roof["select"] = {"kernel": f"select_geo_kernel<{E}>", "launch_ms": round(sel_ms, 4), "mfma_flops_per_launch": int(mf),
+        ks_spl = ks.get("scenes_per_launch", pmc["scenes_per_launch"])
+        mf = ks["counters"]["SQ_INSTS_MFMA"] * 4096.0 * spl / ks_spl
+        roof["select"] = {"kernel": f"{sel_name}<{E}>", "launch_ms": round(sel_ms, 4), "mfma_flops_per_launch": int(mf),
                           "mfma_tflops": round(mf / (sel_ms * 1e-3) / 1e12, 3), "mfma_peak": PEAK_FP32_MFMA_TFLOPS,
                           "mfma_frac": round(mf / (sel_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 5),
                           "valu_issue_frac_alone": ks.get("valu_issue_frac"), "mfma_busy_frac_alone": ks.get("mfma_busy_frac"),
-                          "traffic": int(ks["hbm_bytes_per_launch"] * B / pmc["scenes_per_launch"]),
-                          "algorithmic_bytes_per_launch": int(B * (8 * N * (2 if lp.args[0][5] is not None else 1) + 400))}
+                          "traffic": int(ks["hbm_bytes_per_launch"] * spl / ks_spl),
+                          "algorithmic_bytes_per_launch": int(spl * (8 * N * (2 if lp.args[0][5] is not None else 1) + 400))}
     roof["note"] = ("dominant kernel by GPU time = the QP (fp64 Mehrotra IPM, one wave per scene, serial chain: latency / VALU-issue "
                     "bound).  achieved = (interior-point iterations per launch, measured on the device in this run) x (fp64 flops per "
                     "iteration) + solves x (fixed flops per solve), the two per-unit figures from PMC counts at two operating points "
@@ -501,7 +723,7 @@ def main():
                     ("geometric distance keys inside select_geo_kernel nominate the candidates, the exact fp32-MFMA encoder runs on "
                      "those only (~1.1 tiles of 32 points per slice instead of N/32); no dune_kernel launch" if km["key_terms"] == 4
                      else f"network keys (mode {km['key_terms']}) from dune_kernel over every point, exact re-encode of the candidates"))
-    mfd = dune_mfma_rate(km, cfg, B, dune_ms)
+    mfd = dune_mfma_rate(km, cfg, B, dune_ms, args.steps, elapsed)
     if mfd:
         roof["dune_executed_mfma"] = mfd
 
@@ -521,12 +743,14 @@ def main():
                                     + ("; rows from the LABELLED bf16 tier (not the reference's arithmetic)"
                                        if os.environ.get("NPA_ROWS_PRECISION") == "bf16" else ""),
                    "scenes_per_gpu": B, "points": N, "T": T, "K": K, "M": cfg.nrmp_max_num,
-                   "batches_in_flight": nfl, "schedule": "one HIP stream per batch in flight, one prepared library call per step "
-                                                        "(PAN.make_step), " + ("the chains of a round issued breadth-first "
-                                                        "(npa_forward_batch_group), " if lp.loop.groups is not None else "") +
-                                                        ("eager launches" if not args.graph else
-                                                        "HIP-graph replay except on the planners that carry timing events") +
-                                                        ", gathers on one communication stream",
+                   "batches_in_flight": nfl, "chains": lp.chains,
+                   "schedule": ((f"{lp.chains} launch chains of {mem} steps each: the steps of a chain (own scenes, buffers, planner state) are issued "
+                                 "as ONE npa_forward_batch_group call on ONE stream and every stage of theirs runs as one merged launch "
+                                 f"over {spl} scenes (blockIdx.y = the step), " if lp.chains else
+                                 "one HIP stream per batch in flight, one prepared library call per step (PAN.make_step), " +
+                                 ("the chains of a round issued breadth-first (npa_forward_batch_group), " if lp.loop.groups is not None else "")) +
+                                ("eager launches" if not args.graph else "HIP-graph replay except on the planners that carry timing events") +
+                                ", gathers on one communication stream"),
                    "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "numa_node": numa, "issue_threads": lp.loop.threads,
                    "parallelism": f"scene-shard x{world}, RCCL all-gather of controls"
                                   + (f" (process group initialised; {lp.gatherer.collectives} collectives for {lp.gatherer.issued} "
@@ -591,6 +815,8 @@ def main():
                                           f"thread, BLAS/OpenMP pinned to 1 thread in the parent before the spawn; best rate of a "
                                           f"sweep over the number of concurrent workers ({ncore} won; host: {phys} physical cores, "
                                           f"{logical} hardware threads, cgroup CPU quota {quota}), 2-4 plans per worker, workers started and warm",
+                                "sample_short": f"first {n_sc} scenes of the same workload, K={K} each, oracle/pan_oracle.py (numpy fp32 + fp64 IPM), "
+                                                f"worker processes x 1 thread, best of a sweep over the worker count",
                                 "cgroup_cpu_quota": quota,
                                 "sweep": getattr(run_ensemble, "last_sweep", None),
                                 "seconds_per_plan_single_worker": round(getattr(run_ensemble, "last_single_seconds", 0.0) or 0.0, 3)}
@@ -627,6 +853,7 @@ def main():
                                        "solution of its last QP and objective gap to the oracle's solve of the same problem, "
                                        "all scenes of the batch; stat_oracle = the same certificate on the oracle's solutions")
         line["parity"] = rep
+    lp_chains = lp.chains
     lp.close()
 
     # ---- the other paths and configurations, in the same line (GPU legs are short loops; parity legs: 16 scenes each) -----
@@ -662,7 +889,8 @@ def main():
         b0 = make_batch(cfg, 0, B)
         res["candidates_per_slice_corridor_workload"] = cand(WORKLOAD, [b0["nom_s"], None, None, None, b0["points"], None])
         if with_cpu:
-            res["parity"] = slim(parity_leg(l2, 8, cores, n_ulp=4, n_perm=2)[0])
+            # (32 scenes x 12 members, like the headline's ensemble: "no well-posed scene" is then a measured statement)
+            res["parity"] = slim(parity_leg(l2, 32, cores, n_ulp=8, n_perm=4)[0])
         res["note"] = ("SURVEY 8(d) config 2's cloud exactly as specified (uniform x in [-2, 12], y in [-6, 6], rejection box): 6 points "
                        "per m^2 around a 1.6 x 2.0 m robot -- most scenes have no collision-free plan (d at d_min), the PAN iteration is "
                        "ill posed on them; candidates per slice = points the geometric keys could not rule out (255 = capped)")
@@ -691,23 +919,54 @@ def main():
                                                 "reference ships no E = 8 checkpoint: ours, trained with its recipe on closed-form labels) in "
                                                 "exact fp32 and in the LABELLED bf16 tier of the rows (v_mfma_f32_32x32x16_bf16; its parity "
                                                 "entry shows what that costs); parity = ensemble verdicts on the first 16 scenes (6 members)")
-        # how far the chip is from full at 20 x 256 scenes in flight: the same loop with more scenes per launch (the chains in
-        # flight are capped by the ~24 hardware queues a process gets, DESIGN.md section 4, so more work in flight means bigger
-        # launches).  NOT the configuration the metric is quoted on -- a ceiling for it.
+        # the same 20 batches in flight under other schedules: one stream and one launch chain per step (round 4's default),
+        # and other numbers of merged chains.  NOT other workloads: every step is 256 scenes with its own planner state.
         shapes = {}
-        for b_, nf, st_ in ((512, nfl, 96), (1024, nfl, 64), (2048, 12, 36)):
-            res, l2 = short_run(WORKLOAD, b_, nf, dev, st_, st_ // 4, issue_threads=args.issue_threads)
-            shapes[f"{b_}_scenes_per_launch_{nf}_in_flight"] = {k: res[k] for k in ("plans_per_s", "ms_per_step", "steps", "scenes_per_step",
-                                                                                      "batches_in_flight", "select_launch_ms", "qp_launch_ms")}
+        for tag, ch in (("one_chain_per_step", 0), ("2_chains", 2), ("10_chains", 10)):
+            if ch == lp_chains:
+                continue
+            res, l2 = short_run(WORKLOAD, B, nfl, dev, 60, 20, issue_threads=args.issue_threads, chains=ch)
+            shapes[tag] = {k: res[k] for k in ("plans_per_s", "ms_per_step", "steps", "scenes_per_step", "batches_in_flight", "chains",
+                                               "select_launch_ms", "qp_launch_ms")}
             l2.close()
-        ex["launch_shapes"] = dict(shapes, note="the default workload with 2 / 4 / 8 batches of 256 scenes coalesced into one launch chain: "
-                                                "what the two kernels deliver when the chip is given enough independent scenes (a launch "
-                                                "lasts as long as its slowest scene, so at 20 x 256 in flight most wave slots idle behind "
-                                                "tails); the headline value is NOT taken from these")
+        ex["launch_shapes"] = dict(shapes, note="the default workload and batch size under other launch schedules (60 steps): "
+                                                "one_chain_per_step = round 4's default (20 streams, 1 + 2K launches per step); n_chains = "
+                                                "the 20 batches in flight merged into n launch chains")
+        # SURVEY 8(d)'s second run: the reference's default stop threshold (pan.py:243: iter_threshold = 0.1).  Every step starts
+        # from a cleared stop-criterion state (like every other leg), so a scene runs at least 2 iterations: the first only
+        # stores its iterate (pan.py:218-221)
+        le = Loop(WORKLOAD, B, nfl, dev, issue_threads=args.issue_threads, over={"iter_threshold": 0.1})
+        re_ = le.timed(60, 20)
+        it = le.last_iters
+        ex["early_exit"] = {"iter_threshold": 0.1, "plans_per_s": round(B * 60 / re_["elapsed"], 1), "steps": 60,
+                            "iterations_mean": round(float(it.mean()), 3), "iterations_max": int(it.max()), "iterations_min": int(it.min()),
+                            "share_stopped_before_K": round(float((it < K).mean()), 4),
+                            "note": "the default loop with the reference's default iter_threshold (pan.py:243); executed PAN iterations per "
+                                    "scene over the last step of every batch in flight; the launches of a step still number K (a stopped "
+                                    "scene's waves return at once)"}
+        le.close()
+        # PCIe-inclusive: every step's inputs (nominal and reference trajectories, the cloud) uploaded from pinned host memory on
+        # the step's own stream in front of the step -- what a host caller of the reference does per cycle (neupan.py:123-127)
+        lh = Loop(WORKLOAD, B, nfl, dev, issue_threads=args.issue_threads, h2d=True)
+        rh = lh.timed(60, 20)
+        ex["h2d_inclusive"] = {"plans_per_s": round(B * 60 / rh["elapsed"], 1), "steps": 60, "bytes_per_step": int(lh.h2d_bytes),
+                               "upload_GBps": round(lh.h2d_bytes * 60 / rh["elapsed"] / 1e9, 2),
+                               "note": "inputs of every step copied host (pinned) -> device on the step's stream inside the timed region; "
+                                       "NOT the headline (whose inputs are resident in HBM)"}
+        lh.close()
         ex["seconds"] = round(time.perf_counter() - t_ex, 1)
         line["extra"] = ex
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        full_path = os.environ.get("NPA_BENCH_FULL", os.path.join(ROOT, "bench_full.json"))
+        try:
+            with open(full_path, "w") as f:
+                f.write(json.dumps(line) + "\n")
+        except OSError as e:                      # (a read-only tree: the compact line is still the record)
+            full_path = f"not written: {e}"
+        short = compact(line, os.path.relpath(full_path, ROOT) if os.path.isabs(full_path) and full_path.startswith(ROOT) else full_path)
+        txt = json.dumps(short)
+        assert len(txt) <= COMPACT_LIMIT, len(txt)
+        print(txt, flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -242,6 +242,15 @@ typedef struct npa_forward_call {
   void *stream;
 } npa_forward_call;
 int npa_forward_batch_group(int n, const npa_forward_call *calls, int flags);
+/* MERGED LAUNCHES.  Calls of a group that share ONE stream, a batch size and a configuration (same npa_config, geometric
+ * keys, T = 10 or 20 with M = 10, E = 4 or 8) run every stage of theirs as ONE launch over all their scenes, in runs of
+ * <= 8 calls: blockIdx.y = the call, the kernels' statements and every result bitwise those of the call-by-call form.  A
+ * launch is a barrier over its scenes (the chain goes on when its slowest scene is done): merged, the wave slots a
+ * straggler leaves idle are refilled from the same launch and the run occupies one hardware queue instead of one per
+ * call.  Same ownership rules: every call keeps its own handle, tensors, workspace and planner state.
+ * npa_forward_group_merged: 1 when npa_forward_batch_group(n, calls, .) would run calls[0..n) as ONE merged run, else 0
+ * (different streams / batch sizes / configurations, network keys, n < 2 or n > 8, NPA_GROUP_MERGE=0 in the environment). */
+int npa_forward_group_merged(int n, const npa_forward_call *calls);
 
 /* Stage entry points (used by the parity tests and for profiling one stage alone).
  * npa_dune_stage  = generate_point_flow + DUNE.forward + the top-M gather:

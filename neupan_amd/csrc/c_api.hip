@@ -51,6 +51,13 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
                                     double* qp_info, double* warm, float* trig_out, float* dbg_abc, float* dbg_f, double* dbg_x,
                                     hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, int aset_launch);
 extern "C" size_t npa_qp_shmem_bytes(int T, int M);
+extern "C" int npa_select_geo_group_supported(int E);
+extern "C" hipError_t npa_launch_select_geo_group(const DevParams& P, const SelGeoGroup& G, int n, int batch, int t0, int n_stride_max,
+                                                  int debug, unsigned audit_thresh, float margin_scale, int rows_bf16,
+                                                  hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);
+extern "C" int npa_qp_group_supported(int T, int M);
+extern "C" hipError_t npa_launch_qp_group(const DevParams& P, const QpGroup& G, int n, int batch, hipStream_t stream,
+                                          hipEvent_t ev_start, hipEvent_t ev_stop);
 extern "C" hipError_t npa_launch_nominal(int batch, int T, int kin, double dt, double L, const double* state,
                                          const float* vel, const double* ref_speed, const double* path,
                                          const int* curve_off, const int* curve_len, const int* point_index,
@@ -83,6 +90,8 @@ struct PendingCall {
   float* state = nullptr;
   hipStream_t stream = nullptr;
   bool dune = false;
+  const float *nom_s = nullptr, *nom_u = nullptr;     // (the staging launch's sources: the merged group path launches it later)
+  bool reset_state = false;
 };
 
 struct npa_handle {
@@ -885,6 +894,30 @@ __global__ void stage_kernel(float* __restrict__ cur_s, const float* __restrict_
   }
 }
 
+// stage_kernel for a group of forward calls of one size (merged launches, pan_common.h): blockIdx.y = the call
+__global__ void stage_group_kernel(StageGroup G, size_t ns, size_t nu, size_t nflag, size_t ncount, size_t nstate, int T) {
+  const StageCall& q = G.c[blockIdx.y];
+  float* __restrict__ cur_s = q.cur_s; const float* __restrict__ nom_s = q.nom_s; float* __restrict__ cur_u = q.cur_u;
+  const float* __restrict__ nom_u = q.nom_u; int* __restrict__ flags = q.flags; int* __restrict__ count = q.count;
+  int* __restrict__ state = q.state; float* __restrict__ trig = q.trig;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;; i += stride) {
+    bool any = false;
+    if (i < ns) { cur_s[i] = nom_s[i]; any = true; }
+    if (i < ncount) {
+      const size_t b = i / (size_t)(T + 1), t = i - b * (size_t)(T + 1);
+      float c, sn;
+      npa_trig(nom_s[b * 3 * (size_t)(T + 1) + 2 * (size_t)(T + 1) + t], c, sn);
+      trig[2 * i] = c; trig[2 * i + 1] = sn;
+    }
+    if (i < nu) { cur_u[i] = nom_u[i]; any = true; }
+    if (i < nflag) { flags[i] = 0; any = true; }
+    if (i < ncount) { count[i] = 0; any = true; }
+    if (i < nstate) { state[i] = 0; any = true; }
+    if (!any) break;
+  }
+}
+
 // ---- forward = begin + K x iter + end ------------------------------------------------------------
 // One forward call is a chain of launches on ONE stream: staging, then per PAN iteration the selection (preceded by
 // the key launch when the handle uses network keys) and the QP.  Independent batches overlap by running on different
@@ -917,12 +950,14 @@ static void key_policy(npa_handle* h, int batch, int n_stride) {
   ++h->calls_window;
 }
 
-extern "C" int npa_forward_begin(npa_handle* h, int batch, int n_stride, const float* nom_s, const float* nom_u,
-                                 const float* ref_s, const float* ref_us, const float* points,
-                                 const float* velocities, const int32_t* n_points, float* out_s, float* out_u,
-                                 float* out_d, float* out_min_distance, int32_t* out_iters, float* out_nrmp_points,
-                                 void* workspace, size_t workspace_bytes, void* state, size_t state_bytes,
-                                 void* stream_, int flags) {
+// launch_stage = false: everything of npa_forward_begin except the staging launch (the merged group path stages all its
+// calls with one launch, npa_group_stage_merged below)
+static int forward_begin_impl(npa_handle* h, int batch, int n_stride, const float* nom_s, const float* nom_u,
+                              const float* ref_s, const float* ref_us, const float* points,
+                              const float* velocities, const int32_t* n_points, float* out_s, float* out_u,
+                              float* out_d, float* out_min_distance, int32_t* out_iters, float* out_nrmp_points,
+                              void* workspace, size_t workspace_bytes, void* state, size_t state_bytes,
+                              void* stream_, int flags, bool launch_stage) {
   if (!h || batch < 1 || !nom_s || !nom_u || !ref_s || !ref_us || !out_s || !out_u || !workspace || !state)
     return fail(NPA_E_ARG, "npa_forward_begin: null argument");
   const DevParams& P = h->P;
@@ -945,8 +980,9 @@ extern "C" int npa_forward_begin(npa_handle* h, int batch, int n_stride, const f
   pc->out_md = out_min_distance; pc->out_iters = out_iters; pc->out_np = out_nrmp_points; pc->ws = ws;
   pc->state = (float*)state; pc->stream = stream;
   pc->dune = P.M > 0 && points != nullptr;
+  pc->nom_s = nom_s; pc->nom_u = nom_u; pc->reset_state = reset_state;
   if (pc->dune) key_policy(h, batch, n_stride);
-  {
+  if (launch_stage) {
     // one launch instead of two copies and up to three memsets (each costs tens of microseconds of stream time)
     const size_t ns = (size_t)batch * 3 * (T + 1), nu2 = (size_t)batch * 2 * T;
     const size_t nflag = (size_t)batch * 4, ncount = (size_t)batch * (T + 1);
@@ -959,6 +995,133 @@ extern "C" int npa_forward_begin(npa_handle* h, int batch, int n_stride, const f
     HIP_TRY(hipGetLastError());
   }
   pc->active = true;
+  return NPA_OK;
+}
+
+extern "C" int npa_forward_begin(npa_handle* h, int batch, int n_stride, const float* nom_s, const float* nom_u,
+                                 const float* ref_s, const float* ref_us, const float* points,
+                                 const float* velocities, const int32_t* n_points, float* out_s, float* out_u,
+                                 float* out_d, float* out_min_distance, int32_t* out_iters, float* out_nrmp_points,
+                                 void* workspace, size_t workspace_bytes, void* state, size_t state_bytes,
+                                 void* stream_, int flags) {
+  return forward_begin_impl(h, batch, n_stride, nom_s, nom_u, ref_s, ref_us, points, velocities, n_points, out_s, out_u, out_d,
+                            out_min_distance, out_iters, out_nrmp_points, workspace, workspace_bytes, state, state_bytes, stream_,
+                            flags, true);
+}
+
+// ---- merged launches of a group of forward calls (npa_forward_batch_group, serve_group.hip) --------------------------------
+// n calls qualify when one launch per stage can serve them all: one stream, one batch size, byte-identical kernel parameters,
+// the default selection (geometric keys; exact or bf16 rows alike) and the register-resident interior-point solve, nothing
+// that needs a launch of its own in between.  Everything else keeps the breadth-first call-by-call order.
+extern "C" int npa_group_mergeable(int n, const npa_forward_call* calls) {
+  if (n < 2 || n > NPA_GROUP_MAX || !calls) return 0;
+  static const bool off = getenv("NPA_GROUP_MERGE") != nullptr && atoi(getenv("NPA_GROUP_MERGE")) == 0;
+  if (off) return 0;
+  const npa_handle* h0 = calls[0].h;
+  if (!h0) return 0;
+  const DevParams& P = h0->P;
+  const bool dune0 = P.M > 0 && calls[0].points != nullptr;
+  if (dune0 && !(h0->key_terms == 4 && !h0->select_v1 && !h0->select_scene && npa_select_geo_group_supported(P.E))) return 0;
+  if (!npa_qp_group_supported(P.T, P.M) || h0->qp_generic || P.qp_aset || (h0->aset_auto && calls[0].batch <= h0->aset_small_batch) ||
+      h0->scene_kernel || h0->key_auto)
+    return 0;
+  if (calls[0].iter_num < 1 || calls[0].iter_num > P.K) return 0;       // (the call-by-call path reports that)
+  for (int c = 0; c < n; ++c) {
+    const npa_handle* h = calls[c].h;
+    if (!h || calls[c].stream != calls[0].stream || calls[c].batch != calls[0].batch || calls[c].iter_num != calls[0].iter_num ||
+        h->device != h0->device || memcmp(&h->P, &P, sizeof(DevParams)) != 0 || h->key_terms != h0->key_terms ||
+        h->select_v1 != h0->select_v1 || h->select_scene != h0->select_scene || h->rows_bf16 != h0->rows_bf16 ||
+        h->sel_debug != h0->sel_debug || h->audit_thresh != h0->audit_thresh || h->margin_scale != h0->margin_scale ||
+        h->qp_generic != h0->qp_generic || h->qp_warm != h0->qp_warm || h->scene_kernel || h->key_auto ||
+        (P.M > 0 && calls[c].points != nullptr) != dune0 || (calls[c].out_d == nullptr) != (calls[0].out_d == nullptr))
+      return 0;
+  }
+  return 1;
+}
+
+extern "C" int npa_forward_group_merged(int n, const npa_forward_call* calls) { return npa_group_mergeable(n, calls); }
+
+// begin of every call without its staging launch, then ONE staging launch for the group.  *begun = calls begun (the caller
+// ends them whatever happens).
+extern "C" int npa_group_begin_merged(int n, const npa_forward_call* calls, int flags, int* begun) {
+  *begun = 0;
+  for (int c = 0; c < n; ++c) {
+    const npa_forward_call& a = calls[c];
+    const int rc = forward_begin_impl(a.h, a.batch, a.n_stride, a.nom_s, a.nom_u, a.ref_s, a.ref_us, a.points, a.velocities,
+                                      a.n_points, a.out_s, a.out_u, a.out_d, a.out_min_distance, a.out_iters, a.out_nrmp_points,
+                                      a.workspace, a.workspace_bytes, a.state, a.state_bytes, a.stream, flags, false);
+    if (rc != NPA_OK) return rc;
+    *begun = c + 1;
+  }
+  npa_handle* h0 = calls[0].h;
+  const DevParams& P = h0->P;
+  const int T = P.T, batch = calls[0].batch;
+  const ScratchLayout L = npa_scratch_layout(batch, T, mdim(P), P.E, kstride(h0));
+  StageGroup G;
+  memset(&G, 0, sizeof(G));
+  for (int c = 0; c < n; ++c) {
+    const PendingCall& pc = calls[c].h->pc;
+    G.c[c] = StageCall{pc.ws + L.cur_s, pc.nom_s, pc.ws + L.cur_u, pc.nom_u, (int*)(pc.ws + L.flags), (int*)(pc.ws + L.count),
+                       (int*)pc.state, pc.ws + L.trig};
+  }
+  const size_t ns = (size_t)batch * 3 * (T + 1), nu2 = (size_t)batch * 2 * T;
+  const size_t nflag = (size_t)batch * 4, ncount = (size_t)batch * (T + 1);
+  const size_t nstate = h0->pc.reset_state ? npa_state_bytes(h0, batch) / 4 : 0;
+  const size_t work = std::max(std::max(ns, nu2), std::max(std::max(nflag, ncount), nstate));
+  const int threads = 256;
+  const int blocks = (int)std::min<size_t>((work + threads - 1) / threads, 512);
+  hipLaunchKernelGGL(stage_group_kernel, dim3(blocks, n), dim3(threads), 0, h0->pc.stream, G, ns, nu2, nflag, ncount, nstate, T);
+  HIP_TRY(hipGetLastError());
+  return NPA_OK;
+}
+
+// (diagnostics, not in the header: merged QP launches issued by this process so far -- the tests check that the merged path ran)
+static std::atomic<unsigned long long> g_merged_launches{0};
+extern "C" unsigned long long npa_dbg_group_merged_launches(void) { return g_merged_launches.load(); }
+
+// PAN iteration k of every call of the group: one selection launch, one QP launch (profile events: the first call's)
+extern "C" int npa_group_iter_merged(int n, const npa_forward_call* calls, int k) {
+  npa_handle* h0 = calls[0].h;
+  const DevParams& P = h0->P;
+  if (k < 0 || k >= P.K) return fail(NPA_E_ARG, "npa_forward_batch_group: iteration index out of range");
+  const int T = P.T, batch = calls[0].batch;
+  const ScratchLayout L = npa_scratch_layout(batch, T, mdim(P), P.E, kstride(h0));
+  hipStream_t stream = h0->pc.stream;
+  for (int c = 0; c < n; ++c)
+    if (!calls[c].h->pc.active) return fail(NPA_E_ARG, "npa_forward_batch_group: a call of the group is not in progress");
+  if (h0->pc.dune) {
+    SelGeoGroup G;
+    memset(&G, 0, sizeof(G));
+    int n_stride_max = 1;
+    for (int c = 0; c < n; ++c) {
+      npa_handle* h = calls[c].h;
+      const PendingCall& pc = h->pc;
+      float* ws = pc.ws;
+      G.c[c] = SelGeoCall{h->wpack, ws + L.cur_s, pc.points, pc.velocities, pc.n_points, (const int*)(ws + L.flags),
+                          ws + L.mu, ws + L.lam, ws + L.pts, ws + L.dist, (int*)(ws + L.count), h->sel_stats_dev, ws + L.trig,
+                          h->rows_bf16 ? nullptr : h->audit_dev, pc.n_stride, h->launch_seq++};
+      if (pc.n_stride > n_stride_max) n_stride_max = pc.n_stride;
+    }
+    EventPair* evs = next_event(h0, h0->ev_sel, h0->n_sel);
+    HIP_TRY(npa_launch_select_geo_group(P, G, n, batch, k == 0 ? 0 : 1, n_stride_max, h0->sel_debug, h0->audit_thresh,
+                                        h0->margin_scale, h0->rows_bf16 ? 1 : 0, stream, evs ? evs->a : nullptr,
+                                        evs ? evs->b : nullptr));
+  }
+  QpGroup Q;
+  memset(&Q, 0, sizeof(Q));
+  for (int c = 0; c < n; ++c) {
+    npa_handle* h = calls[c].h;
+    const PendingCall& pc = h->pc;
+    float* ws = pc.ws;
+    float *cur_s = ws + L.cur_s, *cur_u = ws + L.cur_u;
+    Q.c[c] = QpCall{cur_s, cur_u, pc.ref_s, pc.ref_us, ws + L.mu, ws + L.lam, ws + L.pts, ws + L.dist, (const int*)(ws + L.count),
+                    cur_s, cur_u, ws + L.cur_d, pc.out_s, pc.out_u, pc.out_d, pc.out_md, pc.out_iters, pc.out_np,
+                    (int*)(ws + L.flags), pc.state, (double*)(ws + L.qp_info), h->qp_warm ? (double*)(ws + L.warm) : nullptr,
+                    pc.dune ? ws + L.trig : nullptr};
+  }
+  EventPair* ev = next_event(h0, h0->ev_qp, h0->n_qp);
+  HIP_TRY(npa_launch_qp_group(P, Q, n, batch, stream, ev ? ev->a : nullptr, ev ? ev->b : nullptr));
+  g_merged_launches.fetch_add(1);
   return NPA_OK;
 }
 

@@ -210,6 +210,42 @@ extern "C" hipError_t npa_launch_select_geo(const DevParams& P, const float* wpa
   return hipGetLastError();
 }
 
+// select_geo_kernel for a group of n forward calls that share the configuration, the batch size and the stream (c_api.hip
+// checks that): ONE launch, grid (blocks of one call, n).  n_stride_max sizes the LDS key area.
+extern "C" hipError_t npa_launch_select_geo_group(const DevParams& P, const SelGeoGroup& G, int n, int batch, int t0, int n_stride_max,
+                                                  int debug, unsigned audit_thresh, float margin_scale, int rows_bf16,
+                                                  hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  if (n < 1 || n > NPA_GROUP_MAX) return hipErrorInvalidValue;
+  const int nsl = P.T + 1 - t0;
+  int n_use_max = n_stride_max < P.dune_max_num ? n_stride_max : P.dune_max_num;
+  if (n_use_max < 1) n_use_max = 1;
+  const size_t n_pad = ((size_t)n_use_max + SEL2_TRIP - 1) / SEL2_TRIP * SEL2_TRIP;
+  const size_t key_area = std::max<size_t>(n_pad * sizeof(unsigned), SEL_CAP * (NPA_MAX_E + 5 + 2) * sizeof(float));
+  const size_t shmem = (11 * 32 + 8 * 32 + 8 + NPA_GEO_BANDS) * sizeof(float) + (SEL_CAP + NPA_MAX_M) * sizeof(int) +
+                       (key_area + 15) / 16 * 16;
+  const int blocks = (batch + 7) / 8 * 8 * nsl;
+#define LAUNCHG(EE, BB)                                                                                             \
+  do {                                                                                                              \
+    static NpaDeviceOnce big_lds;                                                                                   \
+    int dev_ = 0;                                                                                                   \
+    if (shmem > 60 * 1024 && big_lds.need(&dev_)) {                                                                 \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(select_geo_group_kernel<EE, BB>),           \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
+      if (e_ != hipSuccess) return e_;                                                                              \
+      big_lds.done(dev_);                                                                                           \
+    }                                                                                                               \
+    hipExtLaunchKernelGGL((select_geo_group_kernel<EE, BB>), dim3(blocks, n), dim3(64), shmem, stream, ev_start, ev_stop, 0, P, G, \
+                          t0, nsl, batch, debug, audit_thresh, margin_scale);                                       \
+  } while (0)
+  // (instantiated for the polygon sizes of the benchmark configurations; c_api.hip keeps other sizes call by call)
+  if (P.E == 4) { if (rows_bf16) LAUNCHG(4, true); else LAUNCHG(4, false); }
+  else if (P.E == 8) { if (rows_bf16) LAUNCHG(8, true); else LAUNCHG(8, false); }
+  else return hipErrorInvalidValue;
+#undef LAUNCHG
+  return hipGetLastError();
+}
+extern "C" int npa_select_geo_group_supported(int E) { return E == 4 || E == 8; }
+
 // ---- geometric-key calibration (npa_create) ----------------------------------------------------------
 // f(p) = network distance - geometric distance is a smooth function of the robot-frame position and a property of
 // the checkpoint.  Per distance band (npa_geo_band) this records, over a square grid of spacing d, max |f| and the

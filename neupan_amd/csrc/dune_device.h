@@ -1067,3 +1067,26 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
   const int t = r_ % nsl + t0, b = bl + scene0;
 #include "select_geo_body.inc"
 }
+
+// select_geo_kernel over a GROUP of forward calls (pan_common.h: merged launches): blockIdx.y = the call, blockIdx.x what it
+// is above; the per-call pointers come out of the kernel arguments, everything else is the same statements.
+template <int E, bool BF16 = false>
+__global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(E <= 6 ? 4 : 3, E <= 6 ? 4 : 3))) void select_geo_group_kernel(
+    DevParams P, SelGeoGroup G, int t0, int nsl, int nscene, int debug, unsigned audit_thresh, float margin_scale) {
+  const SelGeoCall& q = G.c[blockIdx.y];
+  const float* __restrict__ wpack = q.wpack; const float* __restrict__ cur_s = q.cur_s; const float* __restrict__ points = q.points;
+  const float* __restrict__ vel = q.vel; const int* __restrict__ n_points = q.n_points; const int* __restrict__ flags = q.flags;
+  float* __restrict__ mu_sorted = q.mu_sorted; float* __restrict__ lam_sorted = q.lam_sorted; float* __restrict__ pts_sorted = q.pts_sorted;
+  float* __restrict__ dist_sorted = q.dist_sorted; int* __restrict__ count = q.count; unsigned* __restrict__ stats = q.stats;
+  const float* __restrict__ trig = q.trig; unsigned* __restrict__ audit = q.audit;
+  const int n_stride = q.n_stride;
+  unsigned audit_seed = q.audit_seed;
+#include "select_geo_carve.inc"
+  const int lane = threadIdx.x, j = lane & 31, hf = lane >> 5;
+  SELP_DECL;
+  const int w = blockIdx.x, xcd = w & 7, r_ = w >> 3;
+  const int bl = (r_ / nsl) * 8 + xcd;
+  if (bl >= nscene) return;
+  const int t = r_ % nsl + t0, b = bl;
+#include "select_geo_body.inc"
+}

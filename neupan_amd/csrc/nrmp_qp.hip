@@ -110,6 +110,30 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
   return hipGetLastError();
 }
 
+// nrmp_qp_kernel for a group of n forward calls that share the configuration, the batch size and the stream: ONE launch,
+// grid (batch, n).  The register-resident instantiations only (c_api.hip keeps everything else call by call).
+extern "C" int npa_qp_group_supported(int T, int M) {
+  static const bool force_generic = getenv("NPA_QP_GENERIC") != nullptr;
+  return !force_generic && M == 10 && (T == 10 || (T == 20 && qp_scan_wide())) ? 1 : 0;
+}
+extern "C" hipError_t npa_launch_qp_group(const DevParams& P, const QpGroup& G, int n, int batch, hipStream_t stream,
+                                          hipEvent_t ev_start, hipEvent_t ev_stop) {
+  if (n < 1 || n > NPA_GROUP_MAX || !npa_qp_group_supported(P.T, P.M)) return hipErrorInvalidValue;
+  const size_t shmem = npa_qp_shmem_bytes_path(P.T, P.M, 1);
+  static NpaDeviceOnce attr_set;
+  int dev_ = 0;
+  if (attr_set.need(&dev_)) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_group_kernel<10, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_group_kernel<20, 10, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set.done(dev_);
+  }
+  if (P.T == 10)
+    hipExtLaunchKernelGGL((nrmp_qp_group_kernel<10, 10>), dim3(batch, n), dim3(QP_THREADS), shmem, stream, ev_start, ev_stop, 0, P, G, batch);
+  else
+    hipExtLaunchKernelGGL((nrmp_qp_group_kernel<20, 10, true>), dim3(batch, n), dim3(QP_THREADS), shmem, stream, ev_start, ev_stop, 0, P, G, batch);
+  return hipGetLastError();
+}
+
 // forward solve + gradient w.r.t. the adjust parameters (generic kernel, one scene per workgroup)
 extern "C" hipError_t npa_launch_qp_backward(const DevParams& P, int batch, const float* nom_s, const float* nom_u,
                                              const float* ref_s, const float* ref_us, const float* mu_sorted,

@@ -301,3 +301,29 @@ void nrmp_qp_kernel(
   const int b = blockIdx.x + scene0;
 #include "nrmp_qp_body.inc"
 }
+
+// nrmp_qp_kernel over a GROUP of forward calls (pan_common.h: merged launches): blockIdx.y = the call, blockIdx.x = the scene
+// of that call; the per-call pointers come out of the kernel arguments, the body is the same statements.  Forward solves only.
+template <int TT, int MM, bool SCANW = false>
+__global__ __attribute__((amdgpu_flat_work_group_size(QP_THREADS, QP_THREADS), amdgpu_waves_per_eu(NPA_QP_WAVES, 3)))
+void nrmp_qp_group_kernel(DevParams P, QpGroup G, int nscene) {
+  extern __shared__ __attribute__((aligned(16))) double sm_all[];
+  constexpr bool BWD = false, ASET_T = false;
+  constexpr int WV = NPA_QP_WAVES;
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x >= nscene) return;
+  const int b = blockIdx.x;
+  const QpCall& q = G.c[blockIdx.y];
+  const float* cur_s_in = q.cur_s_in; const float* cur_u_in = q.cur_u_in;
+  const float* __restrict__ ref_s = q.ref_s; const float* __restrict__ ref_us = q.ref_us;
+  const float* __restrict__ mu_sorted = q.mu_sorted; const float* __restrict__ lam_sorted = q.lam_sorted;
+  const float* __restrict__ pts_sorted = q.pts_sorted; const float* __restrict__ dist_sorted = q.dist_sorted;
+  const int* __restrict__ count = q.count;
+  float* cur_s_out = q.cur_s_out; float* cur_u_out = q.cur_u_out; float* __restrict__ cur_d_out = q.cur_d_out;
+  float* __restrict__ out_s = q.out_s; float* __restrict__ out_u = q.out_u; float* __restrict__ out_d = q.out_d;
+  float* __restrict__ out_min_distance = q.out_min_distance; int* __restrict__ out_iters = q.out_iters;
+  float* __restrict__ out_nrmp_points = q.out_nrmp_points; int* __restrict__ flags = q.flags; float* __restrict__ state = q.state;
+  double* __restrict__ qp_info = q.qp_info; double* __restrict__ warm = q.warm; float* __restrict__ trig_out = q.trig_out;
+  const QpBackward bw{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+#include "nrmp_qp_body.inc"
+}

@@ -58,6 +58,31 @@ __device__ __forceinline__ void npa_setprio(int p) {      // (s_setprio takes an
   else __builtin_amdgcn_s_setprio(3);
 }
 
+// ---- merged launches of a GROUP of forward calls (npa_forward_batch_group, c_api.hip) --------------------------------
+// The chains of a burst that share a stream, a batch size and a configuration run each stage as ONE launch: blockIdx.y
+// selects the call, blockIdx.x is what it is in the single-call kernels.  A launch is a barrier over its scenes (the chain
+// cannot go on before its slowest scene is done): with G x 256 scenes behind one barrier the wave slots a tail leaves idle
+// are refilled from the same launch, and G chains need ONE hardware queue instead of G.  The per-call pointers travel by value
+// in the kernel arguments (an array indexed with blockIdx.y: scalar loads from the kernarg segment, nothing to upload).
+#define NPA_GROUP_MAX 8
+struct SelGeoCall {
+  const float* wpack; const float* cur_s; const float* points; const float* vel; const int* n_points; const int* flags;
+  float* mu_sorted; float* lam_sorted; float* pts_sorted; float* dist_sorted; int* count; unsigned* stats; const float* trig;
+  unsigned* audit; int n_stride; unsigned audit_seed;
+};
+struct SelGeoGroup { SelGeoCall c[NPA_GROUP_MAX]; };
+struct QpCall {
+  const float* cur_s_in; const float* cur_u_in; const float* ref_s; const float* ref_us; const float* mu_sorted;
+  const float* lam_sorted; const float* pts_sorted; const float* dist_sorted; const int* count; float* cur_s_out;
+  float* cur_u_out; float* cur_d_out; float* out_s; float* out_u; float* out_d; float* out_min_distance; int* out_iters;
+  float* out_nrmp_points; int* flags; float* state; double* qp_info; double* warm; float* trig_out;
+};
+struct QpGroup { QpCall c[NPA_GROUP_MAX]; };
+struct StageCall {
+  float* cur_s; const float* nom_s; float* cur_u; const float* nom_u; int* flags; int* count; int* state; float* trig;
+};
+struct StageGroup { StageCall c[NPA_GROUP_MAX]; };
+
 // ---- geometric distance keys ------------------------------------------------------------------------
 // The DUNE network approximates the distance from a point to the robot polygon; the closed-form distance is ~12
 // VALU instructions per edge, so select_kernel<E, true> uses IT to nominate the candidates (the kept rows are still

@@ -471,6 +471,8 @@ class PAN(torch.nn.Module):
 
         def step():
             validate()
+            if step.pre_issue is not None:           # (e.g. the upload of this step's inputs, on the step's stream)
+                step.pre_issue()
             if cur_dev() != idx:                     # the launches must see the device of the handle
                 with torch.cuda.device(dev):
                     rc = fn(*args, C.c_void_p(cur_stream(dev).cuda_stream), flags)
@@ -487,6 +489,7 @@ class PAN(torch.nn.Module):
             self.last_out = out
             return out
         step.device_index = idx
+        step.pre_issue = None                        # optional callable run on the step's stream in front of every issue
         # what StepGroup needs to issue this step inside a breadth-first burst (npa_forward_batch_group)
         step.group_call = dict(args=args, flags=flags, iter_num=self.iter_num, validate=validate, finish=finish, device=dev, lib=lib)
         return step
@@ -851,6 +854,9 @@ class StepGroup:
     (npa_forward_batch_group, include/neupan_amd.h): the staging launch of every step, then PAN iteration 0 of every
     step, ...  The launches and the results are those of calling the steps one after the other; every chain of the burst
     is running after the first 2 n launches instead of after 21 (n - 1).  `streams[i]` is the stream of steps[i].
+    Members that share ONE stream (and a batch size and a configuration) run every stage as one MERGED launch over all their
+    scenes (csrc/serve_group.hip: runs of <= 8 members; same results bitwise): 1 + 2K launches and one hardware queue for the
+    whole run instead of per member.
     issue(n) enqueues the first n members (default: all) and returns their output dicts."""
 
     def __init__(self, steps, streams):
@@ -861,6 +867,7 @@ class StepGroup:
         if len({c["flags"] for c in calls}) != 1 or len({str(c["device"]) for c in calls}) != 1:
             raise NeupanAmdError("StepGroup: the members must share the reset flag and the device")
         self.calls, self.flags, self.lib, self.device = calls, calls[0]["flags"], calls[0]["lib"], calls[0]["device"]
+        self.steps, self.streams = list(steps), list(streams) if streams is not None else None
         self.arr = (NpaForwardCall * len(steps))()
         names = [f[0] for f in NpaForwardCall._fields_]
         for a, c, st in zip(self.arr, calls, streams):
@@ -869,6 +876,19 @@ class StepGroup:
             assert len(vals) == len(names)
             for k, v in zip(names, vals):
                 setattr(a, k, v.value if isinstance(v, C.c_void_p) else v)
+
+    def merged(self, n=None):
+        """Would issue(n) run its members as merged launches (npa_forward_group_merged on runs of <= 8 members)?"""
+        n = len(self.calls) if n is None else n
+        want = (n + 7) // 8
+        base, extra, lo = n // want, n % want, 0
+        for r in range(want):
+            ln = base + (1 if r < extra else 0)
+            sub = (type(self.arr[0]) * ln)(*[self.arr[lo + i] for i in range(ln)])
+            if ln < 2 or not self.lib.npa_forward_group_merged(ln, sub):
+                return False
+            lo += ln
+        return True
 
     def issue(self, n=None):
         n = len(self.calls) if n is None else n
@@ -882,6 +902,11 @@ class StepGroup:
             raise NeupanAmdError("StepGroup.issue: iter_num < 1")
         for c in self.calls[:n]:
             c["validate"]()
+        for i in range(n):
+            pre = getattr(self.steps[i], "pre_issue", None)
+            if pre is not None:
+                with torch.cuda.stream(self.streams[i]):
+                    pre()
         with torch.cuda.device(self.device):
             rc = self.lib.npa_forward_batch_group(n, self.arr, self.flags)
         if rc:

@@ -91,3 +91,57 @@ def test_tracked_pmc_file_matches_the_built_kernels():
         assert bench.kernel_isa_hash("stage_kernel") and bench.kernel_isa_hash("void nrmp_qp_kernel<20, 10, false, true, 2, false>")
         assert bench.kernel_isa_hash("nrmp_qp_kernel<20, 10, false, true, 2, false>") != isa
         assert bench.kernel_isa_hash("no_such_kernel<1>") is None
+
+
+def test_compact_line_stays_under_the_drivers_limit():
+    """The LAST stdout line of bench.py is what the round driver parses; round 4's grew to 21 KB and was not parsed.  compact()
+    of the largest full record on file (every extra leg, parity listings, PMC dump, CPU sweep) must stay <= 6 KB and keep
+    every contract key, the roofline and cpu_baseline objects and one figure per extra leg."""
+    import bench
+    full = _line("r04_bench_driver_flags.json")
+    assert len(json.dumps(full)) > 20000
+    c = bench.compact(full, "bench_full.json")
+    txt = json.dumps(c)
+    assert len(txt) <= bench.COMPACT_LIMIT == 6144, len(txt)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in c, k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in c["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c["cpu_baseline"], k
+    assert c["value"] == full["value"] and c["roofline"]["frac"] == full["roofline"]["frac"]
+    assert "workload" in c["config"] and "model" not in c["config"]
+    assert c["parity"]["A"] is True and c["parity"]["D_unexplained"] == 0
+    assert set(c["extra"]["other_configs"]) == {k for k, v in full["extra"]["other_configs"].items() if isinstance(v, dict)}
+    assert all(isinstance(v["plans_per_s"], float) for v in c["extra"]["other_configs"].values())
+    # a record that would not fit sheds its least essential parts instead of growing
+    fat = json.loads(json.dumps(full))
+    fat["extra"]["other_configs"].update({f"pad{i}": fat["extra"]["other_configs"]["acker_2k_T20_K15"] for i in range(40)})
+    assert len(json.dumps(bench.compact(fat, "x"))) <= bench.COMPACT_LIMIT
+
+
+def test_bare_gpus_2_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's N = 1 command with another N) must
+    not die in argument handling: it re-executes itself under torch.distributed.run, one rank per GPU.  Driven here without a
+    GPU (--dry-run: gloo, a numpy stand-in for the step): rendezvous on 127.0.0.1, barrier + K steps + barrier, MAX over the
+    ranks, exactly ONE JSON line on stdout, from rank 0, with n_gpus = 2."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--dry-run"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["dry_run"] is True
+    assert d["unit"] == "plans/s" and d["scaling"] == "weak" and d["higher_is_better"] is True and d["value"] > 0
+    assert abs(d["value"] - 256 * 2 * 1e3 / d["ms_per_step"]) <= 2e-2 * d["value"]
+    # one rank, launched the way the driver launches N > 1
+    r1 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                         "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--dry-run"],
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    assert json.loads([ln for ln in r1.stdout.strip().split("\n") if ln.startswith("{")][-1])["n_gpus"] == 1

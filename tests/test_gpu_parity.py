@@ -956,6 +956,80 @@ def test_breadth_first_group_issue_equals_call_by_call():
     loop.close()
 
 
+@pytest.mark.parametrize("cfgname,B,nfl,over", [("diff_1k_T10_K10", 40, 5, {}), ("diff_1k_T10_K10", 24, 10, {"iter_threshold": 0.1}),
+                                                ("dyna_4k_T10_K10", 16, 3, {}), ("acker_2k_T20_K15", 16, 4, {}),
+                                                ("poly8_5k_T10_K10", 16, 2, {}), ("diff_1k_T10_K10", 24, 17, {})])
+def test_merged_group_launches_equal_call_by_call(cfgname, B, nfl, over):
+    """Steps of a group that share ONE stream run every stage as one launch over all their scenes (npa_forward_batch_group ->
+    select_geo_group_kernel / nrmp_qp_group_kernel, blockIdx.y = the call): bitwise the controls, states, distances and
+    iteration counts of planning the same batches one call after the other -- every benchmark configuration, ragged clouds with
+    empty scenes, early exit on, 2 ... 17 members (runs of <= 8 calls), consecutive group calls (state carried / reset), and
+    the merged path is what actually ran (the library counts its merged launches)."""
+    import ctypes as C
+    import torch
+    from gpu_helpers import make_gpu_pan
+    from neupan_amd import _lib
+    from neupan_amd.pan import StepGroup
+    cfg = CONFIGS[cfgname]
+    lib = _lib.load()
+    lib.npa_dbg_group_merged_launches.restype = C.c_ulonglong
+    dev = torch.device("cuda", 0)
+    keys = ("nom_s", "nom_u", "ref_s", "ref_us", "points")
+    batches = [make_batch(cfg, 15000 + 100 * j, B) for j in range(nfl)]
+    n_pts = []
+    for j in range(nfl):
+        n = np.full(B, batches[j]["points"].shape[2], dtype=np.int32)
+        n[:5] = [0, 1, 7 + j, 65, 257]
+        n_pts.append(n)
+    args = [[torch.from_numpy(bt[k]).to(dev) for k in keys] +
+            [torch.from_numpy(bt["velocities"]).to(dev) if bt.get("velocities") is not None else None, torch.from_numpy(n).to(dev)]
+            for bt, n in zip(batches, n_pts)]
+    fields = ("opt_u", "opt_s", "opt_d", "min_distance", "iters", "nrmp_points")
+
+    def snap(o):
+        return {k: o[k].cpu().numpy().copy() for k in fields if o.get(k) is not None}
+
+    # reference: every batch planned alone, twice in a row (the second call starts from the state the first one left)
+    ref = []
+    for a in args:
+        p = make_gpu_pan(cfg, **over)
+        r1 = snap(p.forward_batch(*a))
+        r2 = snap(p.forward_batch(*a))
+        ref.append((r1, r2))
+    pans = [make_gpu_pan(cfg, **over) for _ in range(nfl)]
+    st = torch.cuda.Stream(device=dev)
+    steps = []
+    with torch.cuda.stream(st):
+        for j in range(nfl):
+            steps.append(pans[j].make_step(*args[j], reset_state=True))
+    torch.cuda.synchronize()
+    for p in pans:
+        p.reset_stop_state()
+    torch.cuda.synchronize()
+    grp = StepGroup(steps, [st] * nfl)
+    before = lib.npa_dbg_group_merged_launches()
+    with torch.cuda.stream(st):
+        o1 = [snap(o) for o in (grp.issue(), torch.cuda.synchronize())[0]]
+        o2 = [snap(o) for o in (grp.issue(), torch.cuda.synchronize())[0]]
+    assert lib.npa_dbg_group_merged_launches() > before, "the merged path did not run"
+    for j in range(nfl):
+        for k in ref[j][0]:
+            assert np.array_equal(o1[j][k], ref[j][0][k], equal_nan=True), (cfgname, "first call", j, k)
+            assert np.array_equal(o2[j][k], ref[j][1][k], equal_nan=True), (cfgname, "second call", j, k)
+    # members on different streams keep the breadth-first call-by-call order (and the same results)
+    for p in pans:
+        p.reset_stop_state()
+    torch.cuda.synchronize()
+    sts = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
+    grp2 = StepGroup(steps, sts)
+    before = lib.npa_dbg_group_merged_launches()
+    o3 = [snap(o) for o in (grp2.issue(), torch.cuda.synchronize())[0]]
+    assert lib.npa_dbg_group_merged_launches() == before
+    for j in range(nfl):
+        for k in ref[j][0]:
+            assert np.array_equal(o3[j][k], ref[j][0][k], equal_nan=True), (cfgname, "own streams", j, k)
+
+
 @pytest.mark.parametrize("cfgname,B,over", [("diff_1k_T10_K10", 256, {}), ("diff_1k_T10_K10", 80, {"iter_threshold": 0.1}),
                                             ("dyna_4k_T10_K10", 64, {}), ("acker_2k_T20_K15", 64, {}), ("poly8_5k_T10_K10", 64, {})])
 def test_scene_kernel_agrees_with_the_two_launch_path(cfgname, B, over):
