@@ -3,15 +3,14 @@
 1 GPU (per rank), batch = 256 synthetic scenes, diff robot, 1000 obstacle points, T = 10,
 K = 10 PAN iterations (iter_threshold = 0 so that exactly K run), fp32 DUNE + fp64 QP.
 
-    python bench.py [--gpus N --steps K --warmup W]          # N > 1 without a launcher: re-executes itself under
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \      torch.distributed.run
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N --steps K --warmup W]          # (N > 1 without a launcher: re-executes itself as below)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A step = one pass of the hot path (one forward call: K x {selection, QP}) over one batch of 256 scenes per
 rank, inputs already resident in HBM; with N > 1 ranks every rank plans its own 256 scenes (weak scaling, no
 data-path collective) and the control outputs are all-gathered over RCCL inside the timed region.  Like any
-serving loop the bench keeps `--inflight` independent batches in flight; `--chains C` of them (default 4) form
-one launch chain each: the steps of a chain are issued as ONE library call (npa_forward_batch_group) on ONE
+serving loop the bench keeps `--inflight` independent batches in flight, grouped into `--chains C` launch chains
+(default: five batches per chain): the steps of a chain are issued as ONE library call (npa_forward_batch_group) on ONE
 stream and every stage of theirs runs as one merged launch over all their scenes (blockIdx.y = the step).
 Every step still executes its full K iterations inside the timed region, on its own 256 scenes, its own
 buffers and its own planner state; `--chains 0` gives one stream and one launch chain per step (round 4's
@@ -57,18 +56,19 @@ import torch  # noqa: E402
 WORKLOAD = "diff_1k_T10_K10"
 BATCH = 256
 BURST_DEFAULT = 1
-CHAINS_DEFAULT = 4
+CHAINS_DEFAULT = -1        # -1: batches in flight / 5 (four chains of five steps at 20 in flight, eight at 40)
 # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table (256 CUs x 4 SIMDs, 2.4 GHz)
 PEAK_FP64_VALU_TFLOPS = 78.6
 PEAK_FP32_MFMA_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32: what the exact encoder runs on
 PEAK_F16_MFMA_TFLOPS = 2500.0       # dense fp16 / bf16 MFMA
 N_SIMD = 1024
-PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r04_pmc.json", "r03_pmc.json")]     # newest first
+PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json")]     # newest first
 # which source files a kernel's counters depend on (a record is "current" only while these are unchanged)
 _QP_SRC = ("nrmp_qp.hip", "nrmp_qp_device.h", "nrmp_qp_body.inc", "aset_reduce.h", "pan_common.h")
 _DUNE_SRC = ("dune.hip", "dune_device.h", "select_geo_carve.inc", "select_geo_body.inc", "pan_common.h")
-KERNEL_SOURCES = {"nrmp_qp_kernel": _QP_SRC, "select_geo_kernel": _DUNE_SRC, "select_kernel": _DUNE_SRC, "dune_kernel": _DUNE_SRC,
-                  "stage_kernel": ("c_api.hip", "pan_common.h")}
+KERNEL_SOURCES = {"nrmp_qp_kernel": _QP_SRC, "nrmp_qp_group_kernel": _QP_SRC, "select_geo_kernel": _DUNE_SRC,
+                  "select_geo_group_kernel": _DUNE_SRC, "select_kernel": _DUNE_SRC, "dune_kernel": _DUNE_SRC,
+                  "stage_kernel": ("c_api.hip", "pan_common.h"), "stage_group_kernel": ("c_api.hip", "pan_common.h")}
 
 
 def source_hash(files=None):
@@ -218,6 +218,23 @@ class Loop:
                 if j == 0:
                     self._sel = [t.index_select(0, scene_index).contiguous() if t is not None else None for t in a]
                 a = self._sel
+            if h2d:
+                # the step's inputs live in ONE device buffer (views, 256-byte aligned) mirrored by ONE pinned host buffer: a
+                # host caller ships them with a single copy per step
+                offs, tot = [], 0
+                for t in a:
+                    offs.append(tot)
+                    tot += 0 if t is None else (t.numel() * 4 + 255) // 256 * 256
+                blob = torch.empty(tot, dtype=torch.uint8, device=dev)
+                views = []
+                for t, o in zip(a, offs):
+                    if t is None:
+                        views.append(None); continue
+                    v = blob[o:o + t.numel() * 4].view(torch.float32).view(t.shape)
+                    v.copy_(t)
+                    views.append(v)
+                a = views
+                self._blobs = getattr(self, "_blobs", []) + [blob]
             self.args.append(a)
         torch.cuda.synchronize(dev)
         self.cur = torch.cuda.current_stream(dev)
@@ -245,12 +262,10 @@ class Loop:
             # every step's inputs come from pinned host memory, uploaded on the step's own stream in front of the step (what
             # a host caller of the reference does per control cycle, neupan.py:123-127); the device tensors the step reads
             # are the ones it captured
-            self.host = []
+            self.host = [b.cpu().pin_memory() for b in self._blobs]
             for j in range(nfl):
-                pairs = [(t, t.cpu().pin_memory()) for t in self.args[j] if t is not None]
-                self.host.append(pairs)
-                self.steps[j].pre_issue = (lambda pr: (lambda: [d.copy_(h_, non_blocking=True) for d, h_ in pr]))(pairs)
-            self.h2d_bytes = sum(h_.numel() * h_.element_size() for _, h_ in self.host[0])
+                self.steps[j].pre_issue = (lambda d, h_: (lambda: d.copy_(h_, non_blocking=True)))(self._blobs[j], self.host[j])
+            self.h2d_bytes = int(self.host[0].numel())
         self.loop = StepLoop(self.steps, self.streams, self.gatherer, self.cur, threads=issue_threads, burst=Loop.BURST)
 
     def run(self, n):
@@ -379,7 +394,9 @@ def parity_leg(lp, scenes, cores, n_ulp=8, n_perm=4, sweep=False, explain=True):
     tp = tr["trace_pts"].cpu().numpy()[:scenes] if tr.get("trace_pts") is not None else None
     if explain:
         dev, why = one_step_consistency(lp.workload, range(scenes), tr["trace_s"].cpu().numpy()[:scenes], trace_u[:scenes], cores,
-                                        explain=True, trace_pts=tp, trace_merit=tr["trace_qp_info"].cpu().numpy()[:scenes, :, 1])
+                                        explain=True, trace_pts=tp, trace_merit=tr["trace_qp_info"].cpu().numpy()[:scenes, :, 1],
+                                        trace_rows=None if tr.get("trace_mu") is None else (tr["trace_mu"].cpu().numpy()[:scenes],
+                                                                                            tr["trace_lam"].cpu().numpy()[:scenes]))
         rep["one_step"] = one_step_report(dev, why=why)
     else:
         rep["one_step"] = one_step_report(one_step_consistency(lp.workload, range(scenes), tr["trace_s"].cpu().numpy()[:scenes],
@@ -395,9 +412,11 @@ def slim(rep):
             "well_posed_frac")
     out = {k: rep[k] for k in keep if k in rep}
     os_ = rep.get("one_step", {})
-    out["one_step"] = {k: os_[k] for k in ("steps_checked", "max", "p99", "median", "frac_le_tol", "unexplained", "explained_by") if k in os_}
+    out["one_step"] = {k: os_[k] for k in ("steps_checked", "max", "p99", "median", "frac_le_tol", "unexplained", "stalled", "explained_by",
+                                           "largest_explained") if k in os_}
     if os_.get("above_tol"):
         out["one_step"]["worst_above_tol"] = os_["above_tol"][:2]
+        out["one_step"]["unexplained_or_stalled"] = [w for w in os_["above_tol"] if w["explained"] is None or w.get("stalled")][:6]
     return out
 
 
@@ -555,8 +574,8 @@ def compact(line, full_path):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=120)            # (whole rounds of the 20 batches in flight)
-    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=240)            # (whole rounds of the 40 batches in flight)
+    ap.add_argument("--warmup", type=int, default=80)
     ap.add_argument("--cpu-scenes", type=int, default=0,
                     help="scenes of the first batch planned by the CPU oracle + its ensemble (rank 0, N=1); 0 = 256 on a host "
                          "with >= 64 cores, else 96")
@@ -576,7 +595,8 @@ def main():
                          "(npa_forward_batch_group: staging of every chain, then PAN iteration 0 of every chain, ...); 0: call by call")
     ap.add_argument("--chains", type=int, default=CHAINS_DEFAULT,
                     help="launch chains the batches in flight form: the steps of a chain share one stream and run every stage as ONE "
-                         "merged launch (npa_forward_batch_group); 0: one stream and one launch chain per step (round 4's schedule)")
+                         "merged launch (npa_forward_batch_group); -1 (default): batches in flight / 5; 0: one stream and one launch "
+                         "chain per step (round 4's schedule)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: the launch / rendezvous / timing protocol only (gloo)")
     ap.add_argument("--workload", default=WORKLOAD,
                     choices=sorted(k for k in __import__("neupan_amd.scenes", fromlist=["CONFIGS"]).CONFIGS),
@@ -623,10 +643,18 @@ def main():
     # one queue while the other 21 run on -- what rounds 2 and 3 reported as "the communicator's passive cost", 11 - 24 % of a
     # 128-step run, gone with <= 18 chains or once the communicator is destroyed).  A run of <= 20 steps
     # is ONE wave of chains: 20 chains finish it in one chain latency, 18 need two.
-    # With merged launches (--chains C > 0) the chains, not the steps, own the streams: C queues whatever --inflight is.
-    nfl = args.inflight if args.inflight > 0 else (20 if (dist is None or args.steps <= 20 or args.chains > 0) else 18)
+    # With merged launches (--chains C > 0) the chains, not the steps, own the streams: C queues whatever --inflight is, so the
+    # batches in flight are no longer capped by the queue budget: 40 once the run has rounds for them (>= 3 rounds), 20 below
+    # (the driver's 20-step region is one round of 20).  Default chains: 5 steps per chain (measured: gpurun_out/r05a/sweep.txt).
+    merged = args.chains != 0 and bool(args.burst) and not args.graph
+    if args.inflight > 0:
+        nfl = args.inflight
+    elif merged:
+        nfl = 40 if args.steps >= 120 else 20
+    else:
+        nfl = 20 if (dist is None or args.steps <= 20) else 18
     Loop.BURST = bool(args.burst)
-    Loop.CHAINS = max(0, args.chains)
+    Loop.CHAINS = (max(1, nfl // 5) if args.chains < 0 else args.chains) if merged else 0
     lp = Loop(args.workload, B, nfl, dev, rank=rank, world=world, dist=None if os.environ.get("NPA_BENCH_NOGATHER") else dist,
               graph=args.graph, issue_threads=args.issue_threads)
     E = lp.pans[0].E
@@ -860,10 +888,12 @@ def main():
     if extras:
         t_ex = time.perf_counter()
         ex = {}
+        nfx = 20                                # batches in flight of every extra leg (four chains of five where the steps merge)
+        Loop.CHAINS = 4 if merged else 0
         paths = {}
         for tag, env in (("exact_fp32_keys", {"NPA_DUNE_FP32KEYS": "1"}), ("network_keys_1", {"NPA_KEY_TERMS": "1"}),
                          ("network_keys_3", {"NPA_KEY_TERMS": "3"})):
-            res, l2 = short_run(WORKLOAD, B, nfl, dev, 60, 20, env=env, issue_threads=args.issue_threads)
+            res, l2 = short_run(WORKLOAD, B, nfx, dev, 60, 20, env=env, issue_threads=args.issue_threads)
             # the same plans as the default path (the keys only nominate): bitwise, checked on batch 0
             l2.pans[0].reset_stop_state()
             res["controls_equal_default_path"] = bool(np.array_equal(l2.pans[0].forward_batch(*l2.args[0])["opt_u"].cpu().numpy(), timed_u))
@@ -874,7 +904,7 @@ def main():
                                        "paths: dune_kernel encodes EVERY point of every slice (SURVEY 8(d)'s literal path), "
                                        "dune_executed_mfma prices that work against the peak of the MFMA it runs on")
         # SURVEY 8(d)'s uniform cloud
-        res, l2 = short_run("uniform_1k_T10_K10", B, nfl, dev, 60, 20, issue_threads=args.issue_threads)
+        res, l2 = short_run("uniform_1k_T10_K10", B, nfx, dev, 60, 20, issue_threads=args.issue_threads)
 
         def cand(workload, a_):
             with environ({"NPA_SEL_DEBUG": "1"}):
@@ -897,10 +927,10 @@ def main():
         ex["uniform_cloud"] = res
         l2.close()
         others = {}
-        for tag, wl, b_, nf, env in (("acker_2k_T20_K15", "acker_2k_T20_K15", B, nfl, None),
+        for tag, wl, b_, nf, env in (("acker_2k_T20_K15", "acker_2k_T20_K15", B, nfx, None),
                                      ("dyna_4k_T10_K10_batch1024", "dyna_4k_T10_K10", 1024, 4, None),
-                                     ("poly8_5k_T10_K10_exact_fp32_rows", "poly8_5k_T10_K10", B, nfl, None),
-                                     ("poly8_5k_T10_K10_bf16_rows", "poly8_5k_T10_K10", B, nfl, {"NPA_ROWS_PRECISION": "bf16"})):
+                                     ("poly8_5k_T10_K10_exact_fp32_rows", "poly8_5k_T10_K10", B, nfx, None),
+                                     ("poly8_5k_T10_K10_bf16_rows", "poly8_5k_T10_K10", B, nfx, {"NPA_ROWS_PRECISION": "bf16"})):
             # (K = 15 / T = 20 and 5000-point chains are 20 - 30 ms long: enough steps for several rounds of the chains in flight)
             res, l2 = short_run(wl, b_, nf, dev, 24 if b_ > B else 100, 8 if b_ > B else 20, env=env, issue_threads=args.issue_threads)
             if env:
@@ -925,7 +955,7 @@ def main():
         for tag, ch in (("one_chain_per_step", 0), ("2_chains", 2), ("10_chains", 10)):
             if ch == lp_chains:
                 continue
-            res, l2 = short_run(WORKLOAD, B, nfl, dev, 60, 20, issue_threads=args.issue_threads, chains=ch)
+            res, l2 = short_run(WORKLOAD, B, nfx, dev, 60, 20, issue_threads=args.issue_threads, chains=ch)
             shapes[tag] = {k: res[k] for k in ("plans_per_s", "ms_per_step", "steps", "scenes_per_step", "batches_in_flight", "chains",
                                                "select_launch_ms", "qp_launch_ms")}
             l2.close()
@@ -935,7 +965,7 @@ def main():
         # SURVEY 8(d)'s second run: the reference's default stop threshold (pan.py:243: iter_threshold = 0.1).  Every step starts
         # from a cleared stop-criterion state (like every other leg), so a scene runs at least 2 iterations: the first only
         # stores its iterate (pan.py:218-221)
-        le = Loop(WORKLOAD, B, nfl, dev, issue_threads=args.issue_threads, over={"iter_threshold": 0.1})
+        le = Loop(WORKLOAD, B, nfx, dev, issue_threads=args.issue_threads, over={"iter_threshold": 0.1})
         re_ = le.timed(60, 20)
         it = le.last_iters
         ex["early_exit"] = {"iter_threshold": 0.1, "plans_per_s": round(B * 60 / re_["elapsed"], 1), "steps": 60,
@@ -947,7 +977,7 @@ def main():
         le.close()
         # PCIe-inclusive: every step's inputs (nominal and reference trajectories, the cloud) uploaded from pinned host memory on
         # the step's own stream in front of the step -- what a host caller of the reference does per cycle (neupan.py:123-127)
-        lh = Loop(WORKLOAD, B, nfl, dev, issue_threads=args.issue_threads, h2d=True)
+        lh = Loop(WORKLOAD, B, nfx, dev, issue_threads=args.issue_threads, h2d=True)
         rh = lh.timed(60, 20)
         ex["h2d_inclusive"] = {"plans_per_s": round(B * 60 / rh["elapsed"], 1), "steps": 60, "bytes_per_step": int(lh.h2d_bytes),
                                "upload_GBps": round(lh.h2d_bytes * 60 / rh["elapsed"] / 1e9, 2),

@@ -12,9 +12,13 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libneupan_amd.so")
-SOURCES = ["dune.hip", "nrmp_qp.hip", "frontend.hip", "dune_labels.hip", "aset_reduce.hip", "c_api.hip", "serve_group.hip", "pan_scene.hip"]
+# The product build.  NPA_EXPERIMENTS=1 in the environment adds the experiments on record (the forward call
+# as one launch, the scene-wide selection, the active-set launch, the first form of the geometric selection) and their knobs.
+EXPERIMENTS = os.environ.get("NPA_EXPERIMENTS", "0") not in ("", "0")
+SOURCES = ["dune.hip", "nrmp_qp.hip", "frontend.hip", "dune_labels.hip", "c_api.hip", "serve_group.hip"] + \
+          (["aset_reduce.hip", "pan_scene.hip"] if EXPERIMENTS else [])
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
-         "-Wno-unused-result", "-Wno-unused-value"]
+         "-Wno-unused-result", "-Wno-unused-value"] + (["-DNPA_EXPERIMENTS"] if EXPERIMENTS else [])
 
 
 def hipcc_path():

@@ -29,6 +29,15 @@ extern "C" hipError_t npa_launch_select_geo(const DevParams& P, const float* wpa
                                             unsigned* stats, int debug, unsigned* audit, unsigned audit_thresh,
                                             unsigned audit_seed, float margin_scale, int rows_bf16, hipStream_t stream,
                                             hipEvent_t ev_start, hipEvent_t ev_stop);
+// Experiments on record (measured slower than the default path, or not finished) are compiled only with
+// -DNPA_EXPERIMENTS (NPA_EXPERIMENTS=1 python -m neupan_amd.build): the forward call as one launch (pan_scene.hip), the selection
+// with one wave per scene (select_scene.h), the active-set launch in front of the interior-point launch (aset_reduce.*), the
+// first form of the geometric selection.  The default build has neither their kernels nor their environment knobs.
+#ifdef NPA_EXPERIMENTS
+#define NPA_VERSION_SUFFIX " +experiments"
+#else
+#define NPA_VERSION_SUFFIX ""
+#endif
 extern "C" int npa_select_scene_supported(int E, int T);
 extern "C" hipError_t npa_launch_select_scene(const DevParams& P, const float* wpack, int batch, int scene0, int t0, int n_stride,
                                               const float* cur_s, const float* points, const float* vel, const int* n_points,
@@ -162,7 +171,15 @@ extern "C" const char* npa_last_error(void) { return g_err.c_str(); }
 #ifndef NPA_HIPCC_VERSION
 #define NPA_HIPCC_VERSION "unknown"
 #endif
-extern "C" const char* npa_version(void) { return "neupan_amd 0.2 (gfx950, hipcc " NPA_HIPCC_VERSION ")"; }
+extern "C" const char* npa_version(void) { return "neupan_amd 0.3 (gfx950, hipcc " NPA_HIPCC_VERSION ")" NPA_VERSION_SUFFIX; }
+#ifndef NPA_EXPERIMENTS
+extern "C" int npa_select_scene_supported(int, int) { return 0; }
+extern "C" hipError_t npa_launch_select_scene(const DevParams&, const float*, int, int, int, int, const float*, const float*, const float*,
+                                              const int*, const int*, const float*, float*, float*, float*, float*, int*, unsigned*, int,
+                                              unsigned*, unsigned, unsigned, float, hipStream_t, hipEvent_t, hipEvent_t) {
+  return hipErrorInvalidValue;
+}
+#endif
 
 static int mdim(const DevParams& P) { return P.M > 0 ? P.M : 1; }
 // per-slice stride of the key buffer inside the workspace: none with geometric keys (select_kernel keeps them in LDS)
@@ -414,23 +431,19 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
   }
   h->sel_debug = getenv("NPA_SEL_DEBUG") != nullptr;
   h->qp_warm = getenv("NPA_QP_COLD") == nullptr;
+  h->qp_generic = getenv("NPA_QP_GENERIC") != nullptr;
+  P.qp_aset = 0;
+#ifdef NPA_EXPERIMENTS
+  h->qp_scan_wide = getenv("NPA_QP_NOSCAN_WIDE") == nullptr;
   P.qp_aset = (getenv("NPA_QP_ASET") != nullptr && atoi(getenv("NPA_QP_ASET")) != 0) ? 1 : 0;
   h->aset_auto = getenv("NPA_QP_ASET") == nullptr;
-  h->qp_generic = getenv("NPA_QP_GENERIC") != nullptr;
   h->scene_kernel = getenv("NPA_SCENE_KERNEL") != nullptr && atoi(getenv("NPA_SCENE_KERNEL")) != 0;
   h->select_scene = getenv("NPA_SELECT_SCENE") != nullptr && atoi(getenv("NPA_SELECT_SCENE")) != 0;
   if (const char* env = getenv("NPA_SCENE_MIN_BATCH")) { int v = atoi(env); if (v >= 1) h->scene_min_batch = v; }
-  h->qp_scan_wide = getenv("NPA_QP_NOSCAN_WIDE") == nullptr;
   if (const char* env = getenv("NPA_QP_ASET_SMALL")) { int v = atoi(env); if (v >= 0) h->aset_small_batch = v; }
   if (const char* env = getenv("NPA_QP_ASET_FROM")) { int v = atoi(env); if (v >= 1) h->aset_from_iter = v; }
-  P.prio_sel = 0; P.prio_qp0 = 3; P.prio_qp1 = 3; P.prio_qp2 = 3; P.prio_it1 = 1 << 30; P.prio_it2 = 1 << 30;
-  if (const char* env = getenv("NPA_PRIO")) {
-    int v[6];
-    if (sscanf(env, "%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]) == 6) {
-      P.prio_sel = v[0]; P.prio_qp0 = v[1]; P.prio_qp1 = v[2]; P.prio_qp2 = v[3]; P.prio_it1 = v[4]; P.prio_it2 = v[5];
-    }
-  }
   if (const char* env = getenv("NPA_QP_ASET_MIN_BATCH")) { int v = atoi(env); if (v >= 1) h->aset_min_batch = v; }
+#endif
   hipError_t e = hipGetDevice(&h->device);
   if (e == hipSuccess) {
     hipDeviceProp_t prop;
@@ -567,7 +580,9 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
     if (e == hipSuccess) e = hipMalloc(&h->audit_dev, 8 * sizeof(unsigned));       // [4]: launches seen (device side)
     if (e == hipSuccess) e = hipHostMalloc(&h->audit_host, sizeof(unsigned), hipHostMallocMapped);
     if (e == hipSuccess) e = audit_block_reset(h);
+#ifdef NPA_EXPERIMENTS
     h->select_v1 = getenv("NPA_SELECT_V1") != nullptr;
+#endif
     if (const char* env = getenv("NPA_ROWS_PRECISION")) {
       if (!strcmp(env, "bf16")) {
         if (e == hipSuccess && !(h->key_terms == 4 && !h->select_v1 && (P.E == 4 || P.E == 8))) {
@@ -1204,6 +1219,15 @@ extern "C" int npa_forward_end(npa_handle* h) {
 }
 
 // ---- the whole forward call as one launch (pan_scene.hip), opt-in -----------------------------------------------------
+#ifndef NPA_EXPERIMENTS
+static int npa_pan_scene_supported(int, int, int) { return 0; }
+static hipError_t npa_launch_pan_scene(const DevParams&, const float*, int, int, const float*, const float*, const int*, float*, float*, float*,
+                                       const float*, const float*, float*, float*, float*, float*, int*, float*, float*, float*, float*,
+                                       int*, float*, int*, float*, double*, double*, float*, int, int, unsigned*, unsigned*, unsigned,
+                                       unsigned, float, hipStream_t, hipEvent_t, hipEvent_t) {
+  return hipErrorInvalidValue;
+}
+#else
 extern "C" int npa_pan_scene_supported(int E, int T, int M);
 extern "C" hipError_t npa_launch_pan_scene(const DevParams& P, const float* wpack, int batch, int n_stride, const float* points,
                                            const float* vel, const int* n_points, float* cur_s, float* cur_u, float* cur_d,
@@ -1213,6 +1237,7 @@ extern "C" hipError_t npa_launch_pan_scene(const DevParams& P, const float* wpac
                                            double* warm, float* trig, int iters, int debug, unsigned* stats, unsigned* audit,
                                            unsigned audit_thresh, unsigned audit_seed, float margin_scale, hipStream_t stream,
                                            hipEvent_t ev_start, hipEvent_t ev_stop);
+#endif
 // the pending call (begun) qualifies: the default selection (geometric keys, exact rows) and the register-resident interior-
 // point solve, nothing that needs a launch of its own between the two
 static bool scene_kernel_applies(npa_handle* h) {

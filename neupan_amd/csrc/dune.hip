@@ -67,7 +67,8 @@ extern "C" hipError_t npa_launch_encode(const DevParams& P, const float* wpack, 
   // one 16-wave workgroup per CU once every wave has a few tiles to stream; small launches keep
   // 4-wave workgroups (more CUs busy).  NPA_ENC_WAVES=4 forces the small form.
   static const bool small_only = getenv("NPA_ENC_WAVES") && atoi(getenv("NPA_ENC_WAVES")) == 4;
-  int waves = (split && !small_only && tiles >= (long long)n_cu * 16 * 4) ? 16 : DUNE_WAVES;
+  // (the 16-wave form is instantiated for E = 4, the polygon of every shipped robot but one; other sizes keep 4-wave workgroups)
+  int waves = (split && !small_only && P.E == 4 && tiles >= (long long)n_cu * 16 * 4) ? 16 : DUNE_WAVES;
   const int slots = waves >= 8 ? n_cu : n_cu * blocks_per_cu;
   int blocks = (int)((tiles + waves - 1) / waves);
   if (blocks > slots) blocks = slots;
@@ -81,21 +82,26 @@ extern "C" hipError_t npa_launch_encode(const DevParams& P, const float* wpack, 
                         chunk, trig)
 #define LAUNCH(EE)                                                                                                  \
   do {                                                                                                              \
-    if (single && waves == 16) LAUNCH1(EE, 1, 16);                                                                  \
-    else if (single) LAUNCH1(EE, 1, DUNE_WAVES);                                                                    \
-    else if (split && waves == 16) LAUNCH1(EE, 3, 16);                                                              \
+    if (single) LAUNCH1(EE, 1, DUNE_WAVES);                                                                         \
     else if (split) LAUNCH1(EE, 3, DUNE_WAVES);                                                                     \
     else LAUNCH1(EE, 0, DUNE_WAVES);                                                                                \
   } while (0)
+#define LAUNCH16(EE)                                                                                                \
+  do {                                                                                                              \
+    if (single && waves == 16) LAUNCH1(EE, 1, 16);                                                                  \
+    else if (split && waves == 16) LAUNCH1(EE, 3, 16);                                                              \
+    else LAUNCH(EE);                                                                                                \
+  } while (0)
   switch (P.E) {
     case 3: LAUNCH(3); break;
-    case 4: LAUNCH(4); break;
+    case 4: LAUNCH16(4); break;
     case 5: LAUNCH(5); break;
     case 6: LAUNCH(6); break;
     case 7: LAUNCH(7); break;
     case 8: LAUNCH(8); break;
     default: return hipErrorInvalidValue;
   }
+#undef LAUNCH16
 #undef LAUNCH
 #undef LAUNCH1
   return hipGetLastError();
@@ -134,11 +140,19 @@ extern "C" hipError_t npa_launch_select(const DevParams& P, const float* wpack, 
                           wpack, n_stride, cur_s, points, vel, n_points, flags, gkeys, tps * 32, mu_sorted, lam_sorted, \
                           pts_sorted, dist_sorted, count, scene0, t0, approx, e0, stats, trig);                      \
   } while (0)
+#ifdef NPA_EXPERIMENTS
 #define LAUNCH(EE)                                                                                                  \
   do {                                                                                                              \
     if (geo) LAUNCH1(EE, true);                                                                                     \
     else LAUNCH1(EE, false);                                                                                        \
   } while (0)
+#else               // (the first form of the geometric selection, NPA_SELECT_V1: experiments build only)
+#define LAUNCH(EE)                                                                                                  \
+  do {                                                                                                              \
+    if (geo) return hipErrorInvalidValue;                                                                           \
+    LAUNCH1(EE, false);                                                                                             \
+  } while (0)
+#endif
   switch (P.E) {
     case 3: LAUNCH(3); break;
     case 4: LAUNCH(4); break;

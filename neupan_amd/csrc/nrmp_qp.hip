@@ -40,8 +40,12 @@ static bool qp_fast_path(int T, int M) { return (T == 10 || T == 20) && M == 10;
 
 // LDS bytes of one scene; `fast` = the register-resident instantiation (packed H, L and P staging)
 static bool qp_scan_wide() {
+#ifdef NPA_EXPERIMENTS       // (NPA_QP_NOSCAN_WIDE=1: the T = 20 instantiation with a stored Phi, for A/B measurements)
   static const bool v = getenv("NPA_QP_NOSCAN_WIDE") == nullptr;
   return v;
+#else
+  return true;
+#endif
 }
 // LDS bytes of one scene; fast = the register-resident instantiation (packed H, L and P staging); scan = its form
 // without a stored Phi (T <= 16, or T <= 32 with the wide scans)
@@ -85,8 +89,12 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
   if (attr_set.need(&dev_)) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<10, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#ifdef NPA_EXPERIMENTS
     hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<10, 10, false, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
+#ifdef NPA_EXPERIMENTS
     hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<20, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#endif
     hipFuncSetAttribute(reinterpret_cast<const void*>(nrmp_qp_kernel<20, 10, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set.done(dev_);
   }
@@ -99,12 +107,18 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
   const bool scan_wide = qp_scan_wide();
   if (aset_launch) {
     // the active-set launch that precedes the interior-point launch of the same PAN iteration (see the kernel's top)
+#ifdef NPA_EXPERIMENTS
     if (!(P.T == 10 && P.M == 10 && !force_generic && P.qp_aset && warm && flags)) return hipErrorInvalidValue;
     QP_LAUNCH(10, 10, false, false, 2, true);
+#else
+    return hipErrorInvalidValue;          // (the active-set instantiation exists in the experiments build only)
+#endif
   }
   else if (P.T == 10 && P.M == 10 && !force_generic) QP_LAUNCH(10, 10);
   else if (P.T == 20 && P.M == 10 && !force_generic && scan_wide) QP_LAUNCH(20, 10, false, true);
+#ifdef NPA_EXPERIMENTS
   else if (P.T == 20 && P.M == 10 && !force_generic) QP_LAUNCH(20, 10);
+#endif
   else QP_LAUNCH(0, 0);
 #undef QP_LAUNCH
   return hipGetLastError();

@@ -27,6 +27,11 @@
 #define QP_RETRY_MERIT 1e-9    // a cold solve that ends above this is repeated once from round 2's start (unit multipliers)
 #define QP_SIGMA_MU_MIN 1e-15  // floor of the centring target: a gap driven to 1e-20 leaves the Newton matrix too ill
                                //   conditioned for the residuals to follow (solves that ended at 1e-11: 8 -> 1 of 640)
+#define QP_SIGMA_MU_RES 0.01   // ... and never below this x the largest scaled residual of the iterate: complementarity may not run
+                               //   more than 100x ahead of feasibility.  The solves that "stalled" (mu at 1e-15, dual residual stuck at
+                               //   1e-10 .. 1e-12, best iterate after three non-improving iterations: 13 of 3 360 benchmark QPs, one of
+                               //   them 1.2e-4 from the oracle in the controls) end at <= 1e-13 with it (CPU replay of the kernel's
+                               //   method, profiles/r05_qp_stall_study.txt: +0.2 .. +1.0 iterations per solve, the maximum unchanged)
 // the cold starting point: u = 0, d mid-range, slacks >= 1, multipliers QP_START_MU / slack -- or, for the SECOND cold attempt
 // of a solve whose first one jammed (cold_alt), unit multipliers, round 2's start -- (a macro: used before the loop and, in the
 // instantiations with warm start, again at the loop top when a warm attempt is dropped)

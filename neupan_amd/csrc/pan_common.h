@@ -45,18 +45,8 @@ struct DevParams {
   // has a cheaper closed form: centre, half extents; geo_rect != 0 selects it
   int geo_rect;
   float rcx, rcy, rhx, rhy;
-  int qp_aset;                // the QP's warm solves try the active-set iteration first (nrmp_qp.hip; NPA_QP_ASET read by npa_create)
-  // wave priorities (s_setprio 0..3), NPA_PRIO="sel,qp0,qp1,qp2,it1,it2": selection waves run at `sel`; a QP wave starts at qp0 and
-  // moves to qp1 / qp2 once its solve has run it1 / it2 interior-point iterations (the launch lasts as long as its slowest
-  // scene: the stragglers should win the issue arbitration against younger waves of other batches)
-  int prio_sel, prio_qp0, prio_qp1, prio_qp2, prio_it1, prio_it2;
+  int qp_aset;                // (experiments build only: the QP's warm solves try the active-set iteration first, NPA_QP_ASET)
 };
-__device__ __forceinline__ void npa_setprio(int p) {      // (s_setprio takes an immediate)
-  if (p <= 0) __builtin_amdgcn_s_setprio(0);
-  else if (p == 1) __builtin_amdgcn_s_setprio(1);
-  else if (p == 2) __builtin_amdgcn_s_setprio(2);
-  else __builtin_amdgcn_s_setprio(3);
-}
 
 // ---- merged launches of a GROUP of forward calls (npa_forward_batch_group, c_api.hip) --------------------------------
 // The chains of a burst that share a stream, a batch size and a configuration run each stage as ONE launch: blockIdx.y

@@ -69,7 +69,6 @@ __device__ __forceinline__ void select_scene(
     int debug, unsigned* stats, const float* trig, unsigned* audit, unsigned audit_thresh, unsigned audit_seed, float margin_scale,
     const int b, const int t_first) {
   if (flags && __builtin_amdgcn_readfirstlane(__hip_atomic_load(flags + b * 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) return;
-  npa_setprio(P.prio_sel);
   const int lane = threadIdx.x;
   const unsigned todo = ((1u << (TT + 1)) - 1u) & ~((1u << t_first) - 1u);
   unsigned slow = 0;

@@ -502,7 +502,7 @@ class PAN(torch.nn.Module):
         B, T = self._B, self.T
         wsf = self._ws.view(torch.float32)
         off_u = (B * 3 * (T + 1) + 3) // 4 * 4                  # cur_u follows cur_s (pan_common.h: npa_scratch_layout)
-        us, ss, ps, qi = [], [], [], []
+        us, ss, ps, qi, ms, ls = [], [], [], [], [], []
         views = self._workspace_views() if not self.no_obs else None
         qoff = self._lib.npa_workspace_qp_info_offset(self._h, B)
         qview = self._ws[qoff:qoff + B * 16 * 8].view(torch.float64).reshape(B, 16)
@@ -512,7 +512,7 @@ class PAN(torch.nn.Module):
             ss.append(wsf[:B * 3 * (T + 1)].clone().reshape(B, 3, T + 1))
             qi.append(qview.clone())
             if views is not None:
-                ps.append(views["pts"].clone())
+                ps.append(views["pts"].clone()); ms.append(views["mu"].clone()); ls.append(views["lam"].clone())
         out = self.forward_end()
         out["trace_qp_info"] = torch.stack(qi, dim=1)    # (B, K, 16): solver diagnostics of every iteration's QP (include/neupan_amd.h)
         out["trace_u"] = torch.stack(us, dim=1)
@@ -520,6 +520,10 @@ class PAN(torch.nn.Module):
         # (B, K, T+1, M, 2): the points of the rows the selection emitted in every iteration (slice 0 is only redone in the
         # first iteration and keeps its rows afterwards)
         out["trace_pts"] = torch.stack(ps, dim=1) if ps else None
+        # (B, K, T+1, M, E) / (B, K, T+1, M, 2): the mu / lam rows of the same slices -- with trace_pts everything the QP of that
+        # iteration was built from (parity tooling: the oracle's solver on the kernel's rows)
+        out["trace_mu"] = torch.stack(ms, dim=1) if ms else None
+        out["trace_lam"] = torch.stack(ls, dim=1) if ls else None
         return out
 
     # ------------------------------------------------------------------ reference signature

@@ -85,10 +85,14 @@ STEP_ETA = 0.995        # fraction of the step to the boundary: max(STEP_ETA, 1 
 STEP_CAP = 1e-6
 START_MU = 3.0          # cold start: multipliers = START_MU / slack
 SIGMA_MU_MIN = 1e-15    # floor of the centring target sigma * mu
+SIGMA_MU_RES = 0.01     # ... nor below this x the largest scaled residual: complementarity may not run more than 100x ahead of
+                        #   feasibility.  Without it 0.2 - 0.5 % of the benchmark QPs drove mu to 1e-15 while the dual residual sat at
+                        #   1e-10 .. 1e-12 and ended there (three non-improving iterations: "stalled"); with it 1 of 3 360 ends above
+                        #   1e-13 (1.8e-13), for +0.2 .. +1.0 iterations per solve (profiles/r05_qp_stall_study.txt)
 RETRY_MERIT = 1e-9      # a cold solve that ends above this is repeated once with unit multipliers (round 2's start)
 
 
-def solve_condensed(pb: NrmpProblem, tol=1e-14, max_iter=40, trace=None, warm=None, _alt=False):
+def solve_condensed(pb: NrmpProblem, tol=1e-14, max_iter=40, trace=None, warm=None, _alt=False, sigma_mu_res=None):
     """warm = (x, lc, lf) of a previous, similar solve: the kernel's warm start across the PAN
     iterations of one forward call (multipliers and slacks floored at WARM_DELTA), with the kernel's drop rules: the
     attempt is abandoned for a cold start at iteration 0 / 6 when its merit is above WARM_DROP, and a warm-started
@@ -96,6 +100,7 @@ def solve_condensed(pb: NrmpProblem, tol=1e-14, max_iter=40, trace=None, warm=No
     iteration 0 / later, 4 not converged, 5 a cold solve that jammed and was repeated from unit multipliers (qp_info[15] of
     the kernel)."""
     H, g, F, f, C, c, Phi, cv = condense(pb)
+    smr = SIGMA_MU_RES if sigma_mu_res is None else sigma_mu_res      # (the gradient path passes 0: the kernel's BWD instantiations do)
     n = H.shape[0]; T = pb.T; nu = 2 * T
     ro = pb.ro_obs
     mc, mf = C.shape[0], F.shape[0]
@@ -131,14 +136,15 @@ def solve_condensed(pb: NrmpProblem, tol=1e-14, max_iter=40, trace=None, warm=No
         r2 = C @ x + wc - c
         r3 = F @ x - f + lf / ro - wf
         mu = (lc @ wc + lf @ wf) / max(m, 1)
-        merit = max(np.abs(r1).max() / scale_d, (np.abs(r2).max() if mc else 0.0) / scale_p,
-                    (np.abs(r3).max() if mf else 0.0) / scale_p, mu)
+        res = max(np.abs(r1).max() / scale_d, (np.abs(r2).max() if mc else 0.0) / scale_p,
+                  (np.abs(r3).max() if mf else 0.0) / scale_p)
+        merit = max(res, mu)
         if trace is not None:
             trace.append(dict(it=it, merit=merit, mu=mu, x=x.copy()))
         if not np.isfinite(merit):
             break
         if warm is not None and it in WARM_DROP and merit > WARM_DROP[it]:
-            out = solve_condensed(pb, tol=tol, max_iter=max_iter, trace=trace)
+            out = solve_condensed(pb, tol=tol, max_iter=max_iter, trace=trace, sigma_mu_res=sigma_mu_res)
             out[3]["warm_code"] = 2 if it == 0 else 3
             out[3]["iters_total"] = out[3]["iters_total"] + it
             return out
@@ -172,19 +178,19 @@ def solve_condensed(pb: NrmpProblem, tol=1e-14, max_iter=40, trace=None, warm=No
         dx, dwc, dlc, dwf, dlf = solve(lc * wc, lf * wf)
         a_aff = min(max_step(wc, dwc), max_step(lc, dlc), max_step(wf, dwf), max_step(lf, dlf))
         mu_aff = ((lc + a_aff * dlc) @ (wc + a_aff * dwc) + (lf + a_aff * dlf) @ (wf + a_aff * dwf)) / max(m, 1)
-        sigma_mu = max((mu_aff / mu) ** 3 * mu, SIGMA_MU_MIN)
+        sigma_mu = max((mu_aff / mu) ** 3 * mu, SIGMA_MU_MIN, smr * res)
         dx, dwc, dlc, dwf, dlf = solve(lc * wc + dwc * dlc - sigma_mu, lf * wf + dwf * dlf - sigma_mu)
         eta = min(max(STEP_ETA, 1.0 - mu), 1.0 - STEP_CAP)
         a = min(1.0, eta * min(max_step(wc, dwc), max_step(lc, dlc), max_step(wf, dwf), max_step(lf, dlf)))
         x = x + a * dx; wc = wc + a * dwc; lc = lc + a * dlc; wf = wf + a * dwf; lf = lf + a * dlf
         lam_out = (lc, lf)
     if warm is not None and not best[0] <= WARM_ACCEPT:
-        out = solve_condensed(pb, tol=tol, max_iter=max_iter, trace=trace)
+        out = solve_condensed(pb, tol=tol, max_iter=max_iter, trace=trace, sigma_mu_res=sigma_mu_res)
         out[3]["warm_code"] = 4
         out[3]["iters_total"] = out[3]["iters_total"] + it
         return out
     if warm is None and not _alt and START_MU is not None and not best[0] <= RETRY_MERIT:      # jammed: the other start, once
-        out = solve_condensed(pb, tol=tol, max_iter=max_iter, trace=trace, _alt=True)
+        out = solve_condensed(pb, tol=tol, max_iter=max_iter, trace=trace, _alt=True, sigma_mu_res=sigma_mu_res)
         out[3]["warm_code"] = 5
         out[3]["iters_total"] = out[3]["iters_total"] + it
         return out

@@ -51,7 +51,7 @@ def backward_ipm(pb: NrmpProblem, gs, gu, gd, tol=1e-12):
     d_max, d_min."""
     H, g, F, f, C, c, Phi, cv = condense(pb)
     T, nu = pb.T, 2 * pb.T
-    s, u, d, info = solve_condensed(pb, tol=tol)
+    s, u, d, info = solve_condensed(pb, tol=tol, sigma_mu_res=0.0)      # (the kernel's BWD instantiations: no residual floor)
     x, lc, lf = info["warm"]
     x = np.concatenate([u.T.reshape(-1), [] if pb.no_obs else d.reshape(-1)])
     ro = pb.ro_obs

@@ -10,6 +10,16 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "experiments: needs the experiments build of the library (NPA_EXPERIMENTS=1 python -m "
+                                       "neupan_amd.build --force): the kernels DESIGN.md section 7 keeps on record, not in the product")
+
+
+def experiments_built():
+    try:
+        from neupan_amd import _lib
+        return b"+experiments" in _lib.load().npa_version()
+    except Exception:
+        return False
 
 
 def pytest_collection_modifyitems(config, items):
@@ -20,6 +30,11 @@ def pytest_collection_modifyitems(config, items):
         has_gpu = torch.cuda.is_available()
     except Exception:  # pragma: no cover
         has_gpu = False
+    if any("experiments" in item.keywords for item in items) and not experiments_built():
+        skip_x = pytest.mark.skip(reason="the library is the product build (no experiments: NPA_EXPERIMENTS=1 python -m neupan_amd.build --force)")
+        for item in items:
+            if "experiments" in item.keywords:
+                item.add_marker(skip_x)
     if has_gpu:
         return
     skip = pytest.mark.skip(reason="no GPU visible")

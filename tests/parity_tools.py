@@ -253,7 +253,7 @@ RANK_TIE_TOL = 1e-4        # [m] how far beyond the oracle's own cut a point the
                            # the two fp32 encoders agree to 3e-5 in mu / 5e-5 in the distance (test_dune_stage_vs_reference_vectors)
 
 
-def _explain_step(orc, cfg, sc, nom_s, nom_u, hip_pts, u_or, dev, b, k, hip_u=None, hip_merit=None):
+def _explain_step(orc, cfg, sc, nom_s, nom_u, hip_pts, u_or, dev, b, k, hip_u=None, hip_merit=None, hip_rows=None):
     """Why does ONE oracle iteration from the HIP path's own iterate differ from the HIP path's next iterate by more than the
     tolerance?  Two measurable causes (reference semantics: dune.py:100-104 keeps the first M columns of an argsort):
       * selection: the HIP path's M points of a slice are not the oracle's first M.  For every such point the oracle's OWN
@@ -267,9 +267,14 @@ def _explain_step(orc, cfg, sc, nom_s, nom_u, hip_pts, u_or, dev, b, k, hip_u=No
         dynamics, d optimal for them) has the oracle's optimal objective to what fp32 outputs resolve (1e-7 relative, bounds held
         to 1e-6), AND the QP's curvature along the direction between the two points is below 1e-3 of its mean curvature: two
         solvers at their 1e-14 floor on a QP that is flat along that direction (steering of the car where it hardly moves).
-      * stalled: the kernel's own solve of that iteration ended above 1e-13 (trace_qp_info: its best iterate after three
-        non-improving iterations on a degenerate QP; counted, and capped by the tests).
-    Anything else is UNEXPLAINED and fails the tests."""
+      * encoder rounding, solver exonerated: same selection; the rows the kernel built (mu, lam of the selected points) agree
+        with the oracle's to the tolerance the DUNE stage is held to against the reference's own vectors (mu 3e-5, lam 8e-5:
+        two fp32 summation orders of the same network), AND the ORACLE's solver on the KERNEL's rows lands on the kernel's
+        controls (<= 1e-5): the whole deviation is what that rounding does to this QP's optimum, none of it is the solver's.
+    Anything else is UNEXPLAINED and fails the tests.  `stalled` is NOT an explanation: it flags a step whose kernel-side solve
+    ended above 1e-13 (trace_qp_info: its best iterate after three non-improving iterations); such steps are counted on their
+    own (one_step_report: "stalled") and the tests assert that there are none -- a solver that stops short is a defect, and
+    round 5 fixed the one that produced them (QP_SIGMA_MU_RES, csrc/nrmp_qp_device.h)."""
     from oracle import pan_oracle as po
     T, M = cfg.T, cfg.nrmp_max_num
     out = {"scene": int(b), "iteration": int(k) + 1, "ctrl_l2": float(dev), "slices_with_other_set": 0, "rank_gap": 0.0,
@@ -345,9 +350,31 @@ def _explain_step(orc, cfg, sc, nom_s, nom_u, hip_pts, u_or, dev, b, k, hip_u=No
     # the kernel's own solve of that iteration ended short of its 1e-14 target (three non-improving iterations on a degenerate
     # QP: the best iterate stands, status 0 up to 1e-9): reported as what it is
     out["hip_merit"] = None if hip_merit is None else float(hip_merit)
-    stalled = hip_merit is not None and hip_merit > 1e-13 and out["slices_with_other_set"] == 0
+    out["stalled"] = bool(hip_merit is not None and hip_merit > 1e-13)
+    # the oracle's solver on the kernel's rows: separates what the two fp32 encoders contribute from what the two solvers do
+    rows_ok = False
+    if hip_rows is not None and hip_pts is not None and hip_u is not None and out["slices_with_other_set"] == 0 and sc["points"] is not None:
+        hmu, hlam = hip_rows                                     # (T+1, M, E), (T+1, M, 2)
+        mu_l = [np.ascontiguousarray(hmu[t].T) for t in range(T + 1)]
+        lam_l = [np.ascontiguousarray(hlam[t].T) for t in range(T + 1)]
+        pt_l = [np.ascontiguousarray(hip_pts[t].T) for t in range(T + 1)]
+        o3 = _make_oracle(cfg, _WORK["wd"])
+        _, u3, _ = o3.nrmp(nom_s, nom_u, sc["ref_s"], sc["ref_us"], mu_l, lam_l, pt_l)
+        out["oracle_solver_on_hip_rows_vs_hip"] = float(_l2(u3.astype(np.float32), np.asarray(hip_u, dtype=np.float32)))
+        # how far the kernel's rows are from the oracle's own, matched point by point (slice 0 never reaches the QP)
+        omu, olam, opt = orc.last_lists
+        dmu = dlam = 0.0
+        for t in range(1, T + 1):
+            m = min(M, omu[t].shape[1])
+            for j in range(m):
+                d2 = (opt[t][0, :m] - hip_pts[t, j, 0]) ** 2 + (opt[t][1, :m] - hip_pts[t, j, 1]) ** 2
+                i = int(np.argmin(d2))
+                dmu = max(dmu, float(np.abs(omu[t][:, i] - hmu[t, j]).max()))
+                dlam = max(dlam, float(np.abs(olam[t][:, i] - hlam[t, j]).max()))
+        out["rows_mu_diff"], out["rows_lam_diff"] = dmu, dlam
+        rows_ok = out["oracle_solver_on_hip_rows_vs_hip"] <= 1e-5 and dmu <= 3e-5 and dlam <= 8e-5
     out["explained"] = "rank-M tie" if tie else ("one-step ensemble spread" if flat else ("same optimum of a flat QP" if same_opt else
-                       ("kernel's solve stalled above 1e-13" if stalled else None)))
+                       ("encoder rounding, solver exonerated" if rows_ok else None)))
     return out
 
 
@@ -387,11 +414,13 @@ def one_step_job(job):
         dev = float(_l2(u, job[4]))
         if dev > (job[6] if len(job) > 6 else ONE_STEP_TOL):
             orc.last_solution = (np.asarray(s, dtype=np.float64), np.asarray(u, dtype=np.float64), None if d is None else np.asarray(d, dtype=np.float64))
-            why = _explain_step(orc, cfg, sc, nom_s, nom_u, job[5], u, dev, b, k, hip_u=job[4], hip_merit=job[7] if len(job) > 7 else None)
+            why = _explain_step(orc, cfg, sc, nom_s, nom_u, job[5], u, dev, b, k, hip_u=job[4], hip_merit=job[7] if len(job) > 7 else None,
+                                hip_rows=job[8] if len(job) > 8 else None)
     return b, k, u, why
 
 
-def one_step_consistency(workload, scenes, trace_s, trace_u, cores, explain=False, trace_pts=None, tol=None, trace_merit=None):
+def one_step_consistency(workload, scenes, trace_s, trace_u, cores, explain=False, trace_pts=None, tol=None, trace_merit=None,
+                         trace_rows=None):
     """Verdict D: does the HIP path FOLLOW the reference algorithm step by step, also on scenes where the PAN fixed-point
     iteration is chaotic and end-to-end comparisons mean nothing?  For every scene and every PAN iteration k the oracle
     runs ONE iteration from the HIP path's own iterate k-1 (the scene's nominal for k = 0) and its controls are compared
@@ -416,7 +445,9 @@ def one_step_consistency(workload, scenes, trace_s, trace_u, cores, explain=Fals
             if explain:
                 jb = jb + (np.asarray(trace_u[i, k], dtype=np.float32),
                            None if trace_pts is None else np.asarray(trace_pts[i, k], dtype=np.float32),
-                           ONE_STEP_TOL if tol is None else float(tol), None if trace_merit is None else float(trace_merit[i, k]))
+                           ONE_STEP_TOL if tol is None else float(tol), None if trace_merit is None else float(trace_merit[i, k]),
+                           None if trace_rows is None else (np.asarray(trace_rows[0][i, k], dtype=np.float32),
+                                                            np.asarray(trace_rows[1][i, k], dtype=np.float32)))
             jobs.append(jb)
     for kk in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
         os.environ[kk] = "1"
@@ -453,7 +484,10 @@ def one_step_report(dev, tol=ONE_STEP_TOL, why=None):
         rep["unexplained"] = int(sum(w["explained"] is None for w in why))
         rep["explained_by"] = {c: int(sum(w["explained"] == c for w in why))
                                for c in ("rank-M tie", "one-step ensemble spread", "same optimum of a flat QP",
-                                         "kernel's solve stalled above 1e-13")}
+                                         "encoder rounding, solver exonerated")}
+        # steps above the tolerance whose kernel-side solve ended above 1e-13: never an explanation, asserted zero by the tests
+        rep["stalled"] = int(sum(bool(w.get("stalled")) for w in why))
+        rep["largest_explained"] = float(max([w["ctrl_l2"] for w in why if w["explained"] is not None], default=0.0))
         assert len(why) == int((flat > tol).sum())
     return rep
 

@@ -140,31 +140,24 @@ def test_hot_kernels_have_no_spills_and_no_scratch():
     if not kr.tools_available():
         pytest.skip("ROCm LLVM tools not installed")
     res = kr.kernel_resources()
-    sel = {n: r for n, r in res.items() if "select_geo_kernel" in n}
-    assert len(sel) == 8                                        # E = 3 .. 8, plus the bf16 tier of the rows at E = 4 and 8
+    sel = {n: r for n, r in res.items() if "select_geo_kernel" in n or "select_geo_group_kernel" in n}
+    # E = 3 .. 8, plus the bf16 tier of the rows at E = 4 and 8; the merged-launch form (blockIdx.y = the call) for E = 4 and 8, both tiers
+    assert len(sel) == 8 + 4, sorted(sel)
     for n, r in sel.items():
         assert r["vgpr_spill"] == 0 and r["scratch"] == 0, (n, r)
         wide = "ILi7E" in n or "ILi8E" in n                     # (E > 6 is built for three waves per SIMD)
         assert r["vgpr"] + r["agpr"] <= (168 if wide else 128), (n, r)      # four waves per SIMD
-    # (the active-set instantiation -- last template argument true, launched only under NPA_QP_ASET=1 -- spills and is exempt:
-    # it is an experiment on record, not the shipped path)
-    qp = {n: r for n, r in res.items() if "nrmp_qp_kernel" in n and "Lb1EEv" not in n}
-    assert len(qp) >= 4
-    # the opt-in scene kernel (csrc/pan_scene.hip): one wave per SIMD, and NOTHING spilled -- its 256-register build spills
-    # 54 registers and faults on the GPU; a change that brings the spill back must not ship
-    sc = [r for n, r in res.items() if n.startswith("_Z16pan_scene_kernel")]
-    assert len(sc) >= 3
-    for r in sc:
-        assert r["vgpr_spill"] == 0 and r["scratch"] == 0 and r["vgpr"] + r["agpr"] <= 512, r
-    # the opt-in scene-wide selection (csrc/select_scene.h): three waves per SIMD, nothing spilled
-    ss = [r for n, r in res.items() if n.startswith("_Z19select_scene_kernel")]
-    assert len(ss) >= 3
-    for r in ss:
-        assert r["vgpr_spill"] == 0 and r["scratch"] == 0 and r["vgpr"] + r["agpr"] <= 168, r
+    # EVERY QP instantiation of the product build, no exemptions: the experiments that spilled (the active-set launch, the
+    # 256-register scene kernel) are not in it (NPA_EXPERIMENTS build only)
+    qp = {n: r for n, r in res.items() if "nrmp_qp_kernel" in n or "nrmp_qp_group_kernel" in n}
+    assert len(qp) >= 6, sorted(qp)
     for n, r in qp.items():
         assert r["vgpr_spill"] == 0 and r["scratch"] == 0, (n, r)
         assert r["vgpr"] + r["agpr"] <= 256, (n, r)             # two waves per SIMD
-
+    from conftest import experiments_built
+    if not experiments_built():
+        assert not any("pan_scene_kernel" in n or "select_scene_kernel" in n or "aset" in n for n in res), "experiment kernels in the product build"
+        assert os.path.getsize(kr.LIB) < 2 * 1024 * 1024, os.path.getsize(kr.LIB)
 
 def test_build_refuses_an_unvalidated_compiler(monkeypatch):
     """neupan_amd.build fails (not warns) on a hipcc other than the validated one unless NPA_ALLOW_UNVALIDATED=1."""

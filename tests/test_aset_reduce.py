@@ -8,6 +8,8 @@ import sys
 import numpy as np
 import pytest
 
+pytestmark = pytest.mark.experiments
+
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
 
 

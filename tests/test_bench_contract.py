@@ -68,7 +68,7 @@ def test_driver_flag_line_is_the_same_contract():
 
 
 def test_tracked_pmc_file_matches_the_built_kernels():
-    """bench.py prices the roofline with a kernel's record of profiles/r04_pmc.json only while the code the tree builds IS
+    """bench.py prices the roofline with a kernel's record of profiles/r05_pmc.json only while the code the tree builds IS
     the code that was measured: by the fingerprint of the kernel's machine code (bench.kernel_isa_hash: function bytes +
     kernel descriptor of the measured instantiation, read from the built library), or -- where the ROCm LLVM tools are not
     installed -- by the hash of the source files the kernel is built from.  An edit of the dominant kernel that changes its
@@ -76,15 +76,19 @@ def test_tracked_pmc_file_matches_the_built_kernels():
     import bench
     from neupan_amd import build
     build.build(force=False, verbose=False)
-    pj = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc.json")))
+    pj = bench.load_pmc(bench.WORKLOAD)
+    assert pj["_file"] == "profiles/r05_pmc.json"              # the newest tracked record is the one the tree is priced with
+    for name in ("nrmp_qp_kernel", "nrmp_qp_group_kernel", "select_geo_kernel", "select_geo_group_kernel"):
+        k = pj["kernels"][name]
+        isa = bench.kernel_isa_hash(k["kernel"])
+        if isa is not None and k.get("isa_hash"):
+            assert k["isa_hash"] == isa, name
+        else:
+            assert k["source_hash"] == bench.kernel_hash(name), name
+        assert bench.record_is_current(name, k), name
+    assert pj["kernels"]["nrmp_qp_group_kernel"]["scenes_per_launch"] == 1280 and pj["kernels"]["nrmp_qp_kernel"]["scenes_per_launch"] == 256
     k = pj["kernels"]["nrmp_qp_kernel"]
     isa = bench.kernel_isa_hash(k["kernel"])
-    if isa is not None and k.get("isa_hash"):
-        assert k["isa_hash"] == isa
-        assert pj["kernels"]["select_geo_kernel"]["isa_hash"] == bench.kernel_isa_hash(pj["kernels"]["select_geo_kernel"]["kernel"])
-    else:
-        assert k["source_hash"] == bench.kernel_hash("nrmp_qp_kernel")
-    assert bench.record_is_current("nrmp_qp_kernel", k)
     assert k["fp64_flops_per_launch"] > 0 and k["hbm_bytes_per_launch"] > 0 and 0 < k["valu_issue_frac"] < 1
     # the lookup itself: a template instantiation, a plain kernel, an unknown name
     if isa is not None:

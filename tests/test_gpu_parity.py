@@ -165,30 +165,34 @@ def _ensemble_verdict(cfgname, scenes, step_tol=None):
     # convergence, 4 both cold attempts ended above 1e-9), final merit at the solver's own floor
     qi = out["trace_qp_info"].cpu().numpy()
     assert (qi[:, :, 3] == 0).all() and qi[:, :, 1].max() <= 1e-9, (np.argwhere(qi[:, :, 3] != 0)[:5], qi[:, :, 1].max())
+    # (round 5: the centring floor tied to the residual, QP_SIGMA_MU_RES: at most a stray solve per thousand ends above 1e-13)
+    assert (qi[:, :, 1] > 1e-13).mean() <= 2e-3, ((qi[:, :, 1] > 1e-13).sum(), qi[:, :, 1].max())
     base, members, _, _ = run_ensemble(cfgname, range(scenes), os.cpu_count() or 1, sweep=False)
     rep, hip, sp = judge(out["trace_u"].cpu().numpy(), base, members)
     from parity_tools import one_step_consistency, one_step_report
     dev, why = one_step_consistency(cfgname, range(scenes), out["trace_s"].cpu().numpy(), out["trace_u"].cpu().numpy(),
                                     os.cpu_count() or 1, explain=True, trace_pts=out["trace_pts"].cpu().numpy(), tol=step_tol,
-                                    trace_merit=qi[:, :, 1])
+                                    trace_merit=qi[:, :, 1], trace_rows=(out["trace_mu"].cpu().numpy(), out["trace_lam"].cpu().numpy()))
     rep["one_step"] = one_step_report(dev, tol=1e-4 if step_tol is None else step_tol, why=why)
     rep["_hip"], rep["_spread"] = hip, sp
     print({k: v for k, v in rep.items() if k not in ("worst_scenes", "_hip", "_spread")})
     return rep
 
 
-def _assert_follows_the_reference_step_by_step(rep, tol_frac=0.98, cap=None):
+def _assert_follows_the_reference_step_by_step(rep, tol_frac=0.98, cap=1e-3):
     """Verdict D (tests/parity_tools.one_step_consistency): one oracle iteration from the HIP path's own iterate lands on
     the HIP path's next iterate -- on every scene, chaotic or not.  A step above the tolerance must be EXPLAINED, instance
     by instance (parity_tools._explain_step): a tie at rank M / M+1 of a slice that the two fp32 encoders order differently
     (the QP changes discretely; the oracle's own distances put the swapped point within 1e-4 m of its
     cut), or a step on which the oracle's own one-step answer moves by a comparable amount when its inputs move by one
-    float32 ulp.  No unexplained step, at most 2 % explained ones, and (cap) none larger than the cap."""
+    float32 ulp.  No unexplained step, no step behind a stalled solve, at most 2 % explained ones, none larger than the cap."""
     d = rep["one_step"]
     assert d["median"] <= 2e-6 and d["frac_le_tol"] >= tol_frac, d
     assert d["unexplained"] == 0, [w for w in d["above_tol"] if w["explained"] is None]
-    if cap is not None:
-        assert d["max"] <= cap, d["worst"]
+    # no step may rest on a kernel-side solve that stopped short of 1e-13 (a solver defect is not an explanation), and an
+    # explained step is still bounded: 1e-3 unless the caller says otherwise
+    assert d["stalled"] == 0, [w for w in d["above_tol"] if w.get("stalled")]
+    assert d["max"] <= cap, d["worst"]
 
 
 def test_config2_parity_distribution():
@@ -639,6 +643,7 @@ def test_qp_iteration_budget_and_convergence(cfgname, scenes, mean_max, cold_max
 
 @pytest.mark.parametrize("cfgname,B,over", [("diff_1k_T10_K10", 96, {}), ("dyna_4k_T10_K10", 16, {}), ("poly8_5k_T10_K10", 8, {}),
                                             ("diff_1k_T10_K10", 32, dict(dune_max_num=100)), ("acker_2k_T20_K15", 16, {})])
+@pytest.mark.experiments
 def test_both_forms_of_the_geometric_selection_agree(cfgname, B, over):
     """select_geo_kernel (the default: streamed weights, one threshold, XCD-aware block map) against the first form
     (select_kernel<E, true>, NPA_SELECT_V1=1): the same contract, so bitwise the same rows -- on random clouds, moving
@@ -1032,6 +1037,7 @@ def test_merged_group_launches_equal_call_by_call(cfgname, B, nfl, over):
 
 @pytest.mark.parametrize("cfgname,B,over", [("diff_1k_T10_K10", 256, {}), ("diff_1k_T10_K10", 80, {"iter_threshold": 0.1}),
                                             ("dyna_4k_T10_K10", 64, {}), ("acker_2k_T20_K15", 64, {}), ("poly8_5k_T10_K10", 64, {})])
+@pytest.mark.experiments
 def test_scene_kernel_agrees_with_the_two_launch_path(cfgname, B, over):
     """NPA_SCENE_KERNEL=1 (csrc/pan_scene.hip, opt-in): the whole K-iteration loop as ONE launch, a wave keeping its scene from
     the first selection to the last stop test, against the default 2 K launches.  The two run the same statements (textual
@@ -1094,6 +1100,7 @@ def test_scene_kernel_agrees_with_the_two_launch_path(cfgname, B, over):
     assert one.audit()["violations"] == 0
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("cfgname,B", [("diff_1k_T10_K10", 96), ("dyna_4k_T10_K10", 24), ("acker_2k_T20_K15", 24), ("poly8_5k_T10_K10", 12)])
 def test_scene_wide_selection_equals_the_per_slice_selection(cfgname, B):
     """NPA_SELECT_SCENE=1 (csrc/select_scene.h, opt-in): the selection stage with ONE wave per scene -- the keys of all slices per

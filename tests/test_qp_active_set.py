@@ -6,7 +6,7 @@ import pytest
 from helpers import CONFIGS
 from neupan_amd.scenes import make_batch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.experiments, pytest.mark.gpu]
 
 
 @pytest.mark.parametrize("cfgname,scenes", [("diff_1k_T10_K10", 128), ("dyna_4k_T10_K10", 32)])

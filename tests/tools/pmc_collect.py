@@ -1,5 +1,5 @@
-"""PMC evidence for bench.py's roofline object, per kernel, tracked: writes gpurun_out/r04/pmc_<workload>.json (copy it to
-profiles/r04_pmc.json).
+"""PMC evidence for bench.py's roofline object, per kernel, tracked: writes gpurun_out/r05/pmc_<workload>.json (copy it to
+profiles/r05_pmc.json).
 
     python tests/tools/pmc_collect.py [workload]            # on the GPU box
 
@@ -28,7 +28,8 @@ GROUPS = [
     ["FETCH_SIZE"],
     ["WRITE_SIZE"],
 ]
-KERNELS = ("dune_kernel", "select_geo_kernel", "select_kernel", "nrmp_qp_kernel", "stage_kernel")
+KERNELS = ("dune_kernel", "select_geo_kernel", "select_geo_group_kernel", "select_kernel", "nrmp_qp_kernel", "nrmp_qp_group_kernel",
+           "stage_kernel", "stage_group_kernel")
 
 
 def short(name):
@@ -40,6 +41,9 @@ def short(name):
 
 
 BENCH_ARGS = ["--steps", "4", "--warmup", "1", "--no-cpu", "--no-latency", "--no-extras", "--inflight", "1"]
+# the merged-launch kernels (round 5): ONE chain of five steps, i.e. every stage one launch over 5 x 256 scenes, alone on the chip
+MERGED_ARGS = ["--steps", "5", "--warmup", "5", "--no-cpu", "--no-latency", "--no-extras", "--inflight", "5", "--chains", "1"]
+MERGED_SCENES = 5 * 256
 # (no create-time self-test in the profiled process: its 2-scene launches of the same kernels would be averaged in with the
 # 256-scene ones -- round 3's record has them: 9 of 79 QP launches, the per-launch averages of that file are ~10 % low)
 BASE_ENV = {"TMPDIR": "/tmp", "NPA_SKIP_SELFTEST": "1"}
@@ -54,11 +58,11 @@ def bench_iterations(workload, extra_env=None):
     return float(line["roofline"]["ipm_iterations_per_launch"])
 
 
-def run_pass(counters, workload, extra_env=None):
+def run_pass(counters, workload, extra_env=None, bench_args=None):
     d = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
     env = dict(os.environ, **BASE_ENV, **(extra_env or {}))
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "-o", "p", "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), *BENCH_ARGS, "--workload", workload]
+           sys.executable, os.path.join(ROOT, "bench.py"), *(bench_args or BENCH_ARGS), "--workload", workload]
     r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     agg, n = collections.defaultdict(lambda: collections.defaultdict(float)), collections.Counter()
     dur, nd = collections.defaultdict(float), collections.Counter()
@@ -102,25 +106,32 @@ def main():
     kern = collections.defaultdict(dict)
     durs = collections.defaultdict(list)
     names, log = {}, []
-    for g in GROUPS:
-        vals, dur, full, (rc, tail) = run_pass(g, workload)
-        log.append({"counters": g, "rc": rc, "kernels_seen": sorted(vals)})
-        if rc != 0 or not vals:          # an unknown counter kills the pass: retry one by one
-            for c in g:
-                v1, d1, f1, (rc1, _) = run_pass([c], workload)
-                log.append({"counters": [c], "rc": rc1, "kernels_seen": sorted(v1)})
-                for k in v1:
-                    kern[k].update(v1[k]); durs[k].append(d1.get(k, 0.0)); names.update(f1)
-            continue
-        names.update(full)
-        for k in vals:
-            kern[k].update(vals[k]); durs[k].append(dur.get(k, 0.0))
+    for args_ in (BENCH_ARGS, MERGED_ARGS):
+        merged = args_ is MERGED_ARGS
+        for g in GROUPS:
+            vals, dur, full, (rc, tail) = run_pass(g, workload, bench_args=args_)
+            # (a merged run's other kernels -- the priming forward calls of PAN.make_step -- are single-call launches: dropped)
+            vals = {k: v for k, v in vals.items() if ("group" in k) == merged}
+            log.append({"counters": g, "rc": rc, "merged": merged, "kernels_seen": sorted(vals)})
+            if rc != 0 or not vals:          # an unknown counter kills the pass: retry one by one
+                for c in g:
+                    v1, d1, f1, (rc1, _) = run_pass([c], workload, bench_args=args_)
+                    v1 = {k: v for k, v in v1.items() if ("group" in k) == merged}
+                    log.append({"counters": [c], "rc": rc1, "merged": merged, "kernels_seen": sorted(v1)})
+                    for k in v1:
+                        kern[k].update(v1[k]); durs[k].append(d1.get(k, 0.0)); names.update(f1)
+                continue
+            names.update(full)
+            for k in vals:
+                kern[k].update(vals[k]); durs[k].append(dur.get(k, 0.0))
     res = {"source_hash": source_hash(), "workload": workload, "scenes_per_launch": BATCH,
            "command": "rocprofv3 --kernel-trace --pmc <group> -- python bench.py " + " ".join(BENCH_ARGS),
+           "command_merged": "rocprofv3 --kernel-trace --pmc <group> -- python bench.py " + " ".join(MERGED_ARGS),
            "passes": log, "kernels": {}}
     for k, c in kern.items():
         ms = sum(durs[k]) / max(len(durs[k]), 1)
         e = {"kernel": names.get(k, k), "avg_ms_alone": ms, "counters": c, "source_hash": kernel_hash(k),
+             "scenes_per_launch": MERGED_SCENES if "group" in k else BATCH,
              "isa_hash": kernel_isa_hash(names.get(k, k))}          # (machine code of the instantiation that was measured)
         if c.get("SQ_ACTIVE_INST_LDS"):
             e["lds_bank_conflict_frac"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_ACTIVE_INST_LDS"]
@@ -157,8 +168,8 @@ def main():
                                          "same command; per_iteration = slope, per_solve = intercept / scenes"}
     except Exception as e:          # (the record stays usable without the fit: bench.py then scales the launch average)
         res["qp_flops_model_error"] = repr(e)
-    os.makedirs(os.path.join(ROOT, "gpurun_out", "r04"), exist_ok=True)
-    json.dump(res, open(os.path.join(ROOT, "gpurun_out", "r04", f"pmc_{workload}.json"), "w"), indent=1)
+    os.makedirs(os.path.join(ROOT, "gpurun_out", "r05"), exist_ok=True)
+    json.dump(res, open(os.path.join(ROOT, "gpurun_out", "r05", f"pmc_{workload}.json"), "w"), indent=1)
     print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "counters"} for k, v in res["kernels"].items()}, indent=1))
 
 
