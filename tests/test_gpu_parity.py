@@ -165,8 +165,9 @@ def _ensemble_verdict(cfgname, scenes, step_tol=None):
     # convergence, 4 both cold attempts ended above 1e-9), final merit at the solver's own floor
     qi = out["trace_qp_info"].cpu().numpy()
     assert (qi[:, :, 3] == 0).all() and qi[:, :, 1].max() <= 1e-9, (np.argwhere(qi[:, :, 3] != 0)[:5], qi[:, :, 1].max())
-    # (round 5: the centring floor tied to the residual, QP_SIGMA_MU_RES: at most a stray solve per thousand ends above 1e-13)
-    assert (qi[:, :, 1] > 1e-13).mean() <= 2e-3, ((qi[:, :, 1] > 1e-13).sum(), qi[:, :, 1].max())
+    # (round 5: the centring floor tied to the residual, QP_SIGMA_MU_RES -- round 4's kernel left 0.2 - 0.5 % of the solves at
+    # 1e-10 .. 1e-12: now at most a stray solve per hundred ends above 1e-13, none above 1e-12)
+    assert (qi[:, :, 1] > 1e-13).mean() <= 1e-2 and qi[:, :, 1].max() <= 1e-12, ((qi[:, :, 1] > 1e-13).sum(), qi[:, :, 1].max())
     base, members, _, _ = run_ensemble(cfgname, range(scenes), os.cpu_count() or 1, sweep=False)
     rep, hip, sp = judge(out["trace_u"].cpu().numpy(), base, members)
     from parity_tools import one_step_consistency, one_step_report
