@@ -547,7 +547,8 @@ def compact(line, full_path):
             u = x["uniform_cloud"]
             e["uniform_cloud"] = {"plans_per_s": u["plans_per_s"], "parity": _verdicts(u.get("parity"))}
         if "other_configs" in x:
-            e["other_configs"] = {k: {"plans_per_s": v["plans_per_s"], "parity": _verdicts(v.get("parity"))}
+            e["other_configs"] = {k: dict({"plans_per_s": v["plans_per_s"], "parity": _verdicts(v.get("parity"))},
+                                          **({"same_controls_as_exact": v["controls_equal_exact_path"]} if "controls_equal_exact_path" in v else {}))
                                   for k, v in x["other_configs"].items() if isinstance(v, dict)}
         if "launch_shapes" in x:
             e["launch_shapes"] = {k: v["plans_per_s"] for k, v in x["launch_shapes"].items() if isinstance(v, dict)}
@@ -927,19 +928,31 @@ def main():
         ex["uniform_cloud"] = res
         l2.close()
         others = {}
+        exact_u = {}
         for tag, wl, b_, nf, env in (("acker_2k_T20_K15", "acker_2k_T20_K15", B, nfx, None),
                                      ("dyna_4k_T10_K10_batch1024", "dyna_4k_T10_K10", 1024, 4, None),
                                      ("poly8_5k_T10_K10_exact_fp32_rows", "poly8_5k_T10_K10", B, nfx, None),
+                                     ("poly8_5k_T10_K10_bf16_keys", "poly8_5k_T10_K10", B, nfx, {"NPA_KEYS_PRECISION": "bf16"}),
                                      ("poly8_5k_T10_K10_bf16_rows", "poly8_5k_T10_K10", B, nfx, {"NPA_ROWS_PRECISION": "bf16"})):
-            # (K = 15 / T = 20 and 5000-point chains are 20 - 30 ms long: enough steps for several rounds of the chains in flight)
-            res, l2 = short_run(wl, b_, nf, dev, 24 if b_ > B else 100, 8 if b_ > B else 20, env=env, issue_threads=args.issue_threads)
+            # (K = 15 / T = 20 and 5000-point chains are 20 - 30 ms long: enough steps for several rounds of the chains in flight;
+            # these heavier workloads fill the chip with one launch chain per step: merged chains cost them 2 - 6 %, measured)
+            res, l2 = short_run(wl, b_, nf, dev, 24 if b_ > B else 100, 8 if b_ > B else 20, env=env, issue_threads=args.issue_threads,
+                                chains=0)
             if env:
                 res["env"] = env
+            lossy = bool(env) and "NPA_ROWS_PRECISION" in env
+            l2.pans[0].reset_stop_state()
+            u_ = l2.pans[0].forward_batch(*l2.args[0])["opt_u"].cpu().numpy()
+            if not env:
+                exact_u[wl] = u_
+            elif wl in exact_u:
+                # the bf16 KEY tier nominates with the bf16-MFMA encoder and emits exact rows: bitwise the exact path's controls
+                res["controls_equal_exact_path"] = bool(np.array_equal(u_, exact_u[wl]))
             if with_cpu:
-                # (the bf16 tier is judged like the others -- it fails A / C / D by design, that is what its entry shows -- without
-                # the per-step explanations: a different selection through rounded distances needs none)
-                res["parity"] = slim(parity_leg(l2, 16, cores, n_ulp=4, n_perm=2, explain=not env)[0])
-                if env:
+                # (the bf16 ROWS tier is judged like the others -- it fails A / C / D by design, that is what its entry shows --
+                # without the per-step explanations: a different selection through rounded distances needs none)
+                res["parity"] = slim(parity_leg(l2, 16, cores, n_ulp=4, n_perm=2, explain=not lossy)[0])
+                if lossy:
                     res["parity"]["note"] = ("LABELLED reduced-precision tier: not the reference's arithmetic; the verdicts are "
                                              "reported, not expected to hold")
             others[tag] = res
@@ -947,8 +960,10 @@ def main():
         ex["other_configs"] = dict(others, note="BASELINE configs[2] (car, reverse gear on half the scenes), configs[3]'s per-GPU shape "
                                                 "(8192 scenes / 8 GPUs = 1024 per step, 4 steps in flight), configs[4] (8-edge hull; the "
                                                 "reference ships no E = 8 checkpoint: ours, trained with its recipe on closed-form labels) in "
-                                                "exact fp32 and in the LABELLED bf16 tier of the rows (v_mfma_f32_32x32x16_bf16; its parity "
-                                                "entry shows what that costs); parity = ensemble verdicts on the first 16 scenes (6 members)")
+                                                "exact fp32, with the bf16 tier of the KEYS (NPA_KEYS_PRECISION=bf16: v_mfma_f32_32x32x16_bf16 "
+                                                "filters the overflowing candidate lists, the rows stay exact: controls bitwise the exact path's) "
+                                                "and in the LABELLED bf16 tier of the ROWS (its parity entry shows what that costs); parity = "
+                                                "ensemble verdicts on the first 16 scenes (6 members)")
         # the same 20 batches in flight under other schedules: one stream and one launch chain per step (round 4's default),
         # and other numbers of merged chains.  NOT other workloads: every step is 256 scenes with its own planner state.
         shapes = {}

@@ -99,7 +99,10 @@ int npa_key_mode(const npa_handle *h, int *key_terms, float *measured_error, flo
  *       the space between them (node maximum + neighbour difference), largest over the distance bands; <= 1 when the
  *       grids resolve f, and a checkpoint above 1.25 keeps network keys (a ridge narrower than a grid cell),
  *   [4] steepest neighbour difference per metre on the finest grid (an estimate of the Lipschitz constant of f next to
- *       the robot), [5] g_far: points at or beyond this geometric distance are always candidates.
+ *       the robot), [5] g_far: points at or beyond this geometric distance are always candidates,
+ *   [6], [7] (handles created with NPA_KEYS_PRECISION=bf16, else 0): largest measured |bf16-encoder distance - exact distance|
+ *       and the largest margin built from it over the bands below 8 m (the bf16 KEY tier: a slice whose candidate list
+ *       overflows is filtered with the bf16-MFMA encoder, the survivors re-encoded exactly -- rows bitwise the default path's).
  * The margin is MEASURED, not proven (LayerNorm leaves no usable analytic Lipschitz bound); npa_audit_read is the
  * run-time check. */
 int npa_geo_report(const npa_handle *h, float *out, int n);

@@ -61,6 +61,8 @@ extern "C" hipError_t npa_launch_qp(const DevParams& P, int batch, int scene0, c
                                     hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop, int aset_launch);
 extern "C" size_t npa_qp_shmem_bytes(int T, int M);
 extern "C" int npa_select_geo_group_supported(int E);
+extern "C" hipError_t npa_launch_k16_calib(const DevParams& P, const float* wpack, int nside, float half, float inner, unsigned* out,
+                                           int n_cu, hipStream_t stream);
 extern "C" hipError_t npa_launch_select_geo_group(const DevParams& P, const SelGeoGroup& G, int n, int batch, int t0, int n_stride_max,
                                                   int debug, unsigned audit_thresh, float margin_scale, int rows_bf16,
                                                   hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);
@@ -131,6 +133,11 @@ struct npa_handle {
   unsigned* audit_dev = nullptr;
   unsigned* audit_host = nullptr;        // pinned, host-mapped mirror of the violation count (words 6, 7 of audit_dev point at it)
   bool rows_bf16 = false;                // NPA_ROWS_PRECISION=bf16: the labelled reduced-precision tier of the rows (geometric keys, E = 4 / 8)
+  // NPA_KEYS_PRECISION=bf16: the bf16 tier of the KEYS -- a slice whose candidate list overflows runs the list through the
+  // bf16-MFMA encoder, keeps what lies within 2 x the measured |bf16 - exact| of the M-th smallest, re-encodes the survivors
+  // exactly: the rows are bitwise those of the default path (BASELINE configs[4] "bf16 DUNE on MFMA", parity-holding reading)
+  bool keys_bf16 = false;
+  float k16_err = 0.f, k16_margin = 0.f; // largest measured |bf16 - exact| / margin over the bands g in [0, 8] m
   int selftest_flags = 0;                // NPA_SELFTEST_* : what the create-time self-test changed about this handle
   double key_safety = -1.0;              // NPA_KEY_SAFETY at creation (< 0: the defaults)
   unsigned audit_thresh = 0;             // fraction of the slice waves that run an audit tile, x 2^32
@@ -595,6 +602,46 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
         return fail(NPA_E_ARG, "NPA_ROWS_PRECISION must be fp32 or bf16");
       }
     }
+    if (const char* env = getenv("NPA_KEYS_PRECISION")) {
+      if (!strcmp(env, "bf16")) {
+        if (e == hipSuccess && !(h->key_terms == 4 && !h->select_v1 && !h->rows_bf16 && (P.E == 4 || P.E == 8))) {
+          npa_destroy(h);
+          return fail(NPA_E_UNSUPPORTED, "NPA_KEYS_PRECISION=bf16 needs geometric keys, exact rows and a polygon of 4 or 8 edges");
+        }
+        // margin per band of the exact distance: safety (NPA_KEY_SAFETY, default 2: rounding noise sampled on 3 M grid nodes,
+        // and every survivor is audited at run time) x the largest |bf16 - exact| over the band and its two neighbours
+        unsigned* tab = nullptr;
+        if (e == hipSuccess) e = hipMalloc(&tab, NPA_GEO_BANDS * sizeof(unsigned));
+        if (e == hipSuccess) e = hipMemset(tab, 0, NPA_GEO_BANDS * sizeof(unsigned));
+        const float halves[3] = {8.f, 32.f, 128.f};
+        for (int gI = 0; gI < 3 && e == hipSuccess; ++gI)
+          e = npa_launch_k16_calib(P, h->wpack, 1024, halves[gI], gI == 0 ? 0.f : 0.97f * halves[gI - 1], tab, h->n_cu, nullptr);
+        unsigned bits[NPA_GEO_BANDS];
+        if (e == hipSuccess) e = hipMemcpy(bits, tab, sizeof(bits), hipMemcpyDeviceToHost);
+        if (tab) hipFree(tab);
+        if (e == hipSuccess) {
+          double sf = 2.0;
+          if (const char* e2 = getenv("NPA_K16_SAFETY")) { double v = atof(e2); if (v >= 1.0 && v <= 100.0) sf = v; }
+          float raw[NPA_GEO_BANDS], mg[(NPA_GEO_BANDS + 3) & ~3];
+          for (int bnd = 0; bnd < NPA_GEO_BANDS; ++bnd) memcpy(&raw[bnd], &bits[bnd], 4);
+          for (int bnd = 0; bnd < (int)(sizeof(mg) / sizeof(mg[0])); ++bnd) mg[bnd] = INFINITY;
+          float worst = 0.f, worst_m = 0.f;
+          for (int bnd = 0; bnd < NPA_GEO_BANDS; ++bnd) {
+            float m = -1.f;
+            for (int q = std::max(bnd - 1, 0); q <= std::min(bnd + 1, NPA_GEO_BANDS - 1); ++q)
+              if (bits[q] != 0u) m = std::max(m, raw[q]);
+            mg[bnd] = (m < 0.f || !(m < 1e30f)) ? INFINITY : std::max((float)(sf * m), 1e-5f);
+            if (bnd <= npa_geo_band(8.0f) && m >= 0.f) { worst = std::max(worst, m); worst_m = std::max(worst_m, mg[bnd]); }
+          }
+          h->k16_err = worst; h->k16_margin = worst_m;
+          e = hipMemcpy(h->wpack + WP_K16, mg, sizeof(mg), hipMemcpyHostToDevice);
+          h->keys_bf16 = true;
+        }
+      } else if (strcmp(env, "fp32") != 0) {
+        npa_destroy(h);
+        return fail(NPA_E_ARG, "NPA_KEYS_PRECISION must be fp32 or bf16");
+      }
+    }
     {
       double rate = 1.0 / 64.0;              // audit tiles: one slice wave in 64 (NPA_AUDIT_RATE in [0, 1]; 0 = candidates only)
       if (const char* env = getenv("NPA_AUDIT_RATE")) { double v = atof(env); if (v >= 0.0 && v <= 1.0) rate = v; }
@@ -657,8 +704,9 @@ extern "C" int npa_key_mode(const npa_handle* h, int* key_terms, float* measured
 
 extern "C" int npa_geo_report(const npa_handle* h, float* out, int n) {
   if (!h || !out || n < 1) return fail(NPA_E_ARG, "npa_geo_report: bad argument");
-  const float v[6] = {h->geo_valid ? 1.f : 0.f, h->geo_err, h->geo_margin, h->geo_refine, h->geo_slope, h->P.geo_far};
-  for (int i = 0; i < n && i < 6; ++i) out[i] = v[i];
+  const float v[8] = {h->geo_valid ? 1.f : 0.f, h->geo_err, h->geo_margin, h->geo_refine, h->geo_slope, h->P.geo_far,
+                      h->keys_bf16 ? h->k16_err : 0.f, h->keys_bf16 ? h->k16_margin : 0.f};
+  for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
   return NPA_OK;
 }
 
@@ -831,7 +879,7 @@ extern "C" int npa_dune_stage(npa_handle* h, int batch, int n_stride, const floa
     HIP_TRY(npa_launch_select_geo(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr, trig,
                                   mu_sorted, lam_sorted, pts_sorted, dist_sorted, count, h->sel_stats_dev, h->sel_debug,
                                   h->rows_bf16 ? nullptr : h->audit_dev, h->audit_thresh, h->launch_seq++, h->margin_scale,
-                                  h->rows_bf16 ? 1 : 0, (hipStream_t)stream, nullptr, nullptr));
+                                  h->rows_bf16 ? 1 : (h->keys_bf16 ? 2 : 0), (hipStream_t)stream, nullptr, nullptr));
   else
     HIP_TRY(npa_launch_select(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr,
                               (const unsigned*)h->stage_cand, trig, mu_sorted, lam_sorted, pts_sorted, dist_sorted, count,
@@ -1036,7 +1084,7 @@ extern "C" int npa_group_mergeable(int n, const npa_forward_call* calls) {
   if (!h0) return 0;
   const DevParams& P = h0->P;
   const bool dune0 = P.M > 0 && calls[0].points != nullptr;
-  if (dune0 && !(h0->key_terms == 4 && !h0->select_v1 && !h0->select_scene && npa_select_geo_group_supported(P.E))) return 0;
+  if (dune0 && !(h0->key_terms == 4 && !h0->select_v1 && !h0->select_scene && !h0->rows_bf16 && npa_select_geo_group_supported(P.E))) return 0;
   if (!npa_qp_group_supported(P.T, P.M) || h0->qp_generic || P.qp_aset || (h0->aset_auto && calls[0].batch <= h0->aset_small_batch) ||
       h0->scene_kernel || h0->key_auto)
     return 0;
@@ -1045,7 +1093,7 @@ extern "C" int npa_group_mergeable(int n, const npa_forward_call* calls) {
     const npa_handle* h = calls[c].h;
     if (!h || calls[c].stream != calls[0].stream || calls[c].batch != calls[0].batch || calls[c].iter_num != calls[0].iter_num ||
         h->device != h0->device || memcmp(&h->P, &P, sizeof(DevParams)) != 0 || h->key_terms != h0->key_terms ||
-        h->select_v1 != h0->select_v1 || h->select_scene != h0->select_scene || h->rows_bf16 != h0->rows_bf16 ||
+        h->select_v1 != h0->select_v1 || h->select_scene != h0->select_scene || h->rows_bf16 != h0->rows_bf16 || h->keys_bf16 != h0->keys_bf16 ||
         h->sel_debug != h0->sel_debug || h->audit_thresh != h0->audit_thresh || h->margin_scale != h0->margin_scale ||
         h->qp_generic != h0->qp_generic || h->qp_warm != h0->qp_warm || h->scene_kernel || h->key_auto ||
         (P.M > 0 && calls[c].points != nullptr) != dune0 || (calls[c].out_d == nullptr) != (calls[0].out_d == nullptr))
@@ -1119,7 +1167,7 @@ extern "C" int npa_group_iter_merged(int n, const npa_forward_call* calls, int k
     }
     EventPair* evs = next_event(h0, h0->ev_sel, h0->n_sel);
     HIP_TRY(npa_launch_select_geo_group(P, G, n, batch, k == 0 ? 0 : 1, n_stride_max, h0->sel_debug, h0->audit_thresh,
-                                        h0->margin_scale, h0->rows_bf16 ? 1 : 0, stream, evs ? evs->a : nullptr,
+                                        h0->margin_scale, h0->keys_bf16 ? 2 : 0, stream, evs ? evs->a : nullptr,
                                         evs ? evs->b : nullptr));
   }
   QpGroup Q;
@@ -1178,7 +1226,7 @@ extern "C" int npa_forward_iter(npa_handle* h, int k) {
       HIP_TRY(npa_launch_select_geo(P, h->wpack, batch, 0, t0, pc->n_stride, cur_s, pc->points, pc->velocities, pc->n_points,
                                     flags, ws + L.trig, mu, lam, pts, dist, count, h->sel_stats_dev, h->sel_debug,
                                     h->rows_bf16 ? nullptr : h->audit_dev, h->audit_thresh, h->launch_seq++, h->margin_scale,
-                                    h->rows_bf16 ? 1 : 0, stream, evs ? evs->a : nullptr, evs ? evs->b : nullptr));
+                                    h->rows_bf16 ? 1 : (h->keys_bf16 ? 2 : 0), stream, evs ? evs->a : nullptr, evs ? evs->b : nullptr));
     else
       HIP_TRY(npa_launch_select(P, h->wpack, batch, 0, t0, pc->n_stride, cur_s, pc->points, pc->velocities,
                                 pc->n_points, flags, gkeys, ws + L.trig, mu, lam, pts, dist, count, h->key_terms, h->key_e0,

@@ -181,33 +181,35 @@ extern "C" hipError_t npa_launch_select_geo(const DevParams& P, const float* wpa
   if (n_use_max < 1) n_use_max = 1;
   const size_t n_pad = ((size_t)n_use_max + SEL2_TRIP - 1) / SEL2_TRIP * SEL2_TRIP;
   const size_t key_area = std::max<size_t>(n_pad * sizeof(unsigned), SEL_CAP * (NPA_MAX_E + 5 + 2) * sizeof(float));
-  const size_t shmem = (11 * 32 + 8 * 32 + 8 + NPA_GEO_BANDS) * sizeof(float) + (SEL_CAP + NPA_MAX_M) * sizeof(int) +
+  const size_t shmem = (11 * 32 + 8 * 32 + 8 + NPA_GEO_BANDS) * sizeof(float) + (2 * SEL_CAP + NPA_MAX_M) * sizeof(int) +
                        (key_area + 15) / 16 * 16;
   const int blocks = (batch + 7) / 8 * 8 * nsl;
-#define LAUNCHG(EE, BB)                                                                                             \
+#define LAUNCHG(EE, BB, KK)                                                                                         \
   do {                                                                                                              \
     static NpaDeviceOnce big_lds;                                                                                   \
     int dev_ = 0;                                                                                                   \
     if (shmem > 60 * 1024 && big_lds.need(&dev_)) {                                                                 \
-      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(select_geo_kernel<EE, BB>),                 \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(select_geo_kernel<EE, BB, KK>),             \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
       if (e_ != hipSuccess) return e_;                                                                              \
       big_lds.done(dev_);                                                                                           \
     }                                                                                                               \
-    hipExtLaunchKernelGGL((select_geo_kernel<EE, BB>), dim3(blocks), dim3(64), shmem, stream, ev_start, ev_stop, 0, P, wpack,  \
+    hipExtLaunchKernelGGL((select_geo_kernel<EE, BB, KK>), dim3(blocks), dim3(64), shmem, stream, ev_start, ev_stop, 0, P, wpack,  \
                           n_stride, cur_s, points, vel, n_points, flags, mu_sorted, lam_sorted, pts_sorted, dist_sorted, \
                           count, scene0, t0, nsl, batch, debug, stats, trig, audit, audit_thresh, audit_seed, margin_scale); \
   } while (0)
-  // (the reduced-precision tier of the rows is instantiated for the two polygon sizes the benchmark configurations use)
+  // rows_bf16: 0 = exact; 1 = the reduced-precision tier of the ROWS; 2 = the bf16 tier of the KEYS (rows exact).  Both tiers are
+  // instantiated for the two polygon sizes the benchmark configurations use.
 #define LAUNCH(EE)                                                                                                  \
   do {                                                                                                              \
     if (rows_bf16) return hipErrorInvalidValue;                                                                     \
-    LAUNCHG(EE, false);                                                                                             \
+    LAUNCHG(EE, false, false);                                                                                      \
   } while (0)
 #define LAUNCHB(EE)                                                                                                 \
   do {                                                                                                              \
-    if (rows_bf16) LAUNCHG(EE, true);                                                                               \
-    else LAUNCHG(EE, false);                                                                                        \
+    if (rows_bf16 == 1) LAUNCHG(EE, true, false);                                                                   \
+    else if (rows_bf16 == 2) LAUNCHG(EE, false, true);                                                              \
+    else LAUNCHG(EE, false, false);                                                                                 \
   } while (0)
   switch (P.E) {
     case 3: LAUNCH(3); break;
@@ -235,25 +237,27 @@ extern "C" hipError_t npa_launch_select_geo_group(const DevParams& P, const SelG
   if (n_use_max < 1) n_use_max = 1;
   const size_t n_pad = ((size_t)n_use_max + SEL2_TRIP - 1) / SEL2_TRIP * SEL2_TRIP;
   const size_t key_area = std::max<size_t>(n_pad * sizeof(unsigned), SEL_CAP * (NPA_MAX_E + 5 + 2) * sizeof(float));
-  const size_t shmem = (11 * 32 + 8 * 32 + 8 + NPA_GEO_BANDS) * sizeof(float) + (SEL_CAP + NPA_MAX_M) * sizeof(int) +
+  const size_t shmem = (11 * 32 + 8 * 32 + 8 + NPA_GEO_BANDS) * sizeof(float) + (2 * SEL_CAP + NPA_MAX_M) * sizeof(int) +
                        (key_area + 15) / 16 * 16;
   const int blocks = (batch + 7) / 8 * 8 * nsl;
-#define LAUNCHG(EE, BB)                                                                                             \
+#define LAUNCHG(EE, BB, KK)                                                                                         \
   do {                                                                                                              \
     static NpaDeviceOnce big_lds;                                                                                   \
     int dev_ = 0;                                                                                                   \
     if (shmem > 60 * 1024 && big_lds.need(&dev_)) {                                                                 \
-      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(select_geo_group_kernel<EE, BB>),           \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(select_geo_group_kernel<EE, BB, KK>),       \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
       if (e_ != hipSuccess) return e_;                                                                              \
       big_lds.done(dev_);                                                                                           \
     }                                                                                                               \
-    hipExtLaunchKernelGGL((select_geo_group_kernel<EE, BB>), dim3(blocks, n), dim3(64), shmem, stream, ev_start, ev_stop, 0, P, G, \
+    hipExtLaunchKernelGGL((select_geo_group_kernel<EE, BB, KK>), dim3(blocks, n), dim3(64), shmem, stream, ev_start, ev_stop, 0, P, G, \
                           t0, nsl, batch, debug, audit_thresh, margin_scale);                                       \
   } while (0)
-  // (instantiated for the polygon sizes of the benchmark configurations; c_api.hip keeps other sizes call by call)
-  if (P.E == 4) { if (rows_bf16) LAUNCHG(4, true); else LAUNCHG(4, false); }
-  else if (P.E == 8) { if (rows_bf16) LAUNCHG(8, true); else LAUNCHG(8, false); }
+  // (instantiated for the polygon sizes of the benchmark configurations, exact and with bf16 KEYS; the lossy bf16 ROWS tier and
+  // other polygon sizes stay call by call -- c_api.hip asks npa_select_geo_group_supported)
+  if (rows_bf16 == 1) return hipErrorInvalidValue;
+  if (P.E == 4) { if (rows_bf16 == 2) LAUNCHG(4, false, true); else LAUNCHG(4, false, false); }
+  else if (P.E == 8) { if (rows_bf16 == 2) LAUNCHG(8, false, true); else LAUNCHG(8, false, false); }
   else return hipErrorInvalidValue;
 #undef LAUNCHG
   return hipGetLastError();
@@ -329,6 +333,57 @@ extern "C" hipError_t npa_launch_geo_calib(const DevParams& P, const float* wpac
     default: return hipErrorInvalidValue;
   }
 #undef LAUNCH
+  return hipGetLastError();
+}
+
+// ---- bf16 KEY tier: |bf16-encoder distance - exact distance| per band of the exact distance (npa_create) -----------------
+// Rounding noise, not a smooth function: measured on the same nested squares as the geometric margin (1024 x 1024 nodes each),
+// the host applies a safety factor and the kernel audits every survivor at run time (select_geo_body.inc).
+template <int E>
+__global__ __launch_bounds__(256) void k16_calib_kernel(DevParams P, const float* __restrict__ wpack, float half, int nside, float inner,
+                                                        unsigned* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* vec = smem;
+  float* w6 = vec + 11 * 32;
+  float* b6 = w6 + 8 * 32;
+  unsigned* tab = reinterpret_cast<unsigned*>(b6 + 8);          // [NPA_GEO_BANDS]
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hf = lane >> 5;
+  for (int i = tid; i < 11 * 32 + 8 * 32 + 8; i += blockDim.x) smem[i] = wpack[WP_VEC + i];
+  for (int i = tid; i < NPA_GEO_BANDS; i += blockDim.x) tab[i] = 0u;
+  __syncthreads();
+  const float w1 = wpack[WP_W1 + lane];
+  const float step = 2.0f * half / (float)(nside - 1);
+  const int tiles_x = nside >> 3, tiles_y = nside >> 2;
+  const long long tiles = (long long)tiles_x * tiles_y;
+  const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (tid >> 6), nwave = (long long)gridDim.x * (blockDim.x >> 6);
+  for (long long tile = wave; tile < tiles; tile += nwave) {
+    const int ix = (int)(tile % tiles_x) * 8 + (j & 7), iy = (int)(tile / tiles_x) * 4 + (j >> 3);
+    const float p0x = -half + step * (float)ix, p0y = -half + step * (float)iy;
+    float me[E], mb[E];
+    encode_tile_stream<E>(w1, wpack + WP_WLS, vec, w6, b6, p0x, p0y, lane, me);
+    encode_tile_bf16<E>(w1, wpack + WP_WB16, vec, w6, b6, p0x, p0y, lane, mb);
+    float de = 0.f, db = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const float tmp = __fsub_rn(fmaf(P.G[e][0], p0x, __fmul_rn(P.G[e][1], p0y)), P.h[e]);
+      de = fmaf(me[e], tmp, de);
+      db = fmaf(mb[e], tmp, db);
+    }
+    float f = fabsf(db - de);
+    if (!(f == f)) f = 3.0e38f;
+    if (hf == 0 && fmaxf(fabsf(p0x), fabsf(p0y)) >= inner) atomicMax(&tab[npa_geo_band(de)], __float_as_uint(f));
+  }
+  __syncthreads();
+  for (int i = tid; i < NPA_GEO_BANDS; i += blockDim.x)
+    if (tab[i]) atomicMax(&out[i], tab[i]);
+}
+extern "C" hipError_t npa_launch_k16_calib(const DevParams& P, const float* wpack, int nside, float half, float inner, unsigned* out,
+                                           int n_cu, hipStream_t stream) {
+  const size_t shmem = (11 * 32 + 8 * 32 + 8 + NPA_GEO_BANDS) * sizeof(float);
+  const int blocks = n_cu * 4;
+  if (P.E == 4) hipLaunchKernelGGL((k16_calib_kernel<4>), dim3(blocks), dim3(256), shmem, stream, P, wpack, half, nside, inner, out);
+  else if (P.E == 8) hipLaunchKernelGGL((k16_calib_kernel<8>), dim3(blocks), dim3(256), shmem, stream, P, wpack, half, nside, inner, out);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 

@@ -1049,7 +1049,7 @@ extern "C" int npa_dbg_sel_prof(unsigned long long* out16, int reset) {
 #define SELP_DECL
 #define SELP(i)
 #endif
-template <int E, bool BF16 = false>
+template <int E, bool BF16 = false, bool KEYS16 = false>
 __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(E <= 6 ? 4 : 3, E <= 6 ? 4 : 3))) void select_geo_kernel(
     DevParams P, const float* __restrict__ wpack, int n_stride, const float* __restrict__ cur_s,
     const float* __restrict__ points, const float* __restrict__ vel, const int* __restrict__ n_points,
@@ -1070,7 +1070,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
 
 // select_geo_kernel over a GROUP of forward calls (pan_common.h: merged launches): blockIdx.y = the call, blockIdx.x what it
 // is above; the per-call pointers come out of the kernel arguments, everything else is the same statements.
-template <int E, bool BF16 = false>
+template <int E, bool BF16 = false, bool KEYS16 = false>
 __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_eu(E <= 6 ? 4 : 3, E <= 6 ? 4 : 3))) void select_geo_group_kernel(
     DevParams P, SelGeoGroup G, int t0, int nsl, int nscene, int debug, unsigned audit_thresh, float margin_scale) {
   const SelGeoCall& q = G.c[blockIdx.y];

@@ -127,7 +127,10 @@ __host__ __device__ inline int npa_geo_band(float g) {
 // exact network's weights rounded to bf16 (RNE), no scaling, no centring
 #define WP_WB16 (WP_WLS + 4 * 64 * 16)
 #define WP_WB16_FLOATS (4 * 2 * 64 * 4)
-#define WP_TOTAL (WP_WB16 + WP_WB16_FLOATS)
+// the bf16 KEY tier (NPA_KEYS_PRECISION=bf16): margin per band of the EXACT distance for |bf16-encoder distance - exact distance|,
+// measured at creation (k16_calib_kernel); +inf = uncalibrated
+#define WP_K16 (WP_WB16 + WP_WB16_FLOATS)
+#define WP_TOTAL (WP_K16 + ((NPA_GEO_BANDS + 3) & ~3))
 // order of the per-feature vectors
 enum { V_B1 = 0, V_G1, V_BE1, V_B2, V_B3, V_G2, V_BE2, V_B4, V_B5, V_G3, V_BE3 };
 

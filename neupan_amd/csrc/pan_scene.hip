@@ -49,6 +49,7 @@ __device__ __forceinline__ void select_geo_scene(
   float* __restrict__ dist_sorted = dist_sorted_; int* __restrict__ count = count_; unsigned* __restrict__ stats = stats_;
   const float* __restrict__ trig = trig_; unsigned* __restrict__ audit = audit_;
   const int b = b_, t = t_;
+  constexpr bool KEYS16 = false;
 #include "select_geo_carve.inc"
   int lane_ = threadIdx.x;
   asm volatile("" : "+v"(lane_));
@@ -208,7 +209,7 @@ extern "C" hipError_t npa_launch_pan_scene(const DevParams& P, const float* wpac
   if (n_use_max < 1) n_use_max = 1;
   const size_t n_pad = ((size_t)n_use_max + SEL2_TRIP - 1) / SEL2_TRIP * SEL2_TRIP;
   const size_t key_area = std::max<size_t>(n_pad * sizeof(unsigned), SEL_CAP * (NPA_MAX_E + 5 + 2) * sizeof(float));
-  const size_t sel_bytes = (11 * 32 + 8 * 32 + 8 + NPA_GEO_BANDS) * sizeof(float) + (SEL_CAP + NPA_MAX_M) * sizeof(int) +
+  const size_t sel_bytes = (11 * 32 + 8 * 32 + 8 + NPA_GEO_BANDS) * sizeof(float) + (2 * SEL_CAP + NPA_MAX_M) * sizeof(int) +
                            (key_area + 15) / 16 * 16;
   const size_t shmem = std::max(sel_bytes, npa_qp_shmem_bytes_path(P.T, P.M, 1));
 #define SCENE_LAUNCH(EE, TT_, MM_, SW_)                                                                               \
@@ -239,7 +240,7 @@ static size_t scene_select_lds(const DevParams& P, int n_stride) {
   if (n_use_max < 1) n_use_max = 1;
   const size_t n_pad = ((size_t)n_use_max + SEL2_TRIP - 1) / SEL2_TRIP * SEL2_TRIP;
   const size_t key_area = std::max<size_t>(n_pad * sizeof(unsigned), SEL_CAP * (NPA_MAX_E + 5 + 2) * sizeof(float));
-  const size_t slice_body = (11 * 32 + 8 * 32 + 8 + NPA_GEO_BANDS) * sizeof(float) + (SEL_CAP + NPA_MAX_M) * sizeof(int) +
+  const size_t slice_body = (11 * 32 + 8 * 32 + 8 + NPA_GEO_BANDS) * sizeof(float) + (2 * SEL_CAP + NPA_MAX_M) * sizeof(int) +
                             (key_area + 15) / 16 * 16;
   const size_t ns = (size_t)P.T + 1;
   const size_t fast = (11 * 32 + 8 * 32 + 8 + NPA_GEO_BANDS) * sizeof(float) + ns * 16 + ns * SCN_CAP * 2 +

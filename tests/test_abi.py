@@ -141,8 +141,9 @@ def test_hot_kernels_have_no_spills_and_no_scratch():
         pytest.skip("ROCm LLVM tools not installed")
     res = kr.kernel_resources()
     sel = {n: r for n, r in res.items() if "select_geo_kernel" in n or "select_geo_group_kernel" in n}
-    # E = 3 .. 8, plus the bf16 tier of the rows at E = 4 and 8; the merged-launch form (blockIdx.y = the call) for E = 4 and 8, both tiers
-    assert len(sel) == 8 + 4, sorted(sel)
+    # E = 3 .. 8, plus the bf16 tiers of the rows and of the keys at E = 4 and 8; the merged-launch form (blockIdx.y = the call) for
+    # E = 4 and 8, exact and with bf16 keys
+    assert len(sel) == 10 + 4, sorted(sel)
     for n, r in sel.items():
         assert r["vgpr_spill"] == 0 and r["scratch"] == 0, (n, r)
         wide = "ILi7E" in n or "ILi8E" in n                     # (E > 6 is built for three waves per SIMD)

@@ -742,6 +742,48 @@ def test_wrong_margin_is_detected_and_contained():
     assert np.array_equal(out["opt_u"].cpu().numpy(), ref["opt_u"].cpu().numpy())
 
 
+@pytest.mark.parametrize("cfgname,B", [("poly8_5k_T10_K10", 24), ("dyna_4k_T10_K10", 24), ("acker_2k_T20_K15", 24), ("diff_1k_T10_K10", 48)])
+def test_bf16_key_tier_emits_the_exact_rows(cfgname, B):
+    """NPA_KEYS_PRECISION=bf16 -- BASELINE configs[4]'s "bf16 DUNE on MFMA" with parity intact: a slice whose candidate list
+    overflows the final ranking runs the LIST through the bf16-MFMA encoder (v_mfma_f32_32x32x16_bf16), keeps every point within
+    2 x the measured |bf16 - exact| of the M-th smallest bf16 distance, and re-encodes the survivors with the exact fp32
+    encoder -- the rows, and with them every control, are BITWISE those of the default path (any superset of the true nearest
+    M ranked on exact keys gives the same rows).  Checked on the dense clouds where the list does overflow (8-edge hull 5000
+    points, 4000 moving points, the car) and on walls / blobs; the filter must actually have decided slices (debug statistics),
+    every survivor's |exact - bf16| must hold the margin (the audit counts violations: zero), and a forward call agrees bitwise."""
+    import torch
+    from gpu_helpers import make_gpu_pan, wall_batch
+    cfg = CONFIGS[cfgname]
+    ref = make_gpu_pan(cfg)
+    k16 = _with_env({"NPA_KEYS_PRECISION": "bf16"}, lambda: make_gpu_pan(cfg))
+    rep = k16.geo_report()
+    print(cfgname, "bf16 key error", rep["bf16_key_error"], "margin", rep["bf16_key_margin"])
+    # (largest |bf16 - exact| over the bands below 8 m: 2 .. 4 cm for the diff / polygon checkpoints, 18 cm for the car's)
+    assert 0 < rep["bf16_key_error"] < 0.5 and rep["bf16_key_margin"] >= rep["bf16_key_error"]
+    batches = [make_batch(cfg, 21000, B)]
+    if cfgname.startswith("diff"):
+        batches.append(wall_batch(cfg, B))
+    # the filter decided slices (count[] >> 16: 1 = exact keys for the list, 2 = the filter gave up, 3 = the filter decided)
+    dbg = _with_env({"NPA_KEYS_PRECISION": "bf16", "NPA_SEL_DEBUG": "1"}, lambda: make_gpu_pan(cfg))
+    c = _stage_np(dbg, batches[0])["count"] >> 16
+    share = {v: float((c == v).mean()) for v in (0, 1, 2, 3)}
+    print(cfgname, "slices: no overflow %.3f, exact keys for the list %.3f, filter gave up %.3f, filter decided %.3f" %
+          (share[0], share[1], share[2], share[3]))
+    for bi, batch in enumerate(batches):
+        kw = {"n_points": batch["n_points"]} if batch.get("n_points") is not None else {}
+        a, b = _stage_np(ref, batch, **kw), _stage_np(k16, batch, **kw)
+        for k in ("mu", "lam", "pts", "dist", "count"):
+            assert np.array_equal(a[k], b[k]), (cfgname, bi, k)
+        args = [batch[k] for k in ("nom_s", "nom_u", "ref_s", "ref_us", "points")] + [batch.get("velocities"), batch.get("n_points")]
+        ref.reset_stop_state(); k16.reset_stop_state()
+        oa, ob = ref.forward_batch(*args), k16.forward_batch(*args)
+        for k in ("opt_u", "opt_s", "opt_d", "min_distance", "iters"):
+            assert np.array_equal(oa[k].cpu().numpy(), ob[k].cpu().numpy(), equal_nan=True), (cfgname, bi, k)
+    assert k16.audit()["violations"] == 0, k16.audit()
+    if cfgname.startswith("poly8"):
+        assert share[2] + share[3] > 0.2, share       # (the dense cloud's long lists do go through the filter)
+
+
 def test_self_test_outcomes_of_the_shipped_configurations():
     """npa_create's self-test hard-fails only on non-determinism or non-finite / out-of-box controls; warm-vs-cold and
     geometric-vs-exact disagreements are soft (npa_selftest_flags).  None of the benchmark configurations trips either."""
