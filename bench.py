@@ -548,7 +548,8 @@ def compact(line, full_path):
             e["uniform_cloud"] = {"plans_per_s": u["plans_per_s"], "parity": _verdicts(u.get("parity"))}
         if "other_configs" in x:
             e["other_configs"] = {k: dict({"plans_per_s": v["plans_per_s"], "parity": _verdicts(v.get("parity"))},
-                                          **({"same_controls_as_exact": v["controls_equal_exact_path"]} if "controls_equal_exact_path" in v else {}))
+                                          **({"same_controls_as_exact": v["controls_equal_exact_path"]} if "controls_equal_exact_path" in v else {}),
+                                          **({"no_key_table": v["without_key_table"]["plans_per_s"]} if "without_key_table" in v else {}))
                                   for k, v in x["other_configs"].items() if isinstance(v, dict)}
         if "launch_shapes" in x:
             e["launch_shapes"] = {k: v["plans_per_s"] for k, v in x["launch_shapes"].items() if isinstance(v, dict)}
@@ -914,7 +915,10 @@ def main():
                 del dbg
             nc, fb = (c_ >> 8) & 0xFF, c_ >> 16
             return {"median": int(np.median(nc)), "mean": round(float(nc.mean()), 1), "p90": int(np.quantile(nc, 0.9)), "max": int(nc.max()),
-                    "share_gt_32": round(float((nc > 32).mean()), 4), "share_overflow_to_exact_keys": round(float((fb > 0).mean()), 4),
+                    "share_gt_32": round(float((nc > 32).mean()), 4),
+                    # fb: 1 = exact keys for the whole list, 2 = the table filter shortened it first, 3 = the filter decided the slice
+                    "share_overflow_to_exact_keys": round(float(((fb == 1) | (fb == 2)).mean()), 4),
+                    "share_decided_by_table_filter": round(float((fb == 3).mean()), 4),
                     "histogram_0_16_32_64_128_256": np.histogram(nc, bins=[0, 16, 32, 64, 128, 256])[0].tolist()}
         res["candidates_per_slice"] = cand("uniform_1k_T10_K10", l2.args[0])
         b0 = make_batch(cfg, 0, B)
@@ -945,6 +949,15 @@ def main():
             u_ = l2.pans[0].forward_batch(*l2.args[0])["opt_u"].cpu().numpy()
             if not env:
                 exact_u[wl] = u_
+                if wl != "acker_2k_T20_K15":
+                    # the same leg without the key table (NPA_GEO_TABLE=0: round 4's selection -- exact keys for every long
+                    # candidate list): what the second-stage filter is worth on the dense clouds; controls bitwise equal
+                    r0, l0 = short_run(wl, b_, nf, dev, 24 if b_ > B else 100, 8 if b_ > B else 20, env={"NPA_GEO_TABLE": "0"},
+                                       issue_threads=args.issue_threads, chains=0)
+                    l0.pans[0].reset_stop_state()
+                    res["without_key_table"] = {"plans_per_s": r0["plans_per_s"], "select_launch_ms": r0["select_launch_ms"],
+                                                "controls_equal": bool(np.array_equal(l0.pans[0].forward_batch(*l0.args[0])["opt_u"].cpu().numpy(), u_))}
+                    l0.close()
             elif wl in exact_u:
                 # the bf16 KEY tier nominates with the bf16-MFMA encoder and emits exact rows: bitwise the exact path's controls
                 res["controls_equal_exact_path"] = bool(np.array_equal(u_, exact_u[wl]))

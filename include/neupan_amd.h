@@ -103,6 +103,10 @@ int npa_key_mode(const npa_handle *h, int *key_terms, float *measured_error, flo
  *   [6], [7] (handles created with NPA_KEYS_PRECISION=bf16, else 0): largest measured |bf16-encoder distance - exact distance|
  *       and the largest margin built from it over the bands below 8 m (the bf16 KEY tier: a slice whose candidate list
  *       overflows is filtered with the bf16-MFMA encoder, the survivors re-encoded exactly -- rows bitwise the default path's).
+ *   [8], [9] (0 when the handle has no key table: NPA_GEO_TABLE=0, network keys): largest measured |g + f_table - exact
+ *       distance| and the largest margin built from it over the bands below 8 m -- the TABLE-corrected geometric key, the
+ *       second-stage filter of candidate lists longer than one encoder tile (f = network - geometric distance tabulated at
+ *       creation on four nested 512 x 512-cell squares (half extents 2 .. 128 m), bilinear; survivors re-encoded exactly and audited: rows bitwise).
  * The margin is MEASURED, not proven (LayerNorm leaves no usable analytic Lipschitz bound); npa_audit_read is the
  * run-time check. */
 int npa_geo_report(const npa_handle *h, float *out, int n);

@@ -20,6 +20,9 @@ extern "C" hipError_t npa_launch_encode(const DevParams& P, const float* wpack, 
 extern "C" hipError_t npa_launch_trig(const float* cur_s, int batch, int T, float* trig, hipStream_t stream);
 extern "C" hipError_t npa_launch_key_calib(const DevParams& P, const float* wpack, int key_terms, int nside, float half,
                                            unsigned* out, hipStream_t stream);
+extern "C" hipError_t npa_launch_geo_table(const DevParams& P, float* wpack, float* nodes, int n_cu, hipStream_t stream);
+extern "C" hipError_t npa_launch_ktab_calib(const DevParams& P, const float* wpack, int nside, float half, float inner, float cx, float cy,
+                                            unsigned* out, int n_cu, hipStream_t stream);
 extern "C" hipError_t npa_launch_geo_calib(const DevParams& P, const float* wpack, int nside, float half, float inner,
                                            float shift, unsigned* out, int n_cu, hipStream_t stream);
 extern "C" hipError_t npa_launch_select_geo(const DevParams& P, const float* wpack, int batch, int scene0, int t0,
@@ -119,7 +122,9 @@ struct npa_handle {
   int key_terms = 1;                     // 4 = geometric keys computed by select_kernel itself (no dune_kernel launch)
   float key_e0 = 0.f, key_err = 0.f;
   bool qp_warm = true;                   // interior-point warm start across the PAN iterations of a forward call (NPA_QP_COLD=1: off)
-  int sel_debug = 0;                     // NPA_SEL_DEBUG at creation: npa_dune_stage's count[] carries candidate statistics
+  // NPA_SEL_DEBUG at creation: npa_dune_stage's count[] carries candidate statistics.  ONLY there: inside a forward call count[]
+  // is the row count the QP kernel sizes its loops with (a debug word in it once sent the stop test ~200 k rows past its buffer)
+  int sel_debug = 0;
   bool geo_valid = false;                // the polygon could be turned into vertices (consecutive CCW edges)
   float geo_err = 0.f, geo_margin = 0.f; // largest |network - geometric distance| / margin over the bands g in [0.25, 8] m
   // grid-refinement check of the margin (npa_create): largest ratio, over the bands, of |f| seen at the CELL CENTRES of a
@@ -138,6 +143,9 @@ struct npa_handle {
   // exactly: the rows are bitwise those of the default path (BASELINE configs[4] "bf16 DUNE on MFMA", parity-holding reading)
   bool keys_bf16 = false;
   float k16_err = 0.f, k16_margin = 0.f; // largest measured |bf16 - exact| / margin over the bands g in [0, 8] m
+  // the table-corrected geometric key (second-stage filter of long candidate lists, P.geo_tab; NPA_GEO_TABLE=0 switches it off):
+  // largest measured |g + f_table - exact| / margin over the bands of the exact distance in [0, 8] m
+  float ktab_err = 0.f, ktab_margin = 0.f;
   int selftest_flags = 0;                // NPA_SELFTEST_* : what the create-time self-test changed about this handle
   double key_safety = -1.0;              // NPA_KEY_SAFETY at creation (< 0: the defaults)
   unsigned audit_thresh = 0;             // fraction of the slice waves that run an audit tile, x 2^32
@@ -317,7 +325,40 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
   }
 
   std::vector<float> pack(WP_TOTAL, 0.f);
-  for (int i = 0; i < NPA_GEO_BANDS; ++i) pack[WP_GEO + i] = INFINITY;
+  for (int i = 0; i < NPA_GEO_BANDS; ++i) pack[WP_GEO + i] = pack[WP_KTAB + i] = INFINITY;
+  {
+    // header of the key table (pan_common.h, WP_TABH): its squares are centred on the polygon's bounding box
+    float xmin = 3e38f, xmax = -3e38f, ymin = 3e38f, ymax = -3e38f;
+    for (int e = 0; e < P.E && h->geo_valid; ++e) {
+      xmin = std::min(xmin, P.pvx[e]); xmax = std::max(xmax, P.pvx[e]); ymin = std::min(ymin, P.pvy[e]); ymax = std::max(ymax, P.pvy[e]);
+    }
+    const bool okb = h->geo_valid && xmax >= xmin && ymax >= ymin;
+    const float h0 = okb ? std::max(NPA_TAB_HALF0, 1.25f * 0.5f * std::max(xmax - xmin, ymax - ymin)) : NPA_TAB_HALF0;
+    pack[WP_TABH] = okb ? 0.5f * (xmin + xmax) : 0.f; pack[WP_TABH + 1] = okb ? 0.5f * (ymin + ymax) : 0.f;
+    pack[WP_TABH + 2] = h0; pack[WP_TABH + 3] = 0.5f * (float)NPA_TAB_N / h0;
+    // a polygon that is not an axis-aligned box: its bounding box (grown by 10 um: it must CONTAIN the polygon in fp32) for the
+    // key pass, and the slack S = the largest distance from a corner of that box to the polygon
+    pack[WP_TABH + 4] = 0.f;
+    if (okb && !P.geo_rect) {
+      P.rcx = 0.5f * (xmin + xmax); P.rcy = 0.5f * (ymin + ymax);
+      P.rhx = 0.5f * (xmax - xmin) + 1e-5f; P.rhy = 0.5f * (ymax - ymin) + 1e-5f;
+      double S = 0.0;
+      for (int cxs = -1; cxs <= 1; cxs += 2)
+        for (int cys = -1; cys <= 1; cys += 2) {
+          const double qx = (double)P.rcx + cxs * (double)P.rhx, qy = (double)P.rcy + cys * (double)P.rhy;
+          double best = 1e300;
+          for (int e = 0; e < P.E; ++e) {
+            const double rx = qx - P.pvx[e], ry = qy - P.pvy[e];
+            double t = (rx * P.pdx[e] + ry * P.pdy[e]) * P.pil[e];
+            t = std::min(std::max(t, 0.0), 1.0);
+            const double ux = rx - t * P.pdx[e], uy = ry - t * P.pdy[e];
+            best = std::min(best, ux * ux + uy * uy);
+          }
+          S = std::max(S, std::sqrt(best));
+        }
+      pack[WP_TABH + 4] = (float)(S * (1.0 + 1e-5) + 1e-5);
+    }
+  }
   if (need_w) {
     const int E = P.E;
     for (int l = 0; l < 64; ++l) pack[WP_W1 + l] = w->lin_w[0][(l & 31) * 2 + (l >> 5)];   // A[i][k] = W1[i][k]
@@ -457,7 +498,7 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
     if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0)
       h->n_cu = prop.multiProcessorCount;
   }
-  if (e == hipSuccess) e = hipMalloc(&h->wpack, WP_TOTAL * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&h->wpack, ((size_t)WP_TAB + WP_TAB_FLOATS) * sizeof(float));      // (the pack, then the key table)
   if (e == hipSuccess) e = hipMemcpy(h->wpack, pack.data(), WP_TOTAL * sizeof(float), hipMemcpyHostToDevice);
   // Key mode and candidate margin.  Distance KEYS only nominate candidates (select_kernel re-encodes them with the
   // exact network and ranks on the exact result), so their error decides nothing but how many candidates there are
@@ -573,6 +614,47 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
             P.geo_far = (float)std::max(1.0, (double)halves[2] - rmax);
           }
           h->key_terms = 4; h->key_err = worst_err; h->key_e0 = worst_margin;
+        }
+      }
+      // The correction table of the geometric key and the margin of the corrected key (pan_common.h, WP_TAB / WP_KTAB): f at
+      // the nodes of the four squares, then |g + f_table - exact| per band of the exact distance on the calibration grids
+      // (whose nodes drift through every offset inside a cell).  Margin = NPA_KTAB_SAFETY (default 2) x the largest residual over
+      // the band and its two neighbours, at least 0.1 mm; every survivor of the filter is audited against it at run time.
+      const char* tab_env = getenv("NPA_GEO_TABLE");
+      if (e == hipSuccess && geo_ok && (P.E == 4 || P.E == 8) && !(tab_env && atoi(tab_env) == 0)) {
+        float* nodes = nullptr;
+        unsigned* tabk = nullptr;
+        e = hipMalloc(&nodes, (size_t)NPA_TAB_LEVELS * (NPA_TAB_N + 1) * (NPA_TAB_N + 1) * sizeof(float));
+        if (e == hipSuccess) e = npa_launch_geo_table(P, h->wpack, nodes, h->n_cu, nullptr);
+        if (e == hipSuccess) e = hipMalloc(&tabk, NPA_GEO_BANDS * sizeof(unsigned));
+        if (e == hipSuccess) e = hipMemset(tabk, 0, NPA_GEO_BANDS * sizeof(unsigned));
+        // (one calibration square per level of the table, nside^2 nodes each: 8 x 8 samples per cell at the default 4096)
+        const float th0 = pack[WP_TABH + 2];
+        const float khalves[NPA_TAB_LEVELS] = {th0, 4.f * th0, 16.f * th0, 64.f * th0};
+        for (int gI = 0; gI < NPA_TAB_LEVELS && e == hipSuccess; ++gI)
+          e = npa_launch_ktab_calib(P, h->wpack, nside, khalves[gI], gI == 0 ? 0.f : 0.97f * khalves[gI - 1], pack[WP_TABH], pack[WP_TABH + 1],
+                                    tabk, h->n_cu, nullptr);
+        unsigned kb[NPA_GEO_BANDS];
+        if (e == hipSuccess) e = hipMemcpy(kb, tabk, sizeof(kb), hipMemcpyDeviceToHost);
+        if (nodes) hipFree(nodes);
+        if (tabk) hipFree(tabk);
+        if (e == hipSuccess) {
+          double sfk = 2.0;
+          if (const char* e2 = getenv("NPA_KTAB_SAFETY")) { double v = atof(e2); if (v >= 1.0 && v <= 100.0) sfk = v; }
+          float raw[NPA_GEO_BANDS], mk[(NPA_GEO_BANDS + 3) & ~3];
+          for (int bnd = 0; bnd < NPA_GEO_BANDS; ++bnd) memcpy(&raw[bnd], &kb[bnd], 4);
+          for (int bnd = 0; bnd < (int)(sizeof(mk) / sizeof(mk[0])); ++bnd) mk[bnd] = INFINITY;
+          float worst = 0.f, worst_m = 0.f;
+          for (int bnd = 0; bnd < NPA_GEO_BANDS; ++bnd) {
+            float m = -1.f;
+            for (int q = std::max(bnd - 1, 0); q <= std::min(bnd + 1, NPA_GEO_BANDS - 1); ++q)
+              if (kb[q] != 0u) m = std::max(m, raw[q]);
+            mk[bnd] = (m < 0.f || !(m < 1e30f)) ? INFINITY : std::max((float)(sfk * m), 1e-4f);
+            if (bnd <= npa_geo_band(8.0f) && m >= 0.f) { worst = std::max(worst, m); worst_m = std::max(worst_m, mk[bnd]); }
+          }
+          h->ktab_err = worst; h->ktab_margin = worst_m;
+          e = hipMemcpy(h->wpack + WP_KTAB, mk, sizeof(mk), hipMemcpyHostToDevice);
+          if (e == hipSuccess) P.geo_tab = 1;
         }
       }
     }
@@ -704,9 +786,10 @@ extern "C" int npa_key_mode(const npa_handle* h, int* key_terms, float* measured
 
 extern "C" int npa_geo_report(const npa_handle* h, float* out, int n) {
   if (!h || !out || n < 1) return fail(NPA_E_ARG, "npa_geo_report: bad argument");
-  const float v[8] = {h->geo_valid ? 1.f : 0.f, h->geo_err, h->geo_margin, h->geo_refine, h->geo_slope, h->P.geo_far,
-                      h->keys_bf16 ? h->k16_err : 0.f, h->keys_bf16 ? h->k16_margin : 0.f};
-  for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
+  const float v[10] = {h->geo_valid ? 1.f : 0.f, h->geo_err, h->geo_margin, h->geo_refine, h->geo_slope, h->P.geo_far,
+                       h->keys_bf16 ? h->k16_err : 0.f, h->keys_bf16 ? h->k16_margin : 0.f,
+                       h->P.geo_tab ? h->ktab_err : 0.f, h->P.geo_tab ? h->ktab_margin : 0.f};
+  for (int i = 0; i < n && i < 10; ++i) out[i] = v[i];
   return NPA_OK;
 }
 
@@ -1166,7 +1249,7 @@ extern "C" int npa_group_iter_merged(int n, const npa_forward_call* calls, int k
       if (pc.n_stride > n_stride_max) n_stride_max = pc.n_stride;
     }
     EventPair* evs = next_event(h0, h0->ev_sel, h0->n_sel);
-    HIP_TRY(npa_launch_select_geo_group(P, G, n, batch, k == 0 ? 0 : 1, n_stride_max, h0->sel_debug, h0->audit_thresh,
+    HIP_TRY(npa_launch_select_geo_group(P, G, n, batch, k == 0 ? 0 : 1, n_stride_max, 0, h0->audit_thresh,
                                         h0->margin_scale, h0->keys_bf16 ? 2 : 0, stream, evs ? evs->a : nullptr,
                                         evs ? evs->b : nullptr));
   }
@@ -1219,18 +1302,18 @@ extern "C" int npa_forward_iter(npa_handle* h, int k) {
     EventPair* evs = next_event(h, h->ev_sel, h->n_sel);
     if (geo && !h->select_v1 && h->select_scene && !h->rows_bf16 && npa_select_scene_supported(P.E, P.T))
       HIP_TRY(npa_launch_select_scene(P, h->wpack, batch, 0, t0, pc->n_stride, cur_s, pc->points, pc->velocities, pc->n_points,
-                                      flags, ws + L.trig, mu, lam, pts, dist, count, h->sel_stats_dev, h->sel_debug, h->audit_dev,
+                                      flags, ws + L.trig, mu, lam, pts, dist, count, h->sel_stats_dev, 0, h->audit_dev,
                                       h->audit_thresh, h->launch_seq++, h->margin_scale, stream, evs ? evs->a : nullptr,
                                       evs ? evs->b : nullptr));
     else if (geo && !h->select_v1)
       HIP_TRY(npa_launch_select_geo(P, h->wpack, batch, 0, t0, pc->n_stride, cur_s, pc->points, pc->velocities, pc->n_points,
-                                    flags, ws + L.trig, mu, lam, pts, dist, count, h->sel_stats_dev, h->sel_debug,
+                                    flags, ws + L.trig, mu, lam, pts, dist, count, h->sel_stats_dev, 0,
                                     h->rows_bf16 ? nullptr : h->audit_dev, h->audit_thresh, h->launch_seq++, h->margin_scale,
                                     h->rows_bf16 ? 1 : (h->keys_bf16 ? 2 : 0), stream, evs ? evs->a : nullptr, evs ? evs->b : nullptr));
     else
       HIP_TRY(npa_launch_select(P, h->wpack, batch, 0, t0, pc->n_stride, cur_s, pc->points, pc->velocities,
                                 pc->n_points, flags, gkeys, ws + L.trig, mu, lam, pts, dist, count, h->key_terms, h->key_e0,
-                                h->sel_stats_dev, h->sel_debug, stream, evs ? evs->a : nullptr, evs ? evs->b : nullptr));
+                                h->sel_stats_dev, 0, stream, evs ? evs->a : nullptr, evs ? evs->b : nullptr));
   }
   // the active-set launch in front of the interior-point launch (nrmp_qp.hip, top of the kernel): scenes it finishes are skipped
   // by the launch behind it.  Register-resident T = 10 / M = 10 instantiation only; small batches keep the single launch (a
@@ -1309,7 +1392,7 @@ static int forward_scene_launch(npa_handle* h, int iters) {
                                ws + L.cur_u, ws + L.cur_d, pc->ref_s, pc->ref_us, ws + L.mu, ws + L.lam, ws + L.pts, ws + L.dist,
                                (int*)(ws + L.count), pc->out_s, pc->out_u, pc->out_d, pc->out_md, pc->out_iters, pc->out_np,
                                (int*)(ws + L.flags), pc->state, (double*)(ws + L.qp_info),
-                               h->qp_warm ? (double*)(ws + L.warm) : nullptr, ws + L.trig, iters, h->sel_debug, h->sel_stats_dev,
+                               h->qp_warm ? (double*)(ws + L.warm) : nullptr, ws + L.trig, iters, 0, h->sel_stats_dev,
                                h->audit_dev, h->audit_thresh, seq, h->margin_scale, pc->stream, ev ? ev->a : nullptr,
                                ev ? ev->b : nullptr));
   return NPA_OK;

@@ -387,6 +387,117 @@ extern "C" hipError_t npa_launch_k16_calib(const DevParams& P, const float* wpac
   return hipGetLastError();
 }
 
+// ---- table-corrected geometric key (npa_create): the table, then its residual ----------------------------------------------
+// f = network distance - geometric key at the (N + 1)^2 nodes of every level (exact encoder; the key is the run-time one,
+// geo_key: whatever it rounds, the table absorbs), then packed cell by cell (four corners as fp16: one gather per lookup).
+template <int E>
+__global__ __launch_bounds__(256) void geo_table_nodes_kernel(DevParams P, const float* __restrict__ wpack, float* __restrict__ nodes) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* vec = smem;
+  float* w6 = vec + 11 * 32;
+  float* b6 = w6 + 8 * 32;
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hf = lane >> 5;
+  for (int i = tid; i < 11 * 32 + 8 * 32 + 8; i += blockDim.x) smem[i] = wpack[WP_VEC + i];
+  __syncthreads();
+  const float w1 = wpack[WP_W1 + lane];
+  constexpr int nside = NPA_TAB_N + 1, per = nside * nside, total = NPA_TAB_LEVELS * per;
+  const int tiles = (total + 31) / 32;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (tid >> 6), nwave = gridDim.x * (blockDim.x >> 6);
+  for (int tile = wave; tile < tiles; tile += nwave) {
+    const int n = tile * 32 + j, nc = n < total ? n : total - 1;
+    const int lvl = nc / per, r = nc - lvl * per, iy = r / nside, ix = r - iy * nside;
+    const float half = wpack[WP_TABH + 2] * (lvl == 0 ? 1.0f : (lvl == 1 ? 4.0f : (lvl == 2 ? 16.0f : 64.0f)));
+    const float step = 2.0f * half / (float)NPA_TAB_N;
+    const float p0x = wpack[WP_TABH] + fmaf(step, (float)ix, -half), p0y = wpack[WP_TABH + 1] + fmaf(step, (float)iy, -half);
+    float me[E];
+    encode_tile_stream<E>(w1, wpack + WP_WLS, vec, w6, b6, p0x, p0y, lane, me);
+    float de = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) de = fmaf(me[e], __fsub_rn(fmaf(P.G[e][0], p0x, __fmul_rn(P.G[e][1], p0y)), P.h[e]), de);
+    if (hf == 0 && n < total) nodes[n] = de - geo_key<E>(P, p0x, p0y);
+  }
+}
+__global__ void geo_table_pack_kernel(const float* __restrict__ nodes, float* __restrict__ wpack) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int N = NPA_TAB_N, nside = N + 1;
+  if (c >= NPA_TAB_LEVELS * N * N) return;
+  const int lvl = c / (N * N), r = c - lvl * N * N, iy = r / N, ix = r - iy * N;
+  const float* nl = nodes + (size_t)lvl * nside * nside;
+  typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+  union { unsigned u; h2_t h; } lo, hi;
+  lo.h[0] = (_Float16)nl[iy * nside + ix]; lo.h[1] = (_Float16)nl[iy * nside + ix + 1];
+  hi.h[0] = (_Float16)nl[(iy + 1) * nside + ix]; hi.h[1] = (_Float16)nl[(iy + 1) * nside + ix + 1];
+  reinterpret_cast<uint2*>(wpack + WP_TAB)[c] = make_uint2(lo.u, hi.u);
+}
+extern "C" hipError_t npa_launch_geo_table(const DevParams& P, float* wpack, float* nodes, int n_cu, hipStream_t stream) {
+  const size_t shmem = (11 * 32 + 8 * 32 + 8) * sizeof(float);
+  const int blocks = n_cu * 4;
+  // (built for the polygon sizes the filter is built for: select_geo_body.inc, TABF)
+#define LAUNCH(EE) hipLaunchKernelGGL((geo_table_nodes_kernel<EE>), dim3(blocks), dim3(256), shmem, stream, P, wpack, nodes)
+  switch (P.E) {
+    case 4: LAUNCH(4); break;
+    case 8: LAUNCH(8); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef LAUNCH
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const int cells = NPA_TAB_LEVELS * NPA_TAB_N * NPA_TAB_N;
+  hipLaunchKernelGGL(geo_table_pack_kernel, dim3((cells + 255) / 256), dim3(256), 0, stream, nodes, wpack);
+  return hipGetLastError();
+}
+// |corrected key - exact distance| per band of the KEY, on nside x nside nodes of one calibration square (not
+// aligned with the table's cells: 4095 steps against 512 cells, the offset inside a cell drifts through every value)
+template <int E>
+__global__ __launch_bounds__(256) void ktab_calib_kernel(DevParams P, const float* __restrict__ wpack, float half, int nside, float inner,
+                                                         float cx, float cy, unsigned* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* vec = smem;
+  float* w6 = vec + 11 * 32;
+  float* b6 = w6 + 8 * 32;
+  unsigned* tab = reinterpret_cast<unsigned*>(b6 + 8);          // [NPA_GEO_BANDS]
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, hf = lane >> 5;
+  for (int i = tid; i < 11 * 32 + 8 * 32 + 8; i += blockDim.x) smem[i] = wpack[WP_VEC + i];
+  for (int i = tid; i < NPA_GEO_BANDS; i += blockDim.x) tab[i] = 0u;
+  __syncthreads();
+  const float w1 = wpack[WP_W1 + lane];
+  const float step = 2.0f * half / (float)(nside - 1);
+  const int tiles_x = nside >> 3, tiles_y = nside >> 2;
+  const long long tiles = (long long)tiles_x * tiles_y;
+  const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (tid >> 6), nwave = (long long)gridDim.x * (blockDim.x >> 6);
+  for (long long tile = wave; tile < tiles; tile += nwave) {
+    const int ix = (int)(tile % tiles_x) * 8 + (j & 7), iy = (int)(tile / tiles_x) * 4 + (j >> 3);
+    const float qx = -half + step * (float)ix, qy = -half + step * (float)iy;        // (relative to the table's centre)
+    const float p0x = cx + qx, p0y = cy + qy;
+    float me[E];
+    encode_tile_stream<E>(w1, wpack + WP_WLS, vec, w6, b6, p0x, p0y, lane, me);
+    float de = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) de = fmaf(me[e], __fsub_rn(fmaf(P.G[e][0], p0x, __fmul_rn(P.G[e][1], p0y)), P.h[e]), de);
+    const float kc = geo_key<E>(P, p0x, p0y) + geo_tab_corr(wpack, p0x, p0y);
+    float f = fabsf(kc - de);
+    if (!(f == f)) f = 3.0e38f;
+    // (per band of the KEY: that is what a wave knows of a point when it looks the margin up)
+    if (hf == 0 && fmaxf(fabsf(qx), fabsf(qy)) >= inner) atomicMax(&tab[npa_geo_band(kc)], __float_as_uint(f));
+  }
+  __syncthreads();
+  for (int i = tid; i < NPA_GEO_BANDS; i += blockDim.x)
+    if (tab[i]) atomicMax(&out[i], tab[i]);
+}
+extern "C" hipError_t npa_launch_ktab_calib(const DevParams& P, const float* wpack, int nside, float half, float inner, float cx, float cy,
+                                            unsigned* out, int n_cu, hipStream_t stream) {
+  const size_t shmem = (11 * 32 + 8 * 32 + 8 + NPA_GEO_BANDS) * sizeof(float);
+  const int blocks = n_cu * 4;
+#define LAUNCH(EE) hipLaunchKernelGGL((ktab_calib_kernel<EE>), dim3(blocks), dim3(256), shmem, stream, P, wpack, half, nside, inner, cx, cy, out)
+  switch (P.E) {
+    case 4: LAUNCH(4); break;
+    case 8: LAUNCH(8); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef LAUNCH
+  return hipGetLastError();
+}
+
 // ---- key-error calibration (npa_create) ------------------------------------------------------------
 // The distance of a point depends on its robot-frame position only, so the error of the reduced-precision key
 // path is a property of the checkpoint: evaluate both encoders on a grid over the square the DUNE models are
@@ -417,9 +528,11 @@ __global__ __launch_bounds__(256) void key_calib_kernel(DevParams P, const float
   float dk = 0.f, de = 0.f;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
+    // (ONE instantiation, E = NPA_MAX_E, serves every polygon: the rows of the output layer beyond P.E are zero in the pack, so
+    // mk / me are 0 there and the sums below are those of the E-sized loop, term by term)
     const float tmp = __fsub_rn(fmaf(P.G[e][0], p0x, __fmul_rn(P.G[e][1], p0y)), P.h[e]);
-    dk = fmaf(mk[e], tmp, dk);
-    de = fmaf(me[e], tmp, de);
+    dk = e < P.E ? fmaf(mk[e], tmp, dk) : dk;
+    de = e < P.E ? fmaf(me[e], tmp, de) : de;
   }
   float rel = fabsf(dk - de) / (1.0f + fabsf(de));
   if (!(rel == rel)) rel = 1e30f;                            // NaN anywhere disqualifies the mode
@@ -436,15 +549,8 @@ extern "C" hipError_t npa_launch_key_calib(const DevParams& P, const float* wpac
     if (key_terms == 1) hipLaunchKernelGGL((key_calib_kernel<EE, 1>), dim3(blocks), dim3(256), shmem, stream, P, wpack, lo, step, nside, out); \
     else hipLaunchKernelGGL((key_calib_kernel<EE, 3>), dim3(blocks), dim3(256), shmem, stream, P, wpack, lo, step, nside, out); \
   } while (0)
-  switch (P.E) {
-    case 3: LAUNCH(3); break;
-    case 4: LAUNCH(4); break;
-    case 5: LAUNCH(5); break;
-    case 6: LAUNCH(6); break;
-    case 7: LAUNCH(7); break;
-    case 8: LAUNCH(8); break;
-    default: return hipErrorInvalidValue;
-  }
+  if (P.E < 3 || P.E > NPA_MAX_E) return hipErrorInvalidValue;
+  LAUNCH(NPA_MAX_E);
 #undef LAUNCH
   return hipGetLastError();
 }

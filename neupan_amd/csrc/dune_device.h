@@ -978,6 +978,29 @@ __device__ __forceinline__ float geo_key(const DevParams& P, float x, float y) {
   return P.geo_rect ? geo_key_t<E, true>(P, x, y) : geo_key_t<E, false>(P, x, y);
 }
 
+// correction of the geometric key from the table behind the weight pack (pan_common.h, WP_TAB): bilinear in the cell of the
+// finest level whose square holds the point; ONE 8-byte gather (the cell's four corners as fp16) + ~25 VALU instructions.
+// Points outside the largest square take its border cell (their keys are "far": always candidates, whatever this returns).
+__device__ __forceinline__ float geo_tab_corr(const float* __restrict__ wpack, float x, float y) {
+  const float cx = wpack[WP_TABH], cy = wpack[WP_TABH + 1], h0 = wpack[WP_TABH + 2], inv0 = wpack[WP_TABH + 3];     // (wave-uniform)
+  const float rx = x - cx, ry = y - cy;
+  const float a = fmaxf(fabsf(rx), fabsf(ry));
+  const int lvl = a < h0 ? 0 : (a < 4.0f * h0 ? 1 : (a < 16.0f * h0 ? 2 : 3));
+  const float sc = lvl == 0 ? 1.0f : (lvl == 1 ? 4.0f : (lvl == 2 ? 16.0f : 64.0f));
+  const float half = h0 * sc, inv = inv0 * (1.0f / sc);
+  const float fx = fminf(fmaxf((rx + half) * inv, 0.f), (float)NPA_TAB_N - 0.001f);
+  const float fy = fminf(fmaxf((ry + half) * inv, 0.f), (float)NPA_TAB_N - 0.001f);
+  const int ix = (int)fx, iy = (int)fy;
+  const float tx = fx - (float)ix, ty = fy - (float)iy;
+  const uint2 c = reinterpret_cast<const uint2*>(wpack + WP_TAB)[((size_t)lvl * NPA_TAB_N + iy) * NPA_TAB_N + ix];
+  typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+  union { unsigned u; h2_t h; } lo, hi;
+  lo.u = c.x; hi.u = c.y;                                      // (f(ix, iy), f(ix+1, iy)) , (f(ix, iy+1), f(ix+1, iy+1))
+  const float f00 = (float)lo.h[0], f10 = (float)lo.h[1], f01 = (float)hi.h[0], f11 = (float)hi.h[1];
+  const float r0 = fmaf(tx, f10 - f00, f00), r1 = fmaf(tx, f11 - f01, f01);
+  return fmaf(ty, r1 - r0, r0);
+}
+
 #define SEL2_TRIP 256                            // points per trip of the key pass (4 per lane)
 // key pass of select_geo_kernel: dkey[n] = bits of g(point n) (0xFFFFFFFF behind the slice's end); returns the lane's
 // smallest key.  The wave-uniform cases (box or polygon, moving points, decimation) are template parameters: inside

@@ -42,10 +42,12 @@ struct DevParams {
   float geo_rcal;             // half extent of the square (robot frame) over which the geometric key's error was measured
   float geo_far;              // geo_rcal - (largest vertex radius): a point with a smaller geometric distance lies inside that square
   // the common case -- an axis-aligned rectangle in the robot frame (robot.py:342-375 builds length x width boxes) --
-  // has a cheaper closed form: centre, half extents; geo_rect != 0 selects it
+  // has a cheaper closed form: centre, half extents; geo_rect != 0 selects it.  Any other polygon: rc / rh describe its
+  // bounding box (the key pass of select_geo_kernel ranks on the distance to it, pan_common.h WP_TABH[4])
   int geo_rect;
   float rcx, rcy, rhx, rhy;
   int qp_aset;                // (experiments build only: the QP's warm solves try the active-set iteration first, NPA_QP_ASET)
+  int geo_tab;                // the weight pack carries the correction table of the geometric key (WP_TAB) and its margins (WP_KTAB)
 };
 
 // ---- merged launches of a GROUP of forward calls (npa_forward_batch_group, c_api.hip) --------------------------------
@@ -130,7 +132,28 @@ __host__ __device__ inline int npa_geo_band(float g) {
 // the bf16 KEY tier (NPA_KEYS_PRECISION=bf16): margin per band of the EXACT distance for |bf16-encoder distance - exact distance|,
 // measured at creation (k16_calib_kernel); +inf = uncalibrated
 #define WP_K16 (WP_WB16 + WP_WB16_FLOATS)
-#define WP_TOTAL (WP_K16 + ((NPA_GEO_BANDS + 3) & ~3))
+// the TABLE-corrected geometric key (select_geo_kernel's second-stage filter of a long candidate list): f(p) = network distance
+// - geometric distance is a smooth function of the robot-frame position p, so it is TABULATED at creation (geo_table_kernel:
+// the exact encoder at the nodes of four nested 512 x 512-cell squares, half extents 2 / 8 / 32 / 128 m, cells of 8 / 31 / 125 / 500 mm;
+// a cell = its four corner values as fp16, ONE 8-byte gather per point) and g(p) + bilinear f(p) is a key whose error is what
+// the interpolation leaves (the network has creases -- ReLU, LayerNorm -- and a bilinear cell across one is off by ~ cell x
+// slope jump / 4: the finest cells sit where the M nearest points of a dense cloud are) -- millimetres, not the centimetres of g.  WP_KTAB: margin per band of the KEY for
+// |corrected key - exact distance| (ktab_calib_kernel on 4096 x 4096 nodes per square, not aligned with the cells; +inf =
+// uncalibrated).  The table itself follows the pack in the same device allocation (WP_TAB: not part of the host image).
+#define WP_KTAB (WP_K16 + ((NPA_GEO_BANDS + 3) & ~3))
+// header of the table: centre (x, y) of its squares = the centre of the polygon's bounding box, half extent h0 of level 0
+// (>= NPA_TAB_HALF0, and 1.25 x the box: a 4.6 m car is covered by the finest cells nose to tail), cells per metre of level 0
+// [4]: S, the slack of the key pass's BOX key for a polygon that is not an axis-aligned box (0 for one that is): the key pass
+// ranks every point on the distance to the polygon's bounding box -- 8 instructions instead of 12 per edge -- which is a lower
+// bound of the distance g to the polygon with g <= box distance + S, S = the largest g over the box's corners (g is convex)
+#define WP_TABH (WP_KTAB + ((NPA_GEO_BANDS + 3) & ~3))
+#define WP_TOTAL (WP_TABH + 8)
+#define NPA_TAB_KEY_FAR 0xFFFFFFFDu                // filter key of a point beyond the calibrated square (above every ordered_key of a number)
+#define NPA_TAB_N 512                             // cells per side of one level
+#define NPA_TAB_LEVELS 4
+#define NPA_TAB_HALF0 2.0f                        // smallest half extent of level 0; level l: x 4^l (2 / 8 / 32 / 128 m: cells of 8 / 31 / 125 / 500 mm)
+#define WP_TAB ((WP_TOTAL + 3) & ~3)              // [levels][N][N] cells of 4 x fp16 (2 floats each)
+#define WP_TAB_FLOATS (NPA_TAB_LEVELS * NPA_TAB_N * NPA_TAB_N * 2)
 // order of the per-feature vectors
 enum { V_B1 = 0, V_G1, V_BE1, V_B2, V_B3, V_G2, V_BE2, V_B4, V_B5, V_G3, V_BE3 };
 

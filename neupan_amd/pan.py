@@ -694,10 +694,10 @@ class PAN(torch.nn.Module):
         """What npa_create measured about the geometric distance keys of this checkpoint (npa_geo_report)."""
         if self.no_obs:
             return None
-        v = (C.c_float * 8)()
-        check(self._lib.npa_geo_report(self._h, v, 8), "npa_geo_report")
+        v = (C.c_float * 10)()
+        check(self._lib.npa_geo_report(self._h, v, 10), "npa_geo_report")
         return dict(polygon_ok=bool(v[0]), measured_error=v[1], margin=v[2], refine_ratio=v[3], slope_estimate=v[4], g_far=v[5],
-                    bf16_key_error=v[6], bf16_key_margin=v[7])
+                    bf16_key_error=v[6], bf16_key_margin=v[7], table_key_error=v[8], table_key_margin=v[9])
 
     def audit(self, reset=False):
         """Run-time audit counters of the geometric-key margin (npa_audit_read; synchronises the device):

@@ -784,6 +784,54 @@ def test_bf16_key_tier_emits_the_exact_rows(cfgname, B):
         assert share[2] + share[3] > 0.2, share       # (the dense cloud's long lists do go through the filter)
 
 
+@pytest.mark.parametrize("cfgname,B", [("poly8_5k_T10_K10", 24), ("dyna_4k_T10_K10", 24), ("acker_2k_T20_K15", 24), ("diff_1k_T10_K10", 48)])
+def test_table_key_filter_emits_the_exact_rows(cfgname, B):
+    """The second-stage filter of the default selection (round 5): a candidate list longer than one encoder tile is ranked on the
+    TABLE-corrected geometric key g(p) + f_table(p) -- f = network distance - geometric distance tabulated at creation on four
+    nested 512 x 512-cell squares, bilinear, one 8-byte gather per point -- whose error is what interpolation leaves (measured
+    per band of the key at creation, audited on every survivor at run time); only the points that can still be among the M
+    nearest are encoded exactly.  Rows and controls must be BITWISE those of a handle without the table (NPA_GEO_TABLE=0) and of
+    the exact-key build, on the dense clouds (where nearly every slice goes through the filter), walls / blobs (all-slice lists,
+    points inside the polygon) and far clouds (points beyond the calibrated square survive unconditionally); no audit violation."""
+    import torch
+    from gpu_helpers import make_gpu_pan, wall_batch
+    cfg = CONFIGS[cfgname]
+    tab = make_gpu_pan(cfg)
+    rep = tab.geo_report()
+    print(cfgname, "table key error", rep["table_key_error"], "margin", rep["table_key_margin"], "geometric", rep["measured_error"], rep["margin"])
+    assert 0 < rep["table_key_error"] < rep["measured_error"] and rep["table_key_margin"] >= rep["table_key_error"]
+    notab = _with_env({"NPA_GEO_TABLE": "0"}, lambda: make_gpu_pan(cfg))
+    assert notab.geo_report()["table_key_margin"] == 0.0
+    exact = _with_env({"NPA_DUNE_FP32KEYS": "1"}, lambda: make_gpu_pan(cfg))
+    batches = [make_batch(cfg, 23000, B)]
+    if cfgname.startswith("diff"):
+        batches.append(wall_batch(cfg, B))
+    far = dict(batches[0])
+    far["points"] = (np.asarray(batches[0]["points"]) * np.float32(20.0)).copy()        # most of the cloud beyond 128 m
+    batches.append(far)
+    dbg = _with_env({"NPA_SEL_DEBUG": "1"}, lambda: make_gpu_pan(cfg))
+    c = _stage_np(dbg, batches[0])["count"]
+    fb, nc = c >> 16, (c >> 8) & 0xFF
+    share = {v: float((fb == v).mean()) for v in (0, 1, 2, 3)}
+    print(cfgname, "slices: one tile, no filter %.3f | exact keys for the list %.3f | filter shortened the list %.3f | filter decided %.3f; "
+          "lists longer than a tile %.3f" % (share[0], share[1], share[2], share[3], float((nc > 32).mean())))
+    # the filter takes (nearly) every list that is longer than one tile, and decides most of them
+    assert share[2] + share[3] >= 0.95 * float((nc > 32).mean()) - 1e-9, share
+    assert share[3] >= 0.5 * float((nc > 32).mean()) - 1e-9, share
+    for bi, batch in enumerate(batches):
+        kw = {"n_points": batch["n_points"]} if batch.get("n_points") is not None else {}
+        a, b, e = _stage_np(tab, batch, **kw), _stage_np(notab, batch, **kw), _stage_np(exact, batch, **kw)
+        for k in ("mu", "lam", "pts", "dist", "count"):
+            assert np.array_equal(a[k], b[k]), (cfgname, bi, k, "vs no table")
+            assert np.array_equal(a[k], e[k]), (cfgname, bi, k, "vs exact keys")
+        args = [batch[k] for k in ("nom_s", "nom_u", "ref_s", "ref_us", "points")] + [batch.get("velocities"), batch.get("n_points")]
+        tab.reset_stop_state(); notab.reset_stop_state()
+        oa, ob = tab.forward_batch(*args), notab.forward_batch(*args)
+        for k in ("opt_u", "opt_s", "opt_d", "min_distance", "iters"):
+            assert np.array_equal(oa[k].cpu().numpy(), ob[k].cpu().numpy(), equal_nan=True), (cfgname, bi, k)
+    assert tab.audit()["violations"] == 0, tab.audit()
+
+
 def test_self_test_outcomes_of_the_shipped_configurations():
     """npa_create's self-test hard-fails only on non-determinism or non-finite / out-of-box controls; warm-vs-cold and
     geometric-vs-exact disagreements are soft (npa_selftest_flags).  None of the benchmark configurations trips either."""

@@ -35,10 +35,15 @@ for name, B in (("diff_1k_T10_K10", 256), ("acker_2k_T20_K15", 32), ("dyna_4k_T1
     pan, dt = mk(cfg)
     exact, _ = mk(cfg, {"NPA_DUNE_FP32KEYS": "1"})
     print(name, "key_mode", pan.key_mode(), "create %.3f s" % dt, flush=True)
+    gr = pan.geo_report()
+    print("   geometric key: error %.4f margin %.4f m | table-corrected key: error %.2e margin %.2e m" %
+          (gr["measured_error"], gr["margin"], gr["table_key_error"], gr["table_key_margin"]), flush=True)
+    notab, _ = mk(cfg, {"NPA_GEO_TABLE": "0"})
     batch = make_batch(cfg, 1000, B)
     a = pan.dune_stage(batch["nom_s"], batch["points"], batch.get("velocities"))
     b = exact.dune_stage(batch["nom_s"], batch["points"], batch.get("velocities"))
-    print("   bench scenes bitwise equal to exact keys:", same(a, b))
+    print("   bench scenes bitwise equal to exact keys:", same(a, b), "| to the handle without the table:",
+          same(a, notab.dune_stage(batch["nom_s"], batch["points"], batch.get("velocities"))))
     if pan.key_mode()["key_terms"] != 4:
         geo, _ = mk(cfg, {"NPA_KEY_TERMS": "4"})
         print("   forced geometric:", geo.key_mode(), "bitwise:", same(geo.dune_stage(batch["nom_s"], batch["points"], batch.get("velocities")), b))
@@ -59,10 +64,12 @@ for name, B in (("diff_1k_T10_K10", 256), ("acker_2k_T20_K15", 32), ("dyna_4k_T1
     c = dbg.dune_stage(batch["nom_s"], batch["points"], batch.get("velocities"))["count"].cpu().numpy()
     del os.environ["NPA_SEL_DEBUG"]
     nc, fb = (c >> 8) & 0xFF, c >> 16
-    print("   candidates per slice: median %d mean %.1f p90 %d max %d; >32: %.3f; overflow: %.4f" %
-          (np.median(nc), nc.mean(), np.quantile(nc, 0.9), nc.max(), (nc > 32).mean(), fb.mean()))
+    print("   candidates per slice: median %d mean %.1f p90 %d max %d; >32: %.3f; decided by the table filter: %.4f; shortened by it, then "
+          "exact keys: %.4f; exact keys for the whole list: %.4f" %
+          (np.median(nc), nc.mean(), np.quantile(nc, 0.9), nc.max(), (nc > 32).mean(), (fb == 3).mean(), (fb == 2).mean(), (fb == 1).mean()))
+    print("   audit after all of the above:", pan.audit(), flush=True)
     # stage timing
-    for p, tag in ((pan, "default"), (exact, "exact keys")):
+    for p, tag in ((pan, "default"), (notab, "NPA_GEO_TABLE=0"), (exact, "exact keys")):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(20):
             p.dune_stage(batch["nom_s"], batch["points"], batch.get("velocities"))
