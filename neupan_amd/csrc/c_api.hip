@@ -839,6 +839,8 @@ extern "C" int npa_use_network_keys(npa_handle* h) {
   hipError_t e = hipDeviceSynchronize();
   if (e == hipSuccess) e = calibrate_network_keys(h, -1);
   if (e == hipSuccess) e = audit_block_reset(h);
+  // (the reduced-precision tiers belong to the geometric selection: a handle on network keys emits exact fp32 rows, and says so)
+  if (e == hipSuccess) { h->rows_bf16 = false; h->keys_bf16 = false; }
   if (cur != h->device) (void)hipSetDevice(cur);
   HIP_TRY(e);
   h->stats_mark = 0; h->tiles_window = 0; h->calls_window = 0; h->hold = 0;

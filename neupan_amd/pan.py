@@ -370,7 +370,8 @@ class PAN(torch.nn.Module):
         with torch.cuda.device(self.device):
             try:
                 # 1: the loop went out as one launch (a handle created with NPA_SCENE_KERNEL=1, and the call qualifies)
-                whole = lib.npa_forward_scene(h, 0) if self._scene_kernel else 0
+                # (self.iter_num, not the handle's creation-time K: the reference's PAN.iter_num is an attribute callers may lower)
+                whole = lib.npa_forward_scene(h, int(self.iter_num)) if self._scene_kernel else 0
                 if whole < 0:
                     check(whole, "npa_forward_scene")
                 for k in range(0 if whole == 1 else self.iter_num):
