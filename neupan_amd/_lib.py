@@ -10,7 +10,9 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libneupan_amd.so")
+# (NPA_LIB_PATH: a variant build of the same library -- the experiments build, a profiling build -- for tools and tests; there is
+# no fallback of any kind: whichever path is named must exist and export every symbol of include/neupan_amd.h)
+LIB_PATH = os.environ.get("NPA_LIB_PATH") or os.path.join(HERE, "libneupan_amd.so")
 
 NPA_MAX_T, NPA_MAX_M, NPA_MAX_E = 21, 32, 8
 KIN = {"diff": 0, "acker": 1, "omni": 2}

@@ -160,6 +160,46 @@ def test_hot_kernels_have_no_spills_and_no_scratch():
         assert not any("pan_scene_kernel" in n or "select_scene_kernel" in n or "aset" in n for n in res), "experiment kernels in the product build"
         assert os.path.getsize(kr.LIB) < 2 * 1024 * 1024, os.path.getsize(kr.LIB)
 
+def test_no_kernel_has_instructions_that_only_run_with_exec_zero():
+    """The root cause of the register-starved-build hazard (rounds 2 - 4: corrupted loop scalars in spilled QP builds, the
+    faulting two-waves-per-SIMD scene kernel), found in round 5 under rocgdb: hipcc 7.2's register allocator puts live-range
+    split copies and spill stores at the top of the block behind a divergent loop, in FRONT of the s_or_b64 that restores
+    EXEC -- they execute with EXEC == 0, do nothing, and the restores behind the region bring back stale values
+    (tests/tools/hw/README.md, profiles/r05_spilled_build_fault.txt).  Whether a build has such instructions is a static
+    property of its machine code (tests/tools/kernel_resources.exec_zero_dead: a must-analysis of EXEC == 0 over the control
+    flow): the product library must have none, in ANY kernel.  (The analysis is also unit-tested on a hand-written block.)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import kernel_resources as kr
+    # the analysis itself: a divergent loop, then a copy and a spill store in front of the EXEC restore -- and a clean variant
+    def block(after_loop):
+        text = ["v_mov_b32_e32 v1, v2", "s_and_saveexec_b64 s[6:7], vcc", "s_cbranch_execz L_join",
+                "L_loop:", "ds_write_b64 v6, v[8:9]", "s_andn2_b64 exec, exec, s[20:21]", "s_cbranch_execnz L_loop",
+                "L_join:"] + after_loop + ["v_add_f32_e32 v3, v1, v1", "s_endpgm"]
+        labels, ins, a = {}, [], 0x100
+        for t in text:
+            if t.endswith(":"):
+                labels[t[:-1]] = a
+            else:
+                a += 4
+        a = 0x100
+        for t in text:
+            if t.endswith(":"):
+                continue
+            mn, _, ops = t.partition(" ")
+            tgt = labels[ops] - 0x100 if ops in labels else None
+            ins.append((mn, ops, a, tgt))
+            a += 4
+        return ins
+    bad = kr.exec_zero_dead(block(["v_writelane_b32 v254, s24, 21", "v_mov_b32_e32 v142, v136", "scratch_store_dwordx2 off, v[154:155], off offset:32",
+                                   "s_or_b64 exec, exec, s[6:7]"]))
+    assert [b[1].split()[0] for b in bad] == ["v_mov_b32_e32", "scratch_store_dwordx2"], bad          # (v_writelane ignores EXEC: fine)
+    assert kr.exec_zero_dead(block(["s_or_b64 exec, exec, s[6:7]", "v_mov_b32_e32 v142, v136"])) == []
+    if not kr.tools_available():
+        pytest.skip("ROCm LLVM tools not installed")
+    lost = kr.lost_instructions()
+    assert lost == {}, {k: v[:4] for k, v in lost.items()}
+
+
 def test_build_refuses_an_unvalidated_compiler(monkeypatch):
     """neupan_amd.build fails (not warns) on a hipcc other than the validated one unless NPA_ALLOW_UNVALIDATED=1."""
     from neupan_amd import build as b

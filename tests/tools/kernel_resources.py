@@ -121,6 +121,86 @@ def kernel_isa_hashes(lib=LIB):
     return out
 
 
+# ---- instructions that can only execute with EXEC == 0 -----------------------------------------------------------------------
+# Root cause of the "register-starved build" hazard of rounds 2 - 4 (DESIGN.md section 7; tests/tools/hw/README.md): in a build
+# that spills, hipcc 7.2's register allocator places live-range split copies and spill stores at the top of the block that
+# FOLLOWS a divergent loop -- in front of the s_or_b64 that gives EXEC back.  On both ways into that block (the loop's exit: the
+# s_cbranch_execnz back edge not taken; the s_cbranch_execz that skips the loop) EXEC is zero, so the copies and stores do
+# nothing, and the reloads / restores behind the region bring back whatever the register or the scratch slot held before.  In
+# round 4's two-waves-per-SIMD scene kernel that was `v_mov_b32 v142, v136` (a loop-invariant row offset parked while v136 served
+# as a temporary): the restore handed every later hinge-row load the constant v142 held (0x19f4ec90 x 4 bytes past the buffer).
+# The check below finds such instructions in any build: a must-analysis over the kernel's control flow (EXEC is known to be
+# zero on the fall-through edge of s_cbranch_execnz and on the taken edge of s_cbranch_execz, until an instruction writes EXEC);
+# a vector ALU / memory instruction reached ONLY with EXEC == 0 is lost work the compiler cannot have meant.
+_LANE = ("v_readlane", "v_writelane", "v_readfirstlane")
+
+
+def _parse_disassembly(lines):
+    ins = []
+    for l in lines:
+        m = re.match(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):\s*[0-9A-Fa-f ]+(?:<.*\+0x([0-9a-f]+)>)?", l)
+        if m:
+            ins.append((m.group(1), m.group(2), int(m.group(3), 16), int(m.group(4), 16) if m.group(4) else None))
+    return ins
+
+
+def exec_zero_dead(ins):
+    """[(offset in the kernel, instruction)] of the vector instructions of one kernel that are reached only with EXEC == 0.
+    ins: (mnemonic, operands, address, branch target offset or None) per instruction, in address order."""
+    n = len(ins)
+    if not n:
+        return []
+    base = ins[0][2]
+    idx = {a: i for i, (_, _, a, _) in enumerate(ins)}
+    preds = [[] for _ in range(n)]
+    for j, (mn, ops, a, t) in enumerate(ins):
+        if (mn.startswith("s_cbranch") or mn == "s_branch") and t is not None and base + t in idx:
+            preds[idx[base + t]].append(("br", j))
+        if j + 1 < n and mn not in ("s_branch", "s_endpgm", "s_setpc_b64"):
+            preds[j + 1].append(("ft", j))
+    st = [True] * n
+    st[0] = False
+
+    def out(kind, j):
+        mn, ops = ins[j][0], ins[j][1]
+        if kind == "br":
+            return True if mn == "s_cbranch_execz" else (False if mn == "s_cbranch_execnz" else st[j])
+        if mn == "s_cbranch_execnz":
+            return True
+        if mn == "s_cbranch_execz" or "saveexec" in mn or (mn.startswith("s_") and re.match(r"\s*exec\b", ops)):
+            return False
+        return st[j]
+    changed = True
+    while changed:
+        changed = False
+        for i in range(1, n):
+            v = all(out(k, j) for k, j in preds[i]) if preds[i] else False
+            if v != st[i]:
+                st[i], changed = v, True
+    return [("%x" % (a - base), (mn + " " + ops).strip()) for i, (mn, ops, a, t) in enumerate(ins)
+            if st[i] and ((mn.startswith("v_") and not mn.startswith(_LANE)) or mn.startswith(("scratch_", "global_", "buffer_", "flat_", "ds_")))]
+
+
+def lost_instructions(lib=LIB):
+    """{kernel symbol: [(offset, instruction)]} over every kernel of the library that has instructions reachable only with EXEC == 0."""
+    hits = {}
+    with tempfile.TemporaryDirectory() as d:
+        for co in _code_objects(lib, d):
+            text = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], stdout=subprocess.PIPE, text=True).stdout
+            cur, block = None, []
+            for l in text.splitlines() + ["0 <end>:"]:
+                m = re.match(r"^[0-9a-f]+ <(.+)>:", l)
+                if m:
+                    if cur:
+                        bad = exec_zero_dead(_parse_disassembly(block))
+                        if bad:
+                            hits[cur] = bad
+                    cur, block = m.group(1), []
+                else:
+                    block.append(l)
+    return hits
+
+
 def demangle(name):
     try:
         return subprocess.run([os.path.join(LLVM, "llvm-cxxfilt"), name], stdout=subprocess.PIPE, text=True).stdout.strip().split("(")[0]
@@ -129,6 +209,15 @@ def demangle(name):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--lost":         # python tests/tools/kernel_resources.py --lost [library ...]
+        for lib in sys.argv[2:] or [LIB]:
+            h = lost_instructions(lib)
+            print(lib, "-- kernels with vector instructions that can only execute under EXEC = 0:", len(h))
+            for k, v in h.items():
+                print("  ", demangle(k)[:80], len(v))
+                for x in v[:10]:
+                    print("       ", x)
+        sys.exit(0)
     pat = sys.argv[1] if len(sys.argv) > 1 else ""
     res = kernel_resources()
     print(f"{'kernel':70s} vgpr agpr sgpr vspill sspill scratch lds")

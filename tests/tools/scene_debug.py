@@ -1,5 +1,6 @@
 """Debugging aid of the scene kernel (csrc/pan_scene.hip): the two-launch path against NPA_SCENE_KERNEL=1 on one batch, printing
-where they differ instead of asserting.  `--lib=<path>` loads a variant library, `--k=<n>` limits the PAN iterations."""
+where they differ instead of asserting.  `--lib=<path>` loads a variant library, `--k=<n>` limits the PAN iterations, `--cfg=<name>`
+picks the configuration (default diff_1k_T10_K10), `--b=<n>` the batch."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -13,7 +14,7 @@ B = next((int(a[4:]) for a in sys.argv[1:] if a.startswith("--b=")), 96)
 from gpu_helpers import make_gpu_pan
 from helpers import CONFIGS
 from neupan_amd.scenes import make_batch
-cfg = CONFIGS["diff_1k_T10_K10"]
+cfg = CONFIGS[next((a[6:] for a in sys.argv[1:] if a.startswith("--cfg=")), "diff_1k_T10_K10")]
 over = dict(iter_num=K) if K else {}
 two = make_gpu_pan(cfg, **over)
 os.environ["NPA_SCENE_KERNEL"] = "1"
