@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# scratch trees of the hardware repros (tests/tools/hw/README.md builds variant libraries, and once unpacked a whole older tree,
+# under tests/tools/hw/_*): never collected -- a second tests/test_abi.py in there once broke the collection of `pytest tests`
+collect_ignore_glob = ["tools/hw/_*"]
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "experiments: needs the experiments build of the library (NPA_EXPERIMENTS=1 python -m "
