@@ -508,6 +508,8 @@ def compact(line, full_path):
                                 "valu_issue_frac_alone", "lds_bank_conflict_frac", "algorithmic_bytes_per_launch")}
     if r.get("chip_aggregate"):
         ro["chip_aggregate"] = r["chip_aggregate"]
+    if r.get("vector_pipe"):
+        ro["vector_pipe"] = {k: r["vector_pipe"][k] for k in ("simd_cycles_per_plan", "bound_plans_per_s", "frac")}
     if r.get("pmc"):
         pk = r["pmc"].get("per_kernel", {})
         ro["pmc"] = {"file": r["pmc"].get("file"), "current": {k: v.get("current") for k, v in pk.items()}}
@@ -744,6 +746,26 @@ def main():
                           "valu_issue_frac_alone": ks.get("valu_issue_frac"), "mfma_busy_frac_alone": ks.get("mfma_busy_frac"),
                           "traffic": int(ks["hbm_bytes_per_launch"] * spl / ks_spl),
                           "algorithmic_bytes_per_launch": int(spl * (8 * N * (2 if lp.args[0][5] is not None else 1) + 400))}
+    # the loop as a whole against the chip's vector pipes: SIMD-cycles the two kernels keep a SIMD's VALU or MFMA pipe busy per
+    # plan (PMC: 4 x SQ_ACTIVE_INST_VALU quad-cycles + SQ_VALU_MFMA_BUSY_CYCLES per launch, alone on the chip; fp32 MFMA and VALU
+    # do not co-execute on gfx950) -> the rate at which 1024 SIMDs at 2.4 GHz would run THIS instruction mix with no idle cycle
+    if pmc and km["key_terms"] == 4:
+        def pipe_cycles(name):
+            k_ = pmc["kernels"].get(name)
+            c_ = (k_ or {}).get("counters", {})
+            if "SQ_ACTIVE_INST_VALU" not in c_:
+                return None
+            return (4.0 * c_["SQ_ACTIVE_INST_VALU"] + c_.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)) / k_.get("scenes_per_launch", pmc["scenes_per_launch"])
+        pc_sel = pipe_cycles(sel_name) or pipe_cycles("select_geo_kernel")
+        pc_qp = pipe_cycles(qp_name) or pipe_cycles("nrmp_qp_kernel")
+        pc_st = pipe_cycles("stage_group_kernel" if lp.chains else "stage_kernel") or 0.0
+        if pc_sel and pc_qp and args.workload == WORKLOAD:
+            per_plan = K * (pc_sel + pc_qp) + pc_st
+            bound = N_SIMD * 2.4e9 / per_plan
+            roof["vector_pipe"] = {"simd_cycles_per_plan": int(per_plan), "selection_share": round(K * pc_sel / per_plan, 3),
+                                   "bound_plans_per_s": int(bound), "frac": round(value / world / bound, 4),
+                                   "note": "VALU + MFMA busy SIMD-cycles of selection, QP and staging per plan (PMC, kernels alone) -> plans/s "
+                                           "of 1024 SIMDs at 2.4 GHz with no idle cycle; frac = this run's rate per GPU over it"}
     roof["note"] = ("dominant kernel by GPU time = the QP (fp64 Mehrotra IPM, one wave per scene, serial chain: latency / VALU-issue "
                     "bound).  achieved = (interior-point iterations per launch, measured on the device in this run) x (fp64 flops per "
                     "iteration) + solves x (fixed flops per solve), the two per-unit figures from PMC counts at two operating points "
