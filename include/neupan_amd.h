@@ -145,6 +145,15 @@ int npa_use_network_keys(npa_handle *h);
 #define NPA_SELFTEST_GEO_REJECTED 2
 int npa_selftest_flags(const npa_handle *h, int *flags);
 
+/* Handles of the same checkpoint, polygon, calibration knobs and device SHARE what npa_create derives from the checkpoint: the
+ * repacked weights, the margins of the geometric key, the 8.4 MB key table and its margins (the reference loads one model per
+ * planner, dune.py:131-144; a serving process makes one handle per batch in flight).  The first npa_create of a key measures
+ * (ten calibration launches, ~35 ms), the later ones take the device buffer and the figures and run only their self-test.  The
+ * buffer lives as long as a handle uses it.  Everything a handle can change stays its own: the key mode in force
+ * (npa_use_network_keys), audit counters, statistics, self-test outcomes.  This reports, for the process: packs calibrated,
+ * creations that shared one, packs alive now.  NPA_PACK_CACHE=0 in the environment gives every handle a private pack. */
+int npa_pack_cache_stats(int64_t *calibrations, int64_t *shared_creates, int64_t *alive);
+
 /* Replaces NRMP.update_adjust_parameters_value (nrmp.py:170-217). */
 int npa_set_adjust(npa_handle *h, const float q_s[3], float p_u, float eta, float d_max, float d_min);
 

@@ -55,6 +55,7 @@ SYMBOLS = {
     "npa_audit_peek": (_I, [_P, C.POINTER(C.c_uint64)]),
     "npa_use_network_keys": (_I, [_P]),
     "npa_selftest_flags": (_I, [_P, C.POINTER(C.c_int)]),
+    "npa_pack_cache_stats": (_I, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "npa_set_adjust": (_I, [_P, C.POINTER(C.c_float * 3), C.c_float, C.c_float, C.c_float, C.c_float]),
     "npa_workspace_bytes": (_SZ, [_P, _I]),
     "npa_state_bytes": (_SZ, [_P, _I]),

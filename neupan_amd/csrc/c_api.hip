@@ -3,11 +3,14 @@
 #include "../../include/neupan_amd.h"
 #include "pan_common.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -108,7 +111,42 @@ struct PendingCall {
   bool reset_state = false;
 };
 
+// ---- one weight pack, one calibration and one key table per (checkpoint, polygon, knobs, device) per PROCESS -----------------
+// The reference loads one model per planner (dune.py:131-144); a serving process makes tens of handles of the SAME checkpoint
+// (one per batch in flight).  What npa_create derives from the checkpoint -- the repacked weights, the margins of the geometric
+// key (6 x geo_calib_kernel), the 8.4 MB key table and its margins (4 x ktab_calib_kernel), the bf16 key margins -- is read-only
+// after creation and a pure function of (the host image of the pack, E / G / h, the calibration knobs of the environment, the
+// device): handles with the same key SHARE the device buffer and the measured figures.  The cache holds weak references: the
+// buffer lives as long as a handle uses it.  Per handle: the audit block, statistics, the self-test and its outcomes, the key
+// mode in force (npa_use_network_keys switches ONE handle).  NPA_PACK_CACHE=0 gives every handle a private pack (tests).
+struct SharedPack {
+  float* wpack = nullptr;
+  int device = 0;
+  // the figures the calibration leaves in the handle / its DevParams
+  int key_terms = 0;
+  float key_err = 0.f, key_e0 = 0.f;
+  bool key_auto = false;
+  float e0_mode[2] = {0.f, 0.f}, err_mode[2] = {0.f, 0.f};
+  float geo_err = 0.f, geo_margin = 0.f, geo_refine = 0.f, geo_slope = 0.f, geo_rcal = 0.f, geo_far = 0.f;
+  int geo_tab = 0;
+  float ktab_err = 0.f, ktab_margin = 0.f;
+  bool keys_bf16 = false;
+  float k16_err = 0.f, k16_margin = 0.f;
+  ~SharedPack() {
+    if (!wpack) return;
+    int cur = -1;
+    const bool sw = hipGetDevice(&cur) == hipSuccess && cur != device;
+    if (sw) (void)hipSetDevice(device);
+    (void)hipFree(wpack);
+    if (sw) (void)hipSetDevice(cur);
+  }
+};
+static std::mutex g_pack_mu;                                   // held across a creation's calibration: same-key creates queue up
+static std::map<std::string, std::weak_ptr<SharedPack>> g_packs;
+static long long g_pack_calibrations = 0, g_pack_hits = 0;     // (npa_pack_cache_stats)
+
 struct npa_handle {
+  std::shared_ptr<SharedPack> pack;     // owns wpack (possibly with other handles)
   PendingCall pc;
   std::mutex mu;              // guards pc (two threads on ONE handle are a caller's bug; this makes it an error, not a race)
   DevParams P;
@@ -381,6 +419,24 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
       memcpy(&pack[WP_W6 + e * 32], w->lin_w[5] + e * 32, 32 * sizeof(float));
       pack[WP_B6 + e] = w->lin_b[5][e];
     }
+    // the 16-point tile's images (pan_common.h, WP_W116): row i of block mb of a layer's A-fragments is output feature
+    // npa_feat16(4 mb + (i & 3), i >> 2), K entry (s, kq) is input feature npa_feat16(s, kq)
+    {
+      auto fo = [](int mb, int row) { return npa_feat16(4 * mb + (row & 3), row >> 2); };
+      for (int mb = 0; mb < 2; ++mb)
+        for (int l = 0; l < 64; ++l)
+          pack[WP_W116 + mb * 64 + l] = (l >> 4) < 2 ? w->lin_w[0][fo(mb, l & 15) * 2 + (l >> 4)] : 0.f;
+      for (int L = 0; L < 4; ++L)
+        for (int l = 0; l < 64; ++l)
+          for (int s = 0; s < 8; ++s)
+            for (int mb = 0; mb < 2; ++mb)
+              pack[WP_WL16 + (L * 64 + l) * 16 + 2 * s + mb] = w->lin_w[1 + L][fo(mb, l & 15) * 32 + npa_feat16(s, l >> 4)];
+      for (int v = 0; v < 11 + 8; ++v)               // (the eleven vectors, then the eight rows of Linear(32,E): WP_W6 follows WP_VEC)
+        for (int kq = 0; kq < 4; ++kq)
+          for (int s = 0; s < 8; ++s)
+            pack[WP_VEC16 + v * 32 + kq * 8 + s] = pack[WP_VEC + v * 32 + npa_feat16(s, kq)];
+      for (int e = 0; e < 8; ++e) pack[WP_VEC16 + 19 * 32 + e] = pack[WP_B6 + e];
+    }
     // ---- key path (dune_kernel): see pan_common.h --------------------------------------------------
     // LayerNorm centring folded into Linear 1, 3, 5 (fp64, rounded once)
     std::vector<float> wkey[4];                       // the four 32x32 layers as the key path sees them
@@ -498,8 +554,37 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
     if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0)
       h->n_cu = prop.multiProcessorCount;
   }
-  if (e == hipSuccess) e = hipMalloc(&h->wpack, ((size_t)WP_TAB + WP_TAB_FLOATS) * sizeof(float));      // (the pack, then the key table)
-  if (e == hipSuccess) e = hipMemcpy(h->wpack, pack.data(), WP_TOTAL * sizeof(float), hipMemcpyHostToDevice);
+  // the pack's identity (SharedPack above): host image + polygon + calibration knobs + device
+  std::string pack_key;
+  {
+    static const char* const knobs[] = {"NPA_DUNE_FP32KEYS", "NPA_KEY_TERMS", "NPA_KEY_SAFETY", "NPA_GEO_GRID", "NPA_GEO_NOCHECK",
+                                        "NPA_GEO_TABLE", "NPA_KTAB_SAFETY", "NPA_KEYS_PRECISION", "NPA_K16_SAFETY", "NPA_ROWS_PRECISION"};
+    pack_key.assign(reinterpret_cast<const char*>(pack.data()), pack.size() * sizeof(float));
+    pack_key.append(reinterpret_cast<const char*>(&P.E), sizeof(P.E));
+    pack_key.append(reinterpret_cast<const char*>(P.G), sizeof(P.G));
+    pack_key.append(reinterpret_cast<const char*>(P.h), sizeof(P.h));
+    pack_key.append(reinterpret_cast<const char*>(&h->device), sizeof(h->device));
+    pack_key.push_back(need_w ? 'w' : '-');
+    for (const char* k : knobs) { const char* v = getenv(k); pack_key.push_back('|'); if (v) pack_key.append(v); else pack_key.push_back('\x01'); }
+  }
+  const bool use_cache = !(getenv("NPA_PACK_CACHE") && atoi(getenv("NPA_PACK_CACHE")) == 0);
+  std::unique_lock<std::mutex> pack_lock(g_pack_mu);
+  bool pack_hit = false;
+  if (e == hipSuccess && use_cache) {
+    auto it = g_packs.find(pack_key);
+    if (it != g_packs.end()) {
+      h->pack = it->second.lock();
+      if (!h->pack) g_packs.erase(it);
+    }
+    pack_hit = (bool)h->pack;
+  }
+  if (e == hipSuccess && !pack_hit) {
+    h->pack = std::make_shared<SharedPack>();
+    h->pack->device = h->device;
+    e = hipMalloc(&h->pack->wpack, ((size_t)WP_TAB + WP_TAB_FLOATS) * sizeof(float));      // (the pack, then the key table)
+    if (e == hipSuccess) e = hipMemcpy(h->pack->wpack, pack.data(), WP_TOTAL * sizeof(float), hipMemcpyHostToDevice);
+  }
+  if (h->pack) h->wpack = h->pack->wpack;
   // Key mode and candidate margin.  Distance KEYS only nominate candidates (select_kernel re-encodes them with the
   // exact network and ranks on the exact result), so their error decides nothing but how many candidates there are
   // -- PROVIDED the margin covers it.  The error is a property of the checkpoint and is measured here:
@@ -522,7 +607,17 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
     if (const char* env = getenv("NPA_KEY_SAFETY")) { double v = atof(env); if (v >= 1.0 && v <= 1e3) safety = v; }
     h->key_terms = 0;
     bool geo_ok = false;
-    if (h->geo_valid && (forced < 0 || forced == 4)) {
+    if (pack_hit) {
+      // a handle of the same key measured all of this already: its figures, no launches
+      const SharedPack& S = *h->pack;
+      h->key_terms = S.key_terms; h->key_err = S.key_err; h->key_e0 = S.key_e0; h->key_auto = S.key_auto;
+      for (int m = 0; m < 2; ++m) { h->e0_mode[m] = S.e0_mode[m]; h->err_mode[m] = S.err_mode[m]; }
+      h->geo_err = S.geo_err; h->geo_margin = S.geo_margin; h->geo_refine = S.geo_refine; h->geo_slope = S.geo_slope;
+      P.geo_rcal = S.geo_rcal; P.geo_far = S.geo_far; P.geo_tab = S.geo_tab;
+      h->ktab_err = S.ktab_err; h->ktab_margin = S.ktab_margin;
+      geo_ok = S.key_terms == 4;
+      ++g_pack_hits;
+    } else if (h->geo_valid && (forced < 0 || forced == 4)) {
       unsigned* tab = nullptr;
       e = hipMalloc(&tab, 2 * NPA_GEO_BANDS * sizeof(unsigned));
       if (e == hipSuccess) e = hipMemset(tab, 0, 2 * NPA_GEO_BANDS * sizeof(unsigned));
@@ -659,7 +754,7 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
       }
     }
     h->key_safety = safety;
-    if (!geo_ok && e == hipSuccess && forced != 0 && forced != 4) e = calibrate_network_keys(h, forced);
+    if (!pack_hit && !geo_ok && e == hipSuccess && forced != 0 && forced != 4) e = calibrate_network_keys(h, forced);
     // word 0: overflow tiles of the selection (key policy); words 1, 2: slices the scene-wide selection handed to the per-slice
     // body / took itself (select_scene.h, NPA_SELECT_SCENE=1; npa_dbg_select_stats)
     if (e == hipSuccess) e = hipMalloc(&h->sel_stats_dev, 4 * sizeof(unsigned));
@@ -675,23 +770,26 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
     if (const char* env = getenv("NPA_ROWS_PRECISION")) {
       if (!strcmp(env, "bf16")) {
         if (e == hipSuccess && !(h->key_terms == 4 && !h->select_v1 && (P.E == 4 || P.E == 8))) {
-          npa_destroy(h);
+          pack_lock.unlock(); npa_destroy(h);
           return fail(NPA_E_UNSUPPORTED, "NPA_ROWS_PRECISION=bf16 needs geometric keys (select_geo_kernel) and a polygon of 4 or 8 edges");
         }
         h->rows_bf16 = true;
       } else if (strcmp(env, "fp32") != 0) {
-        npa_destroy(h);
+        pack_lock.unlock(); npa_destroy(h);
         return fail(NPA_E_ARG, "NPA_ROWS_PRECISION must be fp32 or bf16");
       }
     }
     if (const char* env = getenv("NPA_KEYS_PRECISION")) {
       if (!strcmp(env, "bf16")) {
         if (e == hipSuccess && !(h->key_terms == 4 && !h->select_v1 && !h->rows_bf16 && (P.E == 4 || P.E == 8))) {
-          npa_destroy(h);
+          pack_lock.unlock(); npa_destroy(h);
           return fail(NPA_E_UNSUPPORTED, "NPA_KEYS_PRECISION=bf16 needs geometric keys, exact rows and a polygon of 4 or 8 edges");
         }
         // margin per band of the exact distance: safety (NPA_KEY_SAFETY, default 2: rounding noise sampled on 3 M grid nodes,
         // and every survivor is audited at run time) x the largest |bf16 - exact| over the band and its two neighbours
+        if (pack_hit) {                                    // (measured by the handle that made the pack: NPA_KEYS_PRECISION is part of its key)
+          h->k16_err = h->pack->k16_err; h->k16_margin = h->pack->k16_margin; h->keys_bf16 = h->pack->keys_bf16;
+        } else {
         unsigned* tab = nullptr;
         if (e == hipSuccess) e = hipMalloc(&tab, NPA_GEO_BANDS * sizeof(unsigned));
         if (e == hipSuccess) e = hipMemset(tab, 0, NPA_GEO_BANDS * sizeof(unsigned));
@@ -719,8 +817,9 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
           e = hipMemcpy(h->wpack + WP_K16, mg, sizeof(mg), hipMemcpyHostToDevice);
           h->keys_bf16 = true;
         }
+        }
       } else if (strcmp(env, "fp32") != 0) {
-        npa_destroy(h);
+        pack_lock.unlock(); npa_destroy(h);
         return fail(NPA_E_ARG, "NPA_KEYS_PRECISION must be fp32 or bf16");
       }
     }
@@ -732,9 +831,23 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
     }
   }
   if (e != hipSuccess) {
+    pack_lock.unlock();
     npa_destroy(h);                                      // releases whatever was created so far
     return fail(NPA_E_HIP, std::string("npa_create: ") + hipGetErrorString(e));
   }
+  if (!pack_hit && h->pack) {
+    // the figures for the handles that follow (the device buffer is complete: every write to it happened above)
+    SharedPack& S = *h->pack;
+    S.key_terms = h->key_terms; S.key_err = h->key_err; S.key_e0 = h->key_e0; S.key_auto = h->key_auto;
+    for (int m = 0; m < 2; ++m) { S.e0_mode[m] = h->e0_mode[m]; S.err_mode[m] = h->err_mode[m]; }
+    S.geo_err = h->geo_err; S.geo_margin = h->geo_margin; S.geo_refine = h->geo_refine; S.geo_slope = h->geo_slope;
+    S.geo_rcal = P.geo_rcal; S.geo_far = P.geo_far; S.geo_tab = P.geo_tab;
+    S.ktab_err = h->ktab_err; S.ktab_margin = h->ktab_margin;
+    S.keys_bf16 = h->keys_bf16; S.k16_err = h->k16_err; S.k16_margin = h->k16_margin;
+    if (need_w) ++g_pack_calibrations;
+    if (use_cache) g_packs[pack_key] = h->pack;
+  }
+  pack_lock.unlock();
   if (!getenv("NPA_SKIP_SELFTEST")) {
     const int rc = npa_self_test(h);
     if (rc != NPA_OK) {
@@ -766,7 +879,11 @@ extern "C" int npa_destroy(npa_handle* h) {
   for (auto& p : h->ev_sel) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto& p : h->ev_qp) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
   for (auto& p : h->ev_aset) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
-  if (h->wpack) hipFree(h->wpack);
+  h->wpack = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_pack_mu);           // (the last owner frees the buffer; a create of the same key waits or misses)
+    h->pack.reset();
+  }
   if (h->sel_stats_dev) hipFree(h->sel_stats_dev);
   if (h->sel_stats_host) hipHostFree(h->sel_stats_host);
   if (h->audit_dev) hipFree(h->audit_dev);
@@ -781,6 +898,18 @@ extern "C" int npa_key_mode(const npa_handle* h, int* key_terms, float* measured
   if (key_terms) *key_terms = h->key_terms;
   if (measured_error) *measured_error = h->key_err;
   if (margin_e0) *margin_e0 = h->key_e0;
+  return NPA_OK;
+}
+
+extern "C" int npa_pack_cache_stats(int64_t* calibrations, int64_t* shared_creates, int64_t* alive) {
+  std::lock_guard<std::mutex> lk(g_pack_mu);
+  if (calibrations) *calibrations = g_pack_calibrations;
+  if (shared_creates) *shared_creates = g_pack_hits;
+  if (alive) {
+    int64_t n = 0;
+    for (auto& kv : g_packs) n += kv.second.expired() ? 0 : 1;
+    *alive = n;
+  }
   return NPA_OK;
 }
 
@@ -1189,6 +1318,24 @@ extern "C" int npa_group_mergeable(int n, const npa_forward_call* calls) {
 
 extern "C" int npa_forward_group_merged(int n, const npa_forward_call* calls) { return npa_group_mergeable(n, calls); }
 
+// The merged path reads and advances per-handle state of up to NPA_GROUP_MAX handles (pc, launch_seq, the profile events of the
+// first): every member's mutex, taken in address order (two groups that share handles cannot deadlock), like begin / iter / end
+// hold their handle's.  A concurrent call on a member handle from another thread waits instead of racing.
+struct GroupLock {
+  std::mutex* m[NPA_GROUP_MAX];
+  int n = 0;
+  GroupLock(int cnt, const npa_forward_call* calls) {
+    for (int c = 0; c < cnt && n < NPA_GROUP_MAX; ++c)
+      if (calls[c].h) m[n++] = &calls[c].h->mu;
+    std::sort(m, m + n);
+    n = (int)(std::unique(m, m + n) - m);
+    for (int i = 0; i < n; ++i) m[i]->lock();
+  }
+  ~GroupLock() { for (int i = n - 1; i >= 0; --i) m[i]->unlock(); }
+  GroupLock(const GroupLock&) = delete;
+  GroupLock& operator=(const GroupLock&) = delete;
+};
+
 // begin of every call without its staging launch, then ONE staging launch for the group.  *begun = calls begun (the caller
 // ends them whatever happens).
 extern "C" int npa_group_begin_merged(int n, const npa_forward_call* calls, int flags, int* begun) {
@@ -1201,6 +1348,7 @@ extern "C" int npa_group_begin_merged(int n, const npa_forward_call* calls, int 
     if (rc != NPA_OK) return rc;
     *begun = c + 1;
   }
+  GroupLock group_lock(n, calls);
   npa_handle* h0 = calls[0].h;
   const DevParams& P = h0->P;
   const int T = P.T, batch = calls[0].batch;
@@ -1229,6 +1377,7 @@ extern "C" unsigned long long npa_dbg_group_merged_launches(void) { return g_mer
 
 // PAN iteration k of every call of the group: one selection launch, one QP launch (profile events: the first call's)
 extern "C" int npa_group_iter_merged(int n, const npa_forward_call* calls, int k) {
+  GroupLock group_lock(n, calls);
   npa_handle* h0 = calls[0].h;
   const DevParams& P = h0->P;
   if (k < 0 || k >= P.K) return fail(NPA_E_ARG, "npa_forward_batch_group: iteration index out of range");

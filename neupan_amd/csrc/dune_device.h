@@ -34,29 +34,78 @@ __device__ __forceinline__ void load_vec16(const float* v, int hf, float out[16]
   }
 }
 
+// PERM: the vector is the PERMUTED image of the 16-point tile (pan_common.h WP_VEC16: [kq 4][s 8]).  Register r = 2 i + h2 of a
+// lane of the 32-point tile holds feature npa_feat16(i, hf + 2 h2): entry i of group hf (even registers) / 2 + hf (odd ones), so the
+// same four 16-byte loads serve -- the selection keeps ONE image of the vectors in LDS for both tile shapes.
+template <bool PERM>
+__device__ __forceinline__ void load_vec16x(const float* v, int hf, float out[16]) {
+  if constexpr (!PERM) {
+    load_vec16(v, hf, out);
+  } else {
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const float4 t = *reinterpret_cast<const float4*>(v + 16 * h2 + 8 * hf + 4 * qq);
+        out[2 * (4 * qq + 0) + h2] = t.x; out[2 * (4 * qq + 1) + h2] = t.y; out[2 * (4 * qq + 2) + h2] = t.z; out[2 * (4 * qq + 3) + h2] = t.w;
+      }
+  }
+}
+template <bool PERM = false>
 __device__ __forceinline__ f32x16 bias_init(const float* v, int hf) {
   float b[16];
-  load_vec16(v, hf, b);
+  load_vec16x<PERM>(v, hf, b);
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = b[r];
   return acc;
 }
 
+// ---- the canonical reduction order of a point's 32 features (shared by the 32-point and the 16-point tile) ------------------
+// The features fall into four groups of eight, group kq = {npa_feat16(s, kq), s = 0..7} (pan_common.h): what ONE lane of the
+// 16-point tile holds, and what the even (kq = hf) / odd (kq = 2 + hf) accumulator registers of a lane of the 32-point tile hold.
+// A sum over the 32 features is p_kq = the chain over s = 0..7 inside each group, then (p_0 + p_1) + (p_2 + p_3): the same
+// operations in the same order in both layouts (fp addition commutes), so the two tile shapes give BITWISE the same rows.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float quad_sum(float x) {
+  // (row 0 + row 1) + (row 2 + row 3) of the four 16-lane rows, the same bits in all four
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return pair_sum(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+}
+
 // LayerNorm(32, eps=1e-5, affine) + tanh on a point's 32 features (16 here, 16 in lane^32)
+template <bool PERM = false>
 __device__ __forceinline__ void ln_tanh(f32x16 acc, const float* g, const float* be, int hf, float a[16]) {
-  float s = 0.f;
+  float se = acc[0], so = acc[1];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) s += acc[r];
-  float mean = pair_sum(s) * (1.0f / 32.0f);
-  float q = 0.f;
+  for (int r = 2; r < 16; r += 2) { se += acc[r]; so += acc[r + 1]; }
+  float mean = (pair_sum(se) + pair_sum(so)) * (1.0f / 32.0f);
+  float qe = 0.f, qo = 0.f;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { a[r] = acc[r] - mean; q = fmaf(a[r], a[r], q); }
-  float var = pair_sum(q) * (1.0f / 32.0f);
+  for (int r = 0; r < 16; r += 2) {
+    a[r] = acc[r] - mean; qe = fmaf(a[r], a[r], qe);
+    a[r + 1] = acc[r + 1] - mean; qo = fmaf(a[r + 1], a[r + 1], qo);
+  }
+  float var = (pair_sum(qe) + pair_sum(qo)) * (1.0f / 32.0f);
   float ve = var + 1e-5f;
   float rstd = __builtin_amdgcn_rsqf(ve);                 // v_rsq_f32 (1 ulp) + one Newton step
   rstd = rstd * fmaf(-0.5f * ve * rstd, rstd, 1.5f);
   // affine vectors fetched four features at a time (keeps the live register set small)
+  if constexpr (PERM) {
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const float4 gv = *reinterpret_cast<const float4*>(g + 16 * h2 + 8 * hf + 4 * qq);
+        const float4 bv = *reinterpret_cast<const float4*>(be + 16 * h2 + 8 * hf + 4 * qq);
+        const int r0 = 2 * (4 * qq) + h2;
+        a[r0 + 0] = tanh_scaled(fmaf(a[r0 + 0] * rstd, gv.x, bv.x));
+        a[r0 + 2] = tanh_scaled(fmaf(a[r0 + 2] * rstd, gv.y, bv.y));
+        a[r0 + 4] = tanh_scaled(fmaf(a[r0 + 4] * rstd, gv.z, bv.z));
+        a[r0 + 6] = tanh_scaled(fmaf(a[r0 + 6] * rstd, gv.w, bv.w));
+      }
+    return;
+  }
 #pragma unroll
   for (int qd = 0; qd < 4; ++qd) {
     float4 gv = *reinterpret_cast<const float4*>(g + 8 * qd + 4 * hf);
@@ -259,10 +308,10 @@ __device__ __forceinline__ void encode_tile(const WaveWeights& W, const float* v
   for (int e = 0; e < E; ++e) {
     float wv[16];
     load_vec16(w6 + e * 32, hf, wv);
-    float s = 0.f;
+    float se = 0.f, so = 0.f;                 // (the canonical order: even / odd registers are two of the four feature groups)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s = fmaf(wv[r], a[r], s);
-    mu[e] = fmaxf(pair_sum(s) + b6[e], 0.f);
+    for (int r = 0; r < 16; r += 2) { se = fmaf(wv[r], a[r], se); so = fmaf(wv[r + 1], a[r + 1], so); }
+    mu[e] = fmaxf((pair_sum(se) + pair_sum(so)) + b6[e], 0.f);
   }
 }
 
@@ -281,53 +330,160 @@ __device__ __forceinline__ void load_layer(const float* __restrict__ wls, int L,
     w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
   }
 }
-template <int E>
+// PERM: vec / w6 are the permuted images of the 16-point tile (load_vec16x)
+template <int E, bool PERM = false>
 __device__ __forceinline__ void encode_tile_stream(float w1, const float* __restrict__ wls, const float* vec, const float* w6,
                                                    const float* b6, float p0x, float p0y, int lane, float mu[E]) {
   const int hf = lane >> 5;
+  if constexpr (PERM) {                      // (the tile loop of the selection holds BOTH tile shapes: keep the LDS reads in place, see encode_tile16_stream)
+    const float* vq = vec + 8 * hf;
+    asm volatile("" : "+v"(vq));
+    vec = vq - 8 * hf; w6 = vec + 11 * 32; b6 = w6 + 8 * 32;
+  }
   float a[16], wa[16], wb[16];
   // (scheduling barriers between the blocks: left alone the scheduler hoists all four layers' loads to the top -- the
   // 64 registers this form exists to avoid)
   load_layer(wls, 0, lane, wa);
   {
-    f32x16 acc = bias_init(vec + V_B1 * 32, hf);
+    f32x16 acc = bias_init<PERM>(vec + V_B1 * 32, hf);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, hf ? p0y : p0x, acc, 0, 0, 0);
-    ln_tanh(acc, vec + V_G1 * 32, vec + V_BE1 * 32, hf, a);
+    ln_tanh<PERM>(acc, vec + V_G1 * 32, vec + V_BE1 * 32, hf, a);
   }
   __builtin_amdgcn_sched_barrier(0);
   load_layer(wls, 1, lane, wb);
   {
-    f32x16 acc = layer32(wa, a, bias_init(vec + V_B2 * 32, hf));
+    f32x16 acc = layer32(wa, a, bias_init<PERM>(vec + V_B2 * 32, hf));
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r], 0.f);
   }
   __builtin_amdgcn_sched_barrier(0);
   load_layer(wls, 2, lane, wa);
   {
-    f32x16 acc = layer32(wb, a, bias_init(vec + V_B3 * 32, hf));
-    ln_tanh(acc, vec + V_G2 * 32, vec + V_BE2 * 32, hf, a);
+    f32x16 acc = layer32(wb, a, bias_init<PERM>(vec + V_B3 * 32, hf));
+    ln_tanh<PERM>(acc, vec + V_G2 * 32, vec + V_BE2 * 32, hf, a);
   }
   __builtin_amdgcn_sched_barrier(0);
   load_layer(wls, 3, lane, wb);
   {
-    f32x16 acc = layer32(wa, a, bias_init(vec + V_B4 * 32, hf));
+    f32x16 acc = layer32(wa, a, bias_init<PERM>(vec + V_B4 * 32, hf));
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = fmaxf(acc[r], 0.f);
   }
   __builtin_amdgcn_sched_barrier(0);
   {
-    f32x16 acc = layer32(wb, a, bias_init(vec + V_B5 * 32, hf));
-    ln_tanh(acc, vec + V_G3 * 32, vec + V_BE3 * 32, hf, a);
+    f32x16 acc = layer32(wb, a, bias_init<PERM>(vec + V_B5 * 32, hf));
+    ln_tanh<PERM>(acc, vec + V_G3 * 32, vec + V_BE3 * 32, hf, a);
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     float wv[16];
-    load_vec16(w6 + e * 32, hf, wv);
+    load_vec16x<PERM>(w6 + e * 32, hf, wv);
+    float se = 0.f, so = 0.f;                 // (the canonical order: even / odd registers are two of the four feature groups)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) { se = fmaf(wv[r], a[r], se); so = fmaf(wv[r + 1], a[r + 1], so); }
+    mu[e] = fmaxf((pair_sum(se) + pair_sum(so)) + b6[e], 0.f);
+  }
+}
+
+// ---- the exact encoder on a tile of SIXTEEN points (v_mfma_f32_16x16x4_f32) -------------------------------------------------
+// The selection's candidate lists carry a median of 14-19 points: a 32-point tile is half padding.  Here a
+// point is four lanes (lane group kq = lane >> 4 holds eight of its 32 features, pan_common.h WP_W116), a layer is 16 MFMAs of 32
+// cycles on two independent accumulators (dependent latency 40 cycles: alternating them runs at the issue rate), the elementwise
+// work per lane is half a 32-point tile's.  Same fma chains in the same K order and the canonical reductions above: bitwise the
+// rows of encode_tile / encode_tile_stream.  vec / w6 / b6: the PERMUTED images (WP_VEC16).
+__device__ __forceinline__ f32x4 ld4(const float* p) {
+  const float4 t = *reinterpret_cast<const float4*>(p);
+  return f32x4{t.x, t.y, t.z, t.w};
+}
+__device__ __forceinline__ void ln_tanh16(f32x4 c0, f32x4 c1, const float* g, const float* be, int kq, float a[8]) {
+  float s = c0[0];
+  s += c0[1]; s += c0[2]; s += c0[3]; s += c1[0]; s += c1[1]; s += c1[2]; s += c1[3];
+  const float mean = quad_sum(s) * (1.0f / 32.0f);
+  float q = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { a[r] = c0[r] - mean; q = fmaf(a[r], a[r], q); }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { a[4 + r] = c1[r] - mean; q = fmaf(a[4 + r], a[4 + r], q); }
+  const float var = quad_sum(q) * (1.0f / 32.0f);
+  const float ve = var + 1e-5f;
+  float rstd = __builtin_amdgcn_rsqf(ve);
+  rstd = rstd * fmaf(-0.5f * ve * rstd, rstd, 1.5f);
+#pragma unroll
+  for (int qd = 0; qd < 2; ++qd) {
+    const float4 gv = *reinterpret_cast<const float4*>(g + 8 * kq + 4 * qd);
+    const float4 bv = *reinterpret_cast<const float4*>(be + 8 * kq + 4 * qd);
+    a[4 * qd + 0] = tanh_scaled(fmaf(a[4 * qd + 0] * rstd, gv.x, bv.x));
+    a[4 * qd + 1] = tanh_scaled(fmaf(a[4 * qd + 1] * rstd, gv.y, bv.y));
+    a[4 * qd + 2] = tanh_scaled(fmaf(a[4 * qd + 2] * rstd, gv.z, bv.z));
+    a[4 * qd + 3] = tanh_scaled(fmaf(a[4 * qd + 3] * rstd, gv.w, bv.w));
+  }
+}
+__device__ __forceinline__ void layer16(const float (&w)[16], const float (&a)[8], f32x4& c0, f32x4& c1) {
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2 * s], a[s], c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2 * s + 1], a[s], c1, 0, 0, 0);
+  }
+}
+template <int E>
+__device__ __forceinline__ void encode_tile16_stream(float w1a, float w1b, const float* __restrict__ wls16, const float* vec,
+                                                     const float* w6, const float* b6, float p0x, float p0y, int lane, float mu[E]) {
+  const int kq = lane >> 4;
+  const float* vq = vec + 8 * kq;
+  // (the LDS reads below are loop-invariant for the caller's tile loop: behind an opaque address they stay where they are
+  // instead of being hoisted into ~120 registers)
+  asm volatile("" : "+v"(vq));
+  vec = vq - 8 * kq; w6 = vec + 11 * 32; b6 = w6 + 8 * 32;
+  float a[8], wa[16], wb[16];
+  load_layer(wls16, 0, lane, wa);
+  {
+    f32x4 c0 = ld4(vq + V_B1 * 32), c1 = ld4(vq + V_B1 * 32 + 4);
+    // K = 4 with two entries used: the chain is fma(W[i][1], y, fma(W[i][0], x, b)) then twice + 0 * 0 (exact)
+    const float bx = kq == 0 ? p0x : (kq == 1 ? p0y : 0.f);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1a, bx, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1b, bx, c1, 0, 0, 0);
+    ln_tanh16(c0, c1, vec + V_G1 * 32, vec + V_BE1 * 32, kq, a);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  load_layer(wls16, 1, lane, wb);
+  {
+    f32x4 c0 = ld4(vq + V_B2 * 32), c1 = ld4(vq + V_B2 * 32 + 4);
+    layer16(wa, a, c0, c1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { a[r] = fmaxf(c0[r], 0.f); a[4 + r] = fmaxf(c1[r], 0.f); }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  load_layer(wls16, 2, lane, wa);
+  {
+    f32x4 c0 = ld4(vq + V_B3 * 32), c1 = ld4(vq + V_B3 * 32 + 4);
+    layer16(wb, a, c0, c1);
+    ln_tanh16(c0, c1, vec + V_G2 * 32, vec + V_BE2 * 32, kq, a);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  load_layer(wls16, 3, lane, wb);
+  {
+    f32x4 c0 = ld4(vq + V_B4 * 32), c1 = ld4(vq + V_B4 * 32 + 4);
+    layer16(wa, a, c0, c1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { a[r] = fmaxf(c0[r], 0.f); a[4 + r] = fmaxf(c1[r], 0.f); }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    f32x4 c0 = ld4(vq + V_B5 * 32), c1 = ld4(vq + V_B5 * 32 + 4);
+    layer16(wb, a, c0, c1);
+    ln_tanh16(c0, c1, vec + V_G3 * 32, vec + V_BE3 * 32, kq, a);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const f32x4 w0 = ld4(w6 + e * 32 + 8 * kq), w1 = ld4(w6 + e * 32 + 8 * kq + 4);
     float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s = fmaf(wv[r], a[r], s);
-    mu[e] = fmaxf(pair_sum(s) + b6[e], 0.f);
+    for (int r = 0; r < 4; ++r) s = fmaf(w0[r], a[r], s);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s = fmaf(w1[r], a[4 + r], s);
+    mu[e] = fmaxf(quad_sum(s) + b6[e], 0.f);
   }
 }
 
@@ -384,10 +540,10 @@ __device__ __forceinline__ void encode_tile_bf16(float w1, const float* __restri
   for (int e = 0; e < E; ++e) {
     float wv[16];
     load_vec16(w6 + e * 32, hf, wv);
-    float s = 0.f;
+    float se = 0.f, so = 0.f;                 // (the canonical order: even / odd registers are two of the four feature groups)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s = fmaf(wv[r], a[r], s);
-    mu[e] = fmaxf(pair_sum(s) + b6[e], 0.f);
+    for (int r = 0; r < 16; r += 2) { se = fmaf(wv[r], a[r], se); so = fmaf(wv[r + 1], a[r + 1], so); }
+    mu[e] = fmaxf((pair_sum(se) + pair_sum(so)) + b6[e], 0.f);
   }
 }
 
@@ -490,7 +646,7 @@ __device__ __forceinline__ void point_features(const DevParams& P, const SliceFr
 
 // point_features with the streamed-weight encoder (exact rows; same operation order); BF16: the reduced-precision tier,
 // wls then points at the bf16 fragments (WP_WB16)
-template <int E, bool BF16 = false>
+template <int E, bool BF16 = false, bool PERM = false>
 __device__ __forceinline__ void point_features_stream(const DevParams& P, const SliceFrame& F, float w1, const float* __restrict__ wls,
                                                       const float* vec, const float* w6, const float* b6, const float* px_row,
                                                       const float* py_row, const float* vx_row, const float* vy_row, int src,
@@ -506,7 +662,35 @@ __device__ __forceinline__ void point_features_stream(const DevParams& P, const 
   p0x = fmaf(F.c, dx, __fmul_rn(F.s, dy));
   p0y = fmaf(F.c, dy, -__fmul_rn(F.s, dx));
   if constexpr (BF16) encode_tile_bf16<E>(w1, wls, vec, w6, b6, p0x, p0y, lane, mu);
-  else encode_tile_stream<E>(w1, wls, vec, w6, b6, p0x, p0y, lane, mu);
+  else encode_tile_stream<E, PERM>(w1, wls, vec, w6, b6, p0x, p0y, lane, mu);
+  lx = 0.f; ly = 0.f; dist = 0.f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    lx = fmaf(F.rg[0][e], mu[e], lx);
+    ly = fmaf(F.rg[1][e], mu[e], ly);
+    float tmp = __fsub_rn(fmaf(P.G[e][0], p0x, __fmul_rn(P.G[e][1], p0y)), P.h[e]);
+    dist = fmaf(mu[e], tmp, dist);
+  }
+}
+
+// point_features_stream on a 16-point tile: a point is the four lanes {j, j + 16, j + 32, j + 48}; all four return its row
+template <int E>
+__device__ __forceinline__ void point_features_stream16(const DevParams& P, const SliceFrame& F, float w1a, float w1b,
+                                                        const float* __restrict__ wls16, const float* vec, const float* w6,
+                                                        const float* b6, const float* px_row, const float* py_row,
+                                                        const float* vx_row, const float* vy_row, int src, int lane, float mu[E],
+                                                        float& gx, float& gy, float& lx, float& ly, float& dist, float& p0x,
+                                                        float& p0y) {
+  gx = px_row[src];
+  gy = py_row[src];
+  if (vx_row) {
+    gx = __fadd_rn(gx, __fmul_rn(F.tstep, __fmul_rn(vx_row[src], P.dt32)));
+    gy = __fadd_rn(gy, __fmul_rn(F.tstep, __fmul_rn(vy_row[src], P.dt32)));
+  }
+  float dx = __fsub_rn(gx, F.tx), dy = __fsub_rn(gy, F.ty);
+  p0x = fmaf(F.c, dx, __fmul_rn(F.s, dy));
+  p0y = fmaf(F.c, dy, -__fmul_rn(F.s, dx));
+  encode_tile16_stream<E>(w1a, w1b, wls16, vec, w6, b6, p0x, p0y, lane, mu);
   lx = 0.f; ly = 0.f; dist = 0.f;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
@@ -611,12 +795,14 @@ void dune_kernel(
       }
     }
     if (skip || tile * 32 >= n_use) continue;
-    const int n = tile * 32 + j;
-    const int nc = n < n_use ? n : n_use - 1;
-    float mu[E], gx, gy, lx, ly, dist;
-    point_features<E, SPLIT>(P, F, W, wbf, vec, w6, b6, px_row, py_row, vx_row, vy_row, src_index(nc, n_raw, n_use),
-                             lane, mu, gx, gy, lx, ly, dist);
-    if (hf == 0 && n < n_use) key_row[n] = ordered_key(dist);
+    {
+      const int n = tile * 32 + j;
+      const int nc = n < n_use ? n : n_use - 1;
+      float mu[E], gx, gy, lx, ly, dist;
+      point_features<E, SPLIT>(P, F, W, wbf, vec, w6, b6, px_row, py_row, vx_row, vy_row, src_index(nc, n_raw, n_use),
+                               lane, mu, gx, gy, lx, ly, dist);
+      if (hf == 0 && n < n_use) key_row[n] = ordered_key(dist);
+    }
   }
 }
 
@@ -684,7 +870,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
     if (lane == 0) count[orow] = 0;
     return;
   }
-  for (int i = lane; i < 11 * 32 + 8 * 32 + 8; i += 64) smem[i] = wpack[WP_VEC + i];
+  for (int i = lane; i < 11 * 32 + 8 * 32 + 8; i += 64) smem[i] = wpack[WP_VEC16 + i];      // (the 16-point tile's permuted vectors)
   if constexpr (GEO)
     for (int i = lane; i < NPA_GEO_BANDS; i += 64) etab[i] = wpack[WP_GEO + i];
   SliceFrame F;
@@ -726,8 +912,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
     const unsigned* gk = gkeys + orow * key_stride;
     for (int n = lane; n < n_use; n += 64) dkey[n] = gk[n];
   }
-  WaveWeights W;
-  load_weights(wpack, lane, W);
+  const float w1a = wpack[WP_W116 + lane], w1b = wpack[WP_W116 + 64 + lane];
+  const float* wls16 = wpack + WP_WL16;
   WSYNC();
 
   const int msel = n_use < M ? n_use : M;
@@ -853,13 +1039,13 @@ __global__ __attribute__((amdgpu_flat_work_group_size(64, 64), amdgpu_waves_per_
   for (int phase = overflow ? 0 : 1;; phase = 1) {
     const int cnt = phase == 0 ? total : ncand;
 #pragma unroll 1
-    for (int q0 = 0; q0 < cnt; q0 += 32) {
-      const int q = q0 + j, qc = q < cnt ? q : cnt - 1;
+    for (int q0 = 0; q0 < cnt; q0 += 16) {                      // (16-point tiles of the exact encoder, weights streamed)
+      const int q = q0 + (lane & 15), qc = q < cnt ? q : cnt - 1;
       const int idx = phase == 0 ? cand_index(qc) : sel[qc];
-      float mu[E], gx, gy, lx, ly, dist;
-      point_features<E, 0>(P, F, W, nullptr, vec, w6, b6, px_row, py_row, vx_row, vy_row,
-                           src_index(idx, n_raw, n_use), lane, mu, gx, gy, lx, ly, dist);
-      if (hf == 0 && q < cnt) {
+      float mu[E], gx, gy, lx, ly, dist, p0x, p0y;
+      point_features_stream16<E>(P, F, w1a, w1b, wls16, vec, w6, b6, px_row, py_row, vx_row, vy_row,
+                                 src_index(idx, n_raw, n_use), lane, mu, gx, gy, lx, ly, dist, p0x, p0y);
+      if (lane < 16 && q < cnt) {
         const unsigned k = ordered_key(dist);
         if (phase == 0) {
           if (all) dkey[idx] = k;

@@ -87,6 +87,9 @@ struct StageGroup { StageCall c[NPA_GROUP_MAX]; };
 __host__ __device__ inline int npa_geo_band(float g) {
   union { float f; unsigned u; } v;
   v.f = g + 0.25f;
+  // (signed keys reach this -- the table-corrected key, bf16 / exact distances: anything at or below -0.25 m has its sign bit
+  // set and belongs to band 0 like every other negative key, the interval the threshold folds of select_geo_body.inc give band 0)
+  if (v.u & 0x80000000u) return 0;
   const int b = (int)(v.u >> 20) - (int)(0x3E800000u >> 20);
   return b < 0 ? 0 : (b >= NPA_GEO_BANDS ? NPA_GEO_BANDS - 1 : b);
 }
@@ -147,7 +150,23 @@ __host__ __device__ inline int npa_geo_band(float g) {
 // ranks every point on the distance to the polygon's bounding box -- 8 instructions instead of 12 per edge -- which is a lower
 // bound of the distance g to the polygon with g <= box distance + S, S = the largest g over the box's corners (g is convex)
 #define WP_TABH (WP_KTAB + ((NPA_GEO_BANDS + 3) & ~3))
-#define WP_TOTAL (WP_TABH + 8)
+// ---- the 16-point tile of the exact encoder (v_mfma_f32_16x16x4_f32; dune_device.h: encode_tile16_stream) ---------------------
+// A 16x16x4 MFMA holds A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15], D[i = 4 (l >> 4) + v][j = l & 15] (v = 0..3).  A 32-wide
+// layer is TWO row blocks mb = 0, 1 (two independent accumulators of 4 registers) and EIGHT K-steps s; lane group kq = l >> 4 holds,
+// in accumulator register v of block mb, the output feature npa_feat16(4 mb + v, kq) -- chosen so that
+//   * register s = 4 mb + v of a lane IS its B operand of K-step s of the next layer (no data movement between the layers), and
+//   * the K order of a point's fma chain, (s, kq) lexicographic, is feature 0,4,1,5,2,6,3,7,8,12,... : the order of the 32-point
+//     tile's chain (step r: npa_feat(r, 0), npa_feat(r, 1)).  The f32 MFMA is an fmaf chain in K order, so both tile shapes give
+//     bitwise the same accumulators; LayerNorm sums and the output layer reduce in one canonical order in both (dune_device.h).
+// WP_W116: [mb 2][lane 64] A-fragments of Linear(2,32) (K = 2 of 4 used: lanes kq >= 2 hold 0)
+// WP_WL16: [layer 4][lane 64][2 s + mb] A-fragments of the four 32x32 layers, lane-major (streamed with four 16-byte loads per layer)
+// WP_VEC16: the per-feature vectors, the rows of Linear(32,E) and its bias as WP_VEC / WP_W6 / WP_B6 hold them, every 32-vector
+//           permuted to [kq 4][s 8] (a lane reads its eight entries with two 16-byte LDS loads)
+#define WP_W116 (WP_TABH + 8)
+#define WP_WL16 (WP_W116 + 2 * 64)
+#define WP_VEC16 (WP_WL16 + 4 * 64 * 16)
+#define WP_VEC16_FLOATS (11 * 32 + 8 * 32 + 8)
+#define WP_TOTAL (WP_VEC16 + WP_VEC16_FLOATS)
 #define NPA_TAB_KEY_FAR 0xFFFFFFFDu                // filter key of a point beyond the calibrated square (above every ordered_key of a number)
 #define NPA_TAB_N 512                             // cells per side of one level
 #define NPA_TAB_LEVELS 4
@@ -158,6 +177,8 @@ __host__ __device__ inline int npa_geo_band(float g) {
 enum { V_B1 = 0, V_G1, V_BE1, V_B2, V_B3, V_G2, V_BE2, V_B4, V_B5, V_G3, V_BE3 };
 
 __host__ __device__ inline int npa_feat(int r, int hf) { return (r & 3) + 8 * (r >> 2) + 4 * hf; }
+// feature in accumulator register s (= 4 mb + v) of lane group kq (= lane >> 4) of the 16-point tile (see WP_W116 above)
+__host__ __device__ inline int npa_feat16(int s, int kq) { return 8 * (s >> 1) + 2 * (s & 1) + (kq >> 1) + 4 * (kq & 1); }
 
 // ---- per-scene persistent state (stop criterion memory, pan.py:100-105) -------------------
 // floats: prev_s[3(T+1)] prev_u[2T] prev_mu[(T+1) M E] prev_lam[(T+1) M 2]; ints: valid, prev_n, min-distance valid,

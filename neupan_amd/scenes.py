@@ -93,6 +93,15 @@ CONFIGS = {
                    max_speed=[8, 1], max_acce=[8, 3]),
         adjust=dict(q_s=1.0, p_u=1.0, eta=15.0, d_max=1.0, d_min=0.1, bk=0.1, ro_obs=400),
     ),
+    # configs[4]'s size on the polygon the reference SHIPS a checkpoint for (the 4-edge trapezoid of example/polygon_robot,
+    # planner.yaml:16 / example/model/polygon_robot): what a reference-recorded full-size vector can be made of
+    # (tests/golden/make_golden_full.py)
+    "polygon_5k_T10_K10": SceneConfig(
+        name="polygon_5k_T10_K10", n_points=5000, checkpoint="polygon_robot",
+        robot=dict(kinematics="diff", vertices=[[-0.8, -1.0], [-1.8, 1.0], [1.8, 1.0], [0.8, -1.0]],
+                   max_speed=[8, 3], max_acce=[8, 3]),
+        adjust=dict(q_s=1.0, p_u=1.0, eta=15.0, d_max=1.0, d_min=0.1, bk=0.1, ro_obs=400),
+    ),
 }
 
 

@@ -109,7 +109,12 @@ PANS = [("diff_n1000_k3", "diff_1k_T10_K10", dict(iter_num=3)),
         ("decimate_n500_k3", "diff_1k_T10_K10", dict(iter_num=3, dune_max_num=100)),
         ("omni_dyna_n80_k3", "dyna_4k_T10_K10", dict(iter_num=3, dune_max_num=80, robot_kw=OMNI)),
         ("acker_reverse_n150_k4", "acker_2k_T20_K15", dict(iter_num=4, dune_max_num=150)),
-        ("polygon_dyna_n100_k3", "dyna_4k_T10_K10", dict(iter_num=3, dune_max_num=100, robot_kw=POLY, checkpoint="polygon_robot"))]
+        ("polygon_dyna_n100_k3", "dyna_4k_T10_K10", dict(iter_num=3, dune_max_num=100, robot_kw=POLY, checkpoint="polygon_robot")),
+        # tests/golden/make_golden_full.py: BASELINE.json's configurations at their own sizes, two ensemble-well-posed scenes each
+        ("diff_n1000_k10_s0", "diff_1k_T10_K10", dict(iter_num=10)), ("diff_n1000_k10_s1", "diff_1k_T10_K10", dict(iter_num=10)),
+        ("acker_n2000_T20_k15_s0", "acker_2k_T20_K15", dict(iter_num=15)), ("acker_n2000_T20_k15_s1", "acker_2k_T20_K15", dict(iter_num=15)),
+        ("dyna_n4000_k10_s0", "dyna_4k_T10_K10", dict(iter_num=10)), ("dyna_n4000_k10_s1", "dyna_4k_T10_K10", dict(iter_num=10)),
+        ("polygon_n5000_k10_s0", "polygon_5k_T10_K10", dict(iter_num=10)), ("polygon_n5000_k10_s1", "polygon_5k_T10_K10", dict(iter_num=10))]
 
 
 @pytest.mark.parametrize("case,cfgname,over", PANS)
