@@ -62,7 +62,7 @@ PEAK_FP64_VALU_TFLOPS = 78.6
 PEAK_FP32_MFMA_TFLOPS = 157.3       # v_mfma_f32_32x32x2_f32: what the exact encoder runs on
 PEAK_F16_MFMA_TFLOPS = 2500.0       # dense fp16 / bf16 MFMA
 N_SIMD = 1024
-PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json")]     # newest first
+PMC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json")]     # newest first
 # which source files a kernel's counters depend on (a record is "current" only while these are unchanged)
 _QP_SRC = ("nrmp_qp.hip", "nrmp_qp_device.h", "nrmp_qp_body.inc", "aset_reduce.h", "pan_common.h")
 _DUNE_SRC = ("dune.hip", "dune_device.h", "select_geo_carve.inc", "select_geo_body.inc", "pan_common.h")
@@ -405,6 +405,75 @@ def parity_leg(lp, scenes, cores, n_ulp=8, n_perm=4, sweep=False, explain=True):
     return rep, cpu_rate, ncore, hip, sp, tr
 
 
+def fleet_cycle_leg(dev, with_cpu=True, robots=256):
+    """SURVEY.md 8(f) rows 1-2 in their place: ONE closed-loop control cycle of `robots` robots on the device, in the order of
+    neupan.forward (neupan/neupan.py:104-167): scan -> points (neupan.py:173-222), path progress + nominal / reference rollout
+    (initial_path.py:68-126, 247-277), the PAN loop, warm start, stop test, action (neupan_amd.fleet.FleetPlanner).  Two settings:
+    `shipped` = every shipped planner.yaml (K = 2, dune_max_num = 100, iter_threshold = 0.1, a 100-beam lidar) and `k10` = the
+    headline's (K = 10, 1000 beams / points, iter_threshold = 0).  Per setting: robot-cycles/s, and the front end's share of the
+    cycle = (scan -> points + progress + rollout alone) / (whole cycle).  CPU beside it: oracle/frontend_oracle.py (the reference's
+    algorithm, one thread) per robot for the two front-end steps."""
+    import torch
+    from neupan_amd.fleet import FleetPlanner
+    from neupan_amd.robot import Robot
+    from neupan_amd.scenes import CONFIGS
+    cfg = CONFIGS[WORKLOAD]
+    B = robots
+    rng = np.random.default_rng(11)
+    robot = Robot(cfg.T, cfg.dt, **cfg.robot)
+    ck = os.path.join(ROOT, "tests", "golden", "checkpoints", f"{cfg.checkpoint}_model_5000.pth")
+    paths = [[np.array([[i * 0.4], [0.3 * (b % 5) - 0.6], [0.0], [1.0]]) for i in range(80)] for b in range(B)]
+    poses = np.column_stack([rng.uniform(0, 2, B), rng.uniform(-0.6, 0.6, B), rng.uniform(-0.1, 0.1, B)])
+
+    def gpu_us(fn, reps):
+        fn(); fn(); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / reps * 1e6
+
+    out = {"robots": B}
+    for tag, K, beams, thr in (("shipped", 2, 100, 0.1), ("k10", cfg.iter_num, cfg.n_points, 0.0)):
+        fleet = FleetPlanner(robot, cfg.T, cfg.dt, cfg.ref_speed, device=dev, dune_checkpoint=ck, iter_num=K, dune_max_num=beams,
+                             nrmp_max_num=cfg.nrmp_max_num, iter_threshold=thr, adjust_kwargs=dict(cfg.adjust))
+        fleet.set_paths(paths)
+        # a corridor seen by the lidar: walls 3 - 4.5 m to either side, a fifth of the beams out of range
+        ang = np.linspace(-np.pi, np.pi, beams)
+        ranges = np.clip(rng.uniform(3.0, 4.5, (B, 1)) / np.maximum(np.abs(np.sin(ang))[None], 0.3), 0.2, 9.5)
+        ranges[rng.random((B, beams)) < 0.2] = 10.0
+        r_d = torch.from_numpy(ranges).to(dev)
+
+        def front():
+            pts, npts = fleet.scan_to_point(poses, r_d, -np.pi, np.pi, 0.1, 10.0, max_points=beams)
+            fleet.nb.progress(poses, fleet.close_threshold, fleet.ind_range, fleet.arrive_threshold, fleet.arrive_index_threshold)
+            fleet.nb.generate_nom_ref_state(poses, fleet.cur_vel, fleet.ref_speed)
+            return pts, npts
+
+        def cycle():
+            pts, npts = fleet.scan_to_point(poses, r_d, -np.pi, np.pi, 0.1, 10.0, max_points=beams)
+            fleet.forward(poses, pts, None, npts)
+
+        cyc = gpu_us(cycle, 30)
+        fr = gpu_us(front, 30)
+        out[tag] = {"K": K, "beams": beams, "iter_threshold": thr, "us_per_cycle": round(cyc, 1),
+                    "robot_cycles_per_s": round(B / cyc * 1e6), "front_end_us": round(fr, 1), "front_end_share": round(fr / cyc, 3)}
+        if with_cpu:
+            from oracle import frontend_oracle as fo
+            curves = [np.array([p.reshape(4) for p in paths[b]]) for b in range(8)]
+            vel = np.zeros((2, cfg.T), np.float32)
+            t0 = time.perf_counter()
+            for b in range(8):
+                fo.scan_to_point(poses[b], ranges[b], -np.pi, np.pi, 0.1, 10.0)
+                fo.generate_nom_ref_state(curves[b], 0, 0.4, poses[b], vel, cfg.ref_speed, cfg.T, cfg.dt, "diff", 0.0)
+            out[tag]["cpu_front_end_us_per_robot"] = round((time.perf_counter() - t0) / 8 * 1e6, 1)
+        del fleet
+    out["note"] = ("one closed-loop cycle of `robots` robots on the device (FleetPlanner: scan -> points, progress, rollout, PAN, warm "
+                   "start, stop test, action; one host read of the arrival flags per cycle, wall clock incl. the Python wrapper); "
+                   "front_end_share = the front-end steps alone / the whole cycle; cpu_front_end: oracle/frontend_oracle.py, 1 thread")
+    return out
+
+
 def slim(rep):
     """The verdicts of a parity report without the per-scene listings (the other configurations' entries of the line)."""
     keep = ("scenes", "ensemble_members", "ctrl_l2_vs_oracle_median", "max", "frac_le_1e-4", "scenes_well_posed",
@@ -502,6 +571,7 @@ def compact(line, full_path):
     c = line["config"]
     out["config"] = {k: c[k] for k in ("workload", "scenes_per_gpu", "points", "T", "K", "M", "batches_in_flight", "chains",
                                        "issue_threads", "parallelism") if k in c}
+    out["config"]["scenes_per_launch"] = line["roofline"].get("scenes_per_launch")
     r = line["roofline"]
     ro = {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "scenes_per_launch",
                                 "select_launch_ms", "launches_timed", "ipm_iterations_per_launch", "flops_per_launch", "frac_alone",
@@ -558,8 +628,17 @@ def compact(line, full_path):
         for k in ("early_exit", "h2d_inclusive"):
             if k in x:
                 e[k] = {kk: vv for kk, vv in x[k].items() if kk != "note"}
+        if "fleet_cycle" in x:
+            f = x["fleet_cycle"]
+            e["fleet_cycle"] = {"robots": f["robots"], **{t: {k: f[t][k] for k in ("robot_cycles_per_s", "front_end_share", "us_per_cycle",
+                                                                                   "cpu_front_end_us_per_robot") if k in f[t]}
+                                                          for t in ("shipped", "k10") if t in f}}
         e["seconds"] = x.get("seconds")
         out["extra"] = e
+        # the metric is quoted on 256 scenes per STEP; the default schedule merges the steps of a chain into launches of
+        # scenes_per_launch scenes -- the rate of the one-launch-chain-per-step schedule rides in the part that is never dropped
+        if isinstance((x.get("launch_shapes") or {}).get("one_chain_per_step"), dict):
+            out["config"]["plans_per_s_one_chain_per_step"] = x["launch_shapes"]["one_chain_per_step"]["plans_per_s"]
     out["full_record"] = full_path
     # never above the limit: drop the least essential parts first
     for drop in (("extra", "launch_shapes"), ("extra", "paths"), ("parity", "gpu_last_qp"), ("roofline", "pmc"), ("extra", "other_configs"),
@@ -572,6 +651,15 @@ def compact(line, full_path):
                 del out[a]
             else:
                 del out[a][b]
+    if len(json.dumps(out)) > COMPACT_LIMIT:
+        # last resort: the contract keys, the two required objects at their required keys, nothing else -- a line is ALWAYS printed
+        r = out["roofline"]
+        out = {k: out[k] for k in keep + ("config",)}
+        out["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel")}
+        if "cpu_baseline" in line:
+            cb = line["cpu_baseline"]
+            out["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"][:120]}
+        out["full_record"] = full_path
     return out
 
 
@@ -1012,6 +1100,8 @@ def main():
         ex["launch_shapes"] = dict(shapes, note="the default workload and batch size under other launch schedules (60 steps): "
                                                 "one_chain_per_step = round 4's default (20 streams, 1 + 2K launches per step); n_chains = "
                                                 "the 20 batches in flight merged into n launch chains")
+        # the closed-loop cycle around the PAN loop, measured today (round 1's figure predates every kernel here)
+        ex["fleet_cycle"] = fleet_cycle_leg(dev, with_cpu=with_cpu)
         # SURVEY 8(d)'s second run: the reference's default stop threshold (pan.py:243: iter_threshold = 0.1).  Every step starts
         # from a cleared stop-criterion state (like every other leg), so a scene runs at least 2 iterations: the first only
         # stores its iterate (pan.py:218-221)
@@ -1045,7 +1135,6 @@ def main():
             full_path = f"not written: {e}"
         short = compact(line, os.path.relpath(full_path, ROOT) if os.path.isabs(full_path) and full_path.startswith(ROOT) else full_path)
         txt = json.dumps(short)
-        assert len(txt) <= COMPACT_LIMIT, len(txt)
         print(txt, flush=True)
     if dist is not None:
         dist.destroy_process_group()

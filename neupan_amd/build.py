@@ -17,7 +17,10 @@ LIB = os.path.join(HERE, "libneupan_amd.so")
 EXPERIMENTS = os.environ.get("NPA_EXPERIMENTS", "0") not in ("", "0")
 SOURCES = ["dune.hip", "nrmp_qp.hip", "frontend.hip", "dune_labels.hip", "c_api.hip", "serve_group.hip"] + \
           (["aset_reduce.hip", "pan_scene.hip"] if EXPERIMENTS else [])
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
+# -ffp-contract=fast-honor-pragmas is hipcc's default for device code, stated here so that it is the BUILD's property, not the
+# compiler's: the bit-exact legs (A / B / C, fa against the reference's tensors) are written with __f*_rn intrinsics where the
+# reference rounds every operation, and with explicit fmaf where it does not
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-ffp-contract=fast-honor-pragmas",
          "-Wno-unused-result", "-Wno-unused-value"] + (["-DNPA_EXPERIMENTS"] if EXPERIMENTS else [])
 
 
@@ -67,14 +70,17 @@ def build(force=False, verbose=True):
             raise UnvalidatedCompiler(msg + ": set NPA_ALLOW_UNVALIDATED=1 to build anyway, then run the -m gpu suite")
         print(msg + ": building because NPA_ALLOW_UNVALIDATED=1 -- run the -m gpu determinism tests before trusting it",
               file=sys.stderr)
-    objs = []
-    for src in SOURCES:
+    objs, procs = [], []
+    for src in SOURCES:                      # (the translation units are independent: compiled side by side)
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         cmd = [hipcc_path(), *FLAGS, f'-DNPA_HIPCC_VERSION="{ver}"', "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        procs.append((cmd, subprocess.Popen(cmd)))
         objs.append(obj)
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -320,9 +320,12 @@ __device__ __forceinline__ void encode_tile(const WaveWeights& W, const float* v
 // the chip reads the same 16 KB) before the current layer's sixteen MFMAs start, which take ~1000 cycles.  Same
 // arithmetic in the same order as encode_tile: bitwise the same rows.
 __device__ __forceinline__ void load_layer(const float* __restrict__ wls, int L, int lane, float (&w)[16]) {
-  // (the address passes through an opaque asm: the loads are loop-invariant, and the compiler would otherwise hoist all
-  // four layers out of the tile loop and keep them in 64 registers -- the layout this form exists to avoid)
-  asm volatile("" : "+s"(wls));
+  // (the LANE INDEX passes through an opaque asm: the loads are loop-invariant, and the compiler would otherwise hoist all
+  // four layers out of the tile loop and keep them in 64 registers -- the layout this form exists to avoid.  The index, not the
+  // pointer: a pointer that went through an asm loses its address space and every access behind it becomes a FLAT load, which
+  // counts on vmcnt AND lgkmcnt and made the compiler put s_waitcnt vmcnt(0) lgkmcnt(0) in front of every layer -- the
+  // prefetched next layer's round trip in full, four times per tile)
+  asm volatile("" : "+v"(lane));
   const float4* p = reinterpret_cast<const float4*>(wls + ((size_t)L * 64 + lane) * 16);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -334,16 +337,13 @@ __device__ __forceinline__ void load_layer(const float* __restrict__ wls, int L,
 template <int E, bool PERM = false>
 __device__ __forceinline__ void encode_tile_stream(float w1, const float* __restrict__ wls, const float* vec, const float* w6,
                                                    const float* b6, float p0x, float p0y, int lane, float mu[E]) {
-  const int hf = lane >> 5;
-  if constexpr (PERM) {                      // (the tile loop of the selection holds BOTH tile shapes: keep the LDS reads in place, see encode_tile16_stream)
-    const float* vq = vec + 8 * hf;
-    asm volatile("" : "+v"(vq));
-    vec = vq - 8 * hf; w6 = vec + 11 * 32; b6 = w6 + 8 * 32;
-  }
+  int hf = lane >> 5;
+  if constexpr (PERM) asm volatile("" : "+v"(hf));      // (both tile shapes sit in one tile loop: keep the LDS reads in place, see encode_tile16_stream)
   float a[16], wa[16], wb[16];
   // (scheduling barriers between the blocks: left alone the scheduler hoists all four layers' loads to the top -- the
   // 64 registers this form exists to avoid)
   load_layer(wls, 0, lane, wa);
+  __builtin_amdgcn_sched_barrier(0);       // (the prefetch is ISSUED here: left to the scheduler it sinks to the end of the layer in front of it)
   {
     f32x16 acc = bias_init<PERM>(vec + V_B1 * 32, hf);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, hf ? p0y : p0x, acc, 0, 0, 0);
@@ -351,6 +351,7 @@ __device__ __forceinline__ void encode_tile_stream(float w1, const float* __rest
   }
   __builtin_amdgcn_sched_barrier(0);
   load_layer(wls, 1, lane, wb);
+  __builtin_amdgcn_sched_barrier(0);       // (the prefetch is ISSUED here: left to the scheduler it sinks to the end of the layer in front of it)
   {
     f32x16 acc = layer32(wa, a, bias_init<PERM>(vec + V_B2 * 32, hf));
 #pragma unroll
@@ -358,12 +359,14 @@ __device__ __forceinline__ void encode_tile_stream(float w1, const float* __rest
   }
   __builtin_amdgcn_sched_barrier(0);
   load_layer(wls, 2, lane, wa);
+  __builtin_amdgcn_sched_barrier(0);       // (the prefetch is ISSUED here: left to the scheduler it sinks to the end of the layer in front of it)
   {
     f32x16 acc = layer32(wb, a, bias_init<PERM>(vec + V_B3 * 32, hf));
     ln_tanh<PERM>(acc, vec + V_G2 * 32, vec + V_BE2 * 32, hf, a);
   }
   __builtin_amdgcn_sched_barrier(0);
   load_layer(wls, 3, lane, wb);
+  __builtin_amdgcn_sched_barrier(0);       // (the prefetch is ISSUED here: left to the scheduler it sinks to the end of the layer in front of it)
   {
     f32x16 acc = layer32(wa, a, bias_init<PERM>(vec + V_B4 * 32, hf));
 #pragma unroll
@@ -429,14 +432,14 @@ __device__ __forceinline__ void layer16(const float (&w)[16], const float (&a)[8
 template <int E>
 __device__ __forceinline__ void encode_tile16_stream(float w1a, float w1b, const float* __restrict__ wls16, const float* vec,
                                                      const float* w6, const float* b6, float p0x, float p0y, int lane, float mu[E]) {
-  const int kq = lane >> 4;
+  // (the LDS reads below are loop-invariant for the caller's tile loop: behind an opaque lane-group INDEX they stay where they
+  // are instead of being hoisted into ~120 registers; the index, not the address -- see load_layer)
+  int kq = lane >> 4;
+  asm volatile("" : "+v"(kq));
   const float* vq = vec + 8 * kq;
-  // (the LDS reads below are loop-invariant for the caller's tile loop: behind an opaque address they stay where they are
-  // instead of being hoisted into ~120 registers)
-  asm volatile("" : "+v"(vq));
-  vec = vq - 8 * kq; w6 = vec + 11 * 32; b6 = w6 + 8 * 32;
   float a[8], wa[16], wb[16];
   load_layer(wls16, 0, lane, wa);
+  __builtin_amdgcn_sched_barrier(0);       // (the prefetch is ISSUED here: left to the scheduler it sinks to the end of the layer in front of it)
   {
     f32x4 c0 = ld4(vq + V_B1 * 32), c1 = ld4(vq + V_B1 * 32 + 4);
     // K = 4 with two entries used: the chain is fma(W[i][1], y, fma(W[i][0], x, b)) then twice + 0 * 0 (exact)
@@ -447,6 +450,7 @@ __device__ __forceinline__ void encode_tile16_stream(float w1a, float w1b, const
   }
   __builtin_amdgcn_sched_barrier(0);
   load_layer(wls16, 1, lane, wb);
+  __builtin_amdgcn_sched_barrier(0);       // (the prefetch is ISSUED here: left to the scheduler it sinks to the end of the layer in front of it)
   {
     f32x4 c0 = ld4(vq + V_B2 * 32), c1 = ld4(vq + V_B2 * 32 + 4);
     layer16(wa, a, c0, c1);
@@ -455,6 +459,7 @@ __device__ __forceinline__ void encode_tile16_stream(float w1a, float w1b, const
   }
   __builtin_amdgcn_sched_barrier(0);
   load_layer(wls16, 2, lane, wa);
+  __builtin_amdgcn_sched_barrier(0);       // (the prefetch is ISSUED here: left to the scheduler it sinks to the end of the layer in front of it)
   {
     f32x4 c0 = ld4(vq + V_B3 * 32), c1 = ld4(vq + V_B3 * 32 + 4);
     layer16(wb, a, c0, c1);
@@ -462,6 +467,7 @@ __device__ __forceinline__ void encode_tile16_stream(float w1a, float w1b, const
   }
   __builtin_amdgcn_sched_barrier(0);
   load_layer(wls16, 3, lane, wb);
+  __builtin_amdgcn_sched_barrier(0);       // (the prefetch is ISSUED here: left to the scheduler it sinks to the end of the layer in front of it)
   {
     f32x4 c0 = ld4(vq + V_B4 * 32), c1 = ld4(vq + V_B4 * 32 + 4);
     layer16(wa, a, c0, c1);

@@ -56,7 +56,9 @@ extern "C" size_t npa_qp_shmem_bytes_path2(int T, int M, int fast, int scan) {
   // (mirrors the kernel's carve: REGROWS keeps 3 of the 6 u / d row arrays and 5 of the 9 hinge row arrays in LDS)
   const bool regrows = fast && M > 0 && M % 2 == 0 && T * M / 2 <= QP_THREADS && 5 * T - 2 <= QP_THREADS;
   const size_t rows = (regrows ? 3 : 6) * mcd + (regrows ? 5 : 9) * mfe;
-  const size_t mats = fast ? nu * (nu + 1) / 2 + nu * ldp : (size_t)T * 2 * ldp + 2 * nu * ldp;
+  // (SLIM, nrmp_qp_body.inc: the wide-scan instantiation folds the packed H and the packed factor L into one block)
+  const bool slim = fast && scan && T > 16;
+  const size_t mats = slim ? nu * (nu + 1) / 2 : (fast ? nu * (nu + 1) / 2 + nu * ldp : (size_t)T * 2 * ldp + 2 * nu * ldp);
   const size_t phi = (fast && scan) ? 0 : (size_t)T * 3 * ldp;
   size_t d = rows + phi + mats + 4 * (T * 3) + T * QP_ABC_LD + (((size_t)T * QP_ST_LD + 1) & ~(size_t)1) + nu + T + (nu + T) + nu + T + nu +
              ((fast && scan) ? 2 * (size_t)T : 0);

@@ -91,14 +91,14 @@ def test_argument_validation_without_gpu(lib):
 
 def test_qp_scene_block_fits_the_residency_the_design_counts_on(lib):
     """LDS per scene of the QP kernel (the launcher's own size function): 8 scenes per CU at (T, M) = (10, 10) -- the
-    block is what limits how many solves a CU holds --, 2 at T = 20, and the largest generic problem
-    still fits one CU."""
+    block is what limits how many solves a CU holds --, 4 at T = 20 (one wave per SIMD; round 5's 51 KB block
+    held 3: a quarter of the SIMDs without a QP wave), and the largest generic problem still fits one CU."""
     import ctypes as C
     f = lib.npa_qp_shmem_bytes_path
     f.restype, f.argtypes = C.c_size_t, [C.c_int, C.c_int, C.c_int]
     cu = 160 * 1024
     assert f(10, 10, 1) <= cu // 8
-    assert f(20, 10, 1) <= cu // 2
+    assert f(20, 10, 1) <= cu // 4
     assert f(21, 32, 0) <= cu and f(10, 0, 0) <= cu // 6
     assert f(10, 10, 0) > f(10, 10, 1)              # the generic instantiation keeps every row array in LDS
 

@@ -459,6 +459,51 @@ def test_key_nominated_selection_equals_exact_key_selection(cfgname, B, mode):
         assert np.array_equal(r[k], e[k]), k
 
 
+@pytest.mark.parametrize("shape", ["pentagon", "trapezoid"])
+def test_general_polygon_selection_equals_exact_keys(shape):
+    """Polygons that are NOT axis-aligned boxes: the key pass ranks every point on the distance to the polygon's BOUNDING BOX (a
+    lower bound of g with g <= key + S, select_geo_body.inc) and U, the far threshold and the band ranges all carry S.  `pentagon`:
+    an irregular rotated 5-edge polygon (no table filter, no merged-launch instantiation: those exist for E = 4 and 8; quick-fit
+    checkpoint of tests/golden/make_poly5_checkpoint.py); `trapezoid`: the reference's shipped polygon_robot (E = 4 but not a box:
+    the table filter on top of the box key).  Rows bitwise those of the exact-key build, on corridor scenes and on a cloud packed
+    into the band between the polygon and its bounding box -- inside the box, outside the polygon, where the box key is 0."""
+    import dataclasses
+    from gpu_helpers import make_gpu_pan
+    if shape == "pentagon":
+        verts = [[-0.9, -0.7], [0.5, -1.1], [1.6, -0.1], [0.7, 1.0], [-0.8, 0.6]]
+        cfg = dataclasses.replace(CONFIGS["diff_1k_T10_K10"], name="poly5_2k", n_points=2000, checkpoint="poly5",
+                                  robot=dict(kinematics="diff", vertices=verts, max_speed=[8, 1], max_acce=[8, 3]))
+    else:
+        cfg = dataclasses.replace(CONFIGS["polygon_5k_T10_K10"], n_points=2000)
+        verts = cfg.robot["vertices"]
+    exact = _with_env({"NPA_DUNE_FP32KEYS": "1"}, lambda: make_gpu_pan(cfg))
+    pan = _with_env({"NPA_KEY_TERMS": "4"}, lambda: make_gpu_pan(cfg))
+    assert pan.key_mode()["key_terms"] == 4 and exact.key_mode()["key_terms"] == 0
+    print(shape, pan.key_mode(), pan.geo_report())
+    B = 16
+    batch = make_batch(cfg, 41000, B)
+    r, e = _stage_np(pan, batch), _stage_np(exact, batch)
+    for k in ("mu", "lam", "pts", "dist", "count"):
+        assert np.array_equal(r[k], e[k]), k
+    # points between the polygon and its bounding box, in the robot frame of the FIRST pose of every scene (the later slices see
+    # them drift out), plus the scene's own cloud behind them
+    v = np.asarray(verts, np.float64)
+    lo, hi = v.min(0), v.max(0)
+    rng = np.random.default_rng(3)
+    pts = batch["points"].copy()
+    for b in range(B):
+        c, s = np.cos(batch["nom_s"][b, 2, 0]), np.sin(batch["nom_s"][b, 2, 0])
+        q = rng.uniform(lo - 0.02, hi + 0.02, (600, 2))
+        gx = batch["nom_s"][b, 0, 0] + c * q[:, 0] - s * q[:, 1]
+        gy = batch["nom_s"][b, 1, 0] + s * q[:, 0] + c * q[:, 1]
+        pts[b, 0, :600], pts[b, 1, :600] = gx, gy
+    batch2 = dict(batch, points=pts)
+    r, e = _stage_np(pan, batch2), _stage_np(exact, batch2)
+    for k in ("mu", "lam", "pts", "dist", "count"):
+        assert np.array_equal(r[k], e[k]), k
+    assert pan.audit()["violations"] == 0
+
+
 def test_badly_fitting_checkpoint_falls_back_to_network_keys():
     """A checkpoint whose distance is far from the geometry (the quick-fit E = 8 stand-in of round 1: 0.6 m off next to
     the robot) must not get geometric keys: npa_create measures its margin above the 0.15 m cap and keeps network keys,

@@ -1,5 +1,5 @@
-"""PMC evidence for bench.py's roofline object, per kernel, tracked: writes gpurun_out/r05/pmc_<workload>.json (copy it to
-profiles/r05_pmc.json).
+"""PMC evidence for bench.py's roofline object, per kernel, tracked: writes gpurun_out/r06/pmc_<workload>.json (copy it to
+profiles/r06_pmc.json; other workloads: profiles/r06_pmc_<tag>.json).
 
     python tests/tools/pmc_collect.py [workload]            # on the GPU box
 
@@ -168,8 +168,8 @@ def main():
                                          "same command; per_iteration = slope, per_solve = intercept / scenes"}
     except Exception as e:          # (the record stays usable without the fit: bench.py then scales the launch average)
         res["qp_flops_model_error"] = repr(e)
-    os.makedirs(os.path.join(ROOT, "gpurun_out", "r05"), exist_ok=True)
-    json.dump(res, open(os.path.join(ROOT, "gpurun_out", "r05", f"pmc_{workload}.json"), "w"), indent=1)
+    os.makedirs(os.path.join(ROOT, "gpurun_out", "r06"), exist_ok=True)
+    json.dump(res, open(os.path.join(ROOT, "gpurun_out", "r06", f"pmc_{workload}.json"), "w"), indent=1)
     print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "counters"} for k, v in res["kernels"].items()}, indent=1))
 
 
