@@ -226,17 +226,6 @@ int npa_forward_begin(npa_handle *h, int batch, int n_stride,
                       void *stream, int flags);
 int npa_forward_iter(npa_handle *h, int k);
 int npa_forward_end(npa_handle *h);
-/* Between npa_forward_begin and npa_forward_end, instead of the iter_num calls of npa_forward_iter: the whole loop of
- * PAN.forward (pan.py:128-145) as ONE launch in which a wave keeps its scene for all iterations (csrc/pan_scene.hip) -- an
- * EXPERIMENT on record: only in a library built with NPA_EXPERIMENTS=1 (the product build always returns 0), when the handle
- * was created with NPA_SCENE_KERNEL=1 and the call qualifies (points given, geometric keys, exact rows, a register-resident
- * solve: (T, M) = (10, 10) or (20, 10), at least NPA_SCENE_MIN_BATCH = 64 scenes).  Returns 1 when the launch went out (call
- * npa_forward_end next), 0 when the call does not qualify (iterate with npa_forward_iter), < 0 on an error.  iters = PAN
- * iterations to run, 1 .. iter_num (<= 0: iter_num).  What is guaranteed against the iterated form: rows, distances and
- * iteration counts equal, controls equal to rounding (the same statements inside another kernel contract differently:
- * <= 1e-6 on all but chaotic scenes) -- NOT bitwise.  Measured slower than the iterated form. */
-int npa_forward_scene(npa_handle *h, int iters);
-
 /* A burst of n INDEPENDENT forward calls -- n planners of the reference (one PAN.forward each, pan.py:109-147), one handle, one
  * stream and one argument set per call -- enqueued BREADTH-FIRST: the staging launch of every call, then PAN iteration 0 of
  * every call, then iteration 1, ...  The launches and the results are those of n npa_forward_batch_flags calls in a row;

@@ -66,7 +66,6 @@ SYMBOLS = {
     "npa_forward_batch_flags": (_I, [_P, _I, _I] + [_P] * 13 + [_P, _SZ, _P, _SZ, _P, _I]),
     "npa_forward_iter": (_I, [_P, _I]),
     "npa_forward_end": (_I, [_P]),
-    "npa_forward_scene": (_I, [_P, _I]),
     "npa_forward_batch_group": (_I, [_I, C.POINTER(NpaForwardCall), _I]),
     "npa_forward_group_merged": (_I, [_I, C.POINTER(NpaForwardCall)]),
     "npa_dune_stage": (_I, [_P, _I, _I] + [_P] * 9 + [_P]),

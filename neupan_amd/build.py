@@ -12,11 +12,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libneupan_amd.so")
-# The product build.  NPA_EXPERIMENTS=1 in the environment adds the experiments on record (the forward call
-# as one launch, the scene-wide selection, the active-set launch, the first form of the geometric selection) and their knobs.
+# The product build.  NPA_EXPERIMENTS=1 in the environment adds the experiments on record (the active-set
+# launch, the first form of the geometric selection) and their knobs.
 EXPERIMENTS = os.environ.get("NPA_EXPERIMENTS", "0") not in ("", "0")
 SOURCES = ["dune.hip", "nrmp_qp.hip", "frontend.hip", "dune_labels.hip", "c_api.hip", "serve_group.hip"] + \
-          (["aset_reduce.hip", "pan_scene.hip"] if EXPERIMENTS else [])
+          (["aset_reduce.hip"] if EXPERIMENTS else [])
 # -ffp-contract=fast-honor-pragmas is hipcc's default for device code, stated here so that it is the BUILD's property, not the
 # compiler's: the bit-exact legs (A / B / C, fa against the reference's tensors) are written with __f*_rn intrinsics where the
 # reference rounds every operation, and with explicit fmaf where it does not

@@ -36,21 +36,16 @@ extern "C" hipError_t npa_launch_select_geo(const DevParams& P, const float* wpa
                                             unsigned audit_seed, float margin_scale, int rows_bf16, hipStream_t stream,
                                             hipEvent_t ev_start, hipEvent_t ev_stop);
 // Experiments on record (measured slower than the default path, or not finished) are compiled only with
-// -DNPA_EXPERIMENTS (NPA_EXPERIMENTS=1 python -m neupan_amd.build): the forward call as one launch (pan_scene.hip), the selection
-// with one wave per scene (select_scene.h), the active-set launch in front of the interior-point launch (aset_reduce.*), the
-// first form of the geometric selection.  The default build has neither their kernels nor their environment knobs.
+// -DNPA_EXPERIMENTS (NPA_EXPERIMENTS=1 python -m neupan_amd.build): the active-set launch in front of the interior-point launch
+// (aset_reduce.*), the first form of the geometric selection.  The default build has neither their kernels nor their environment
+// knobs.  (Round 6 retired the two one-launch experiments -- the forward call as one launch, the selection with one wave per
+// scene: a wave that walks the ten slices of its scene one after the other cannot win where launches are cheap and the chip is
+// empty, and lost 2 x where it is full)
 #ifdef NPA_EXPERIMENTS
 #define NPA_VERSION_SUFFIX " +experiments"
 #else
 #define NPA_VERSION_SUFFIX ""
 #endif
-extern "C" int npa_select_scene_supported(int E, int T);
-extern "C" hipError_t npa_launch_select_scene(const DevParams& P, const float* wpack, int batch, int scene0, int t0, int n_stride,
-                                              const float* cur_s, const float* points, const float* vel, const int* n_points,
-                                              const int* flags, const float* trig, float* mu_sorted, float* lam_sorted,
-                                              float* pts_sorted, float* dist_sorted, int* count, unsigned* stats, int debug,
-                                              unsigned* audit, unsigned audit_thresh, unsigned audit_seed, float margin_scale,
-                                              hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);
 extern "C" hipError_t npa_launch_select(const DevParams& P, const float* wpack, int batch, int scene0, int t0,
                                         int n_stride, const float* cur_s, const float* points, const float* vel,
                                         const int* n_points, const int* flags, const unsigned* gkeys,
@@ -213,11 +208,7 @@ struct npa_handle {
   // NPA_QP_ASET_FROM moves its first iteration.
   bool aset_auto = true, qp_generic = false;
   int aset_small_batch = 0, aset_from_iter = 4;
-  // NPA_SCENE_KERNEL=1: forward calls of at least scene_min_batch scenes run as ONE launch in which a wave keeps its scene for
-  // all K iterations (pan_scene.hip; opt-in: measured, not the default).  NPA_SCENE_MIN_BATCH moves the threshold.
-  bool select_scene = false;             // NPA_SELECT_SCENE=1: the selection stage with one wave per scene and shared passes (select_scene.h)
-  bool scene_kernel = false, qp_scan_wide = true;          // (qp_scan_wide: NPA_QP_NOSCAN_WIDE unset, the T = 20 instantiation the scene kernel holds)
-  int scene_min_batch = 64;
+  bool qp_scan_wide = true;              // (NPA_QP_NOSCAN_WIDE unset: the wide-scan T = 20 instantiation; experiments build only otherwise)
 };
 
 extern "C" const char* npa_last_error(void) { return g_err.c_str(); }
@@ -225,15 +216,6 @@ extern "C" const char* npa_last_error(void) { return g_err.c_str(); }
 #define NPA_HIPCC_VERSION "unknown"
 #endif
 extern "C" const char* npa_version(void) { return "neupan_amd 0.3 (gfx950, hipcc " NPA_HIPCC_VERSION ")" NPA_VERSION_SUFFIX; }
-#ifndef NPA_EXPERIMENTS
-extern "C" int npa_select_scene_supported(int, int) { return 0; }
-extern "C" hipError_t npa_launch_select_scene(const DevParams&, const float*, int, int, int, int, const float*, const float*, const float*,
-                                              const int*, const int*, const float*, float*, float*, float*, float*, int*, unsigned*, int,
-                                              unsigned*, unsigned, unsigned, float, hipStream_t, hipEvent_t, hipEvent_t) {
-  return hipErrorInvalidValue;
-}
-#endif
-
 static int mdim(const DevParams& P) { return P.M > 0 ? P.M : 1; }
 // per-slice stride of the key buffer inside the workspace: none with geometric keys (select_kernel keeps them in LDS)
 static int kstride(const npa_handle* h) { return h->key_terms == 4 ? 0 : h->P.key_stride; }
@@ -541,9 +523,6 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
   h->qp_scan_wide = getenv("NPA_QP_NOSCAN_WIDE") == nullptr;
   P.qp_aset = (getenv("NPA_QP_ASET") != nullptr && atoi(getenv("NPA_QP_ASET")) != 0) ? 1 : 0;
   h->aset_auto = getenv("NPA_QP_ASET") == nullptr;
-  h->scene_kernel = getenv("NPA_SCENE_KERNEL") != nullptr && atoi(getenv("NPA_SCENE_KERNEL")) != 0;
-  h->select_scene = getenv("NPA_SELECT_SCENE") != nullptr && atoi(getenv("NPA_SELECT_SCENE")) != 0;
-  if (const char* env = getenv("NPA_SCENE_MIN_BATCH")) { int v = atoi(env); if (v >= 1) h->scene_min_batch = v; }
   if (const char* env = getenv("NPA_QP_ASET_SMALL")) { int v = atoi(env); if (v >= 0) h->aset_small_batch = v; }
   if (const char* env = getenv("NPA_QP_ASET_FROM")) { int v = atoi(env); if (v >= 1) h->aset_from_iter = v; }
   if (const char* env = getenv("NPA_QP_ASET_MIN_BATCH")) { int v = atoi(env); if (v >= 1) h->aset_min_batch = v; }
@@ -755,8 +734,7 @@ extern "C" int npa_create(const npa_config* cfg, const npa_dune_weights* w, npa_
     }
     h->key_safety = safety;
     if (!pack_hit && !geo_ok && e == hipSuccess && forced != 0 && forced != 4) e = calibrate_network_keys(h, forced);
-    // word 0: overflow tiles of the selection (key policy); words 1, 2: slices the scene-wide selection handed to the per-slice
-    // body / took itself (select_scene.h, NPA_SELECT_SCENE=1; npa_dbg_select_stats)
+    // word 0: overflow tiles of the selection (key policy); words 1 .. 3 spare (npa_dbg_select_stats)
     if (e == hipSuccess) e = hipMalloc(&h->sel_stats_dev, 4 * sizeof(unsigned));
     if (e == hipSuccess) e = hipMemset(h->sel_stats_dev, 0, 4 * sizeof(unsigned));
     if (e == hipSuccess) e = hipHostMalloc(&h->sel_stats_host, sizeof(unsigned), hipHostMallocDefault);
@@ -1084,12 +1062,7 @@ extern "C" int npa_dune_stage(npa_handle* h, int batch, int n_stride, const floa
     HIP_TRY(npa_launch_encode(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr,
                               (unsigned*)h->stage_cand, trig, h->n_cu, 5, h->key_terms, (hipStream_t)stream,
                               nullptr, nullptr));
-  if (geo && !h->select_v1 && h->select_scene && !h->rows_bf16 && npa_select_scene_supported(h->P.E, h->P.T))
-    HIP_TRY(npa_launch_select_scene(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr, trig,
-                                    mu_sorted, lam_sorted, pts_sorted, dist_sorted, count, h->sel_stats_dev, h->sel_debug,
-                                    h->audit_dev, h->audit_thresh, h->launch_seq++, h->margin_scale, (hipStream_t)stream,
-                                    nullptr, nullptr));
-  else if (geo && !h->select_v1)
+  if (geo && !h->select_v1)
     HIP_TRY(npa_launch_select_geo(h->P, h->wpack, batch, 0, 0, n_stride, nom_s, points, velocities, n_points, nullptr, trig,
                                   mu_sorted, lam_sorted, pts_sorted, dist_sorted, count, h->sel_stats_dev, h->sel_debug,
                                   h->rows_bf16 ? nullptr : h->audit_dev, h->audit_thresh, h->launch_seq++, h->margin_scale,
@@ -1298,18 +1271,18 @@ extern "C" int npa_group_mergeable(int n, const npa_forward_call* calls) {
   if (!h0) return 0;
   const DevParams& P = h0->P;
   const bool dune0 = P.M > 0 && calls[0].points != nullptr;
-  if (dune0 && !(h0->key_terms == 4 && !h0->select_v1 && !h0->select_scene && !h0->rows_bf16 && npa_select_geo_group_supported(P.E))) return 0;
+  if (dune0 && !(h0->key_terms == 4 && !h0->select_v1 && !h0->rows_bf16 && npa_select_geo_group_supported(P.E))) return 0;
   if (!npa_qp_group_supported(P.T, P.M) || h0->qp_generic || P.qp_aset || (h0->aset_auto && calls[0].batch <= h0->aset_small_batch) ||
-      h0->scene_kernel || h0->key_auto)
+      h0->key_auto)
     return 0;
   if (calls[0].iter_num < 1 || calls[0].iter_num > P.K) return 0;       // (the call-by-call path reports that)
   for (int c = 0; c < n; ++c) {
     const npa_handle* h = calls[c].h;
     if (!h || calls[c].stream != calls[0].stream || calls[c].batch != calls[0].batch || calls[c].iter_num != calls[0].iter_num ||
         h->device != h0->device || memcmp(&h->P, &P, sizeof(DevParams)) != 0 || h->key_terms != h0->key_terms ||
-        h->select_v1 != h0->select_v1 || h->select_scene != h0->select_scene || h->rows_bf16 != h0->rows_bf16 || h->keys_bf16 != h0->keys_bf16 ||
+        h->select_v1 != h0->select_v1 || h->rows_bf16 != h0->rows_bf16 || h->keys_bf16 != h0->keys_bf16 ||
         h->sel_debug != h0->sel_debug || h->audit_thresh != h0->audit_thresh || h->margin_scale != h0->margin_scale ||
-        h->qp_generic != h0->qp_generic || h->qp_warm != h0->qp_warm || h->scene_kernel || h->key_auto ||
+        h->qp_generic != h0->qp_generic || h->qp_warm != h0->qp_warm || h->key_auto ||
         (P.M > 0 && calls[c].points != nullptr) != dune0 || (calls[c].out_d == nullptr) != (calls[0].out_d == nullptr))
       return 0;
   }
@@ -1451,12 +1424,7 @@ extern "C" int npa_forward_iter(npa_handle* h, int k) {
                                 ev ? ev->a : nullptr, ev ? ev->b : nullptr));
     }
     EventPair* evs = next_event(h, h->ev_sel, h->n_sel);
-    if (geo && !h->select_v1 && h->select_scene && !h->rows_bf16 && npa_select_scene_supported(P.E, P.T))
-      HIP_TRY(npa_launch_select_scene(P, h->wpack, batch, 0, t0, pc->n_stride, cur_s, pc->points, pc->velocities, pc->n_points,
-                                      flags, ws + L.trig, mu, lam, pts, dist, count, h->sel_stats_dev, 0, h->audit_dev,
-                                      h->audit_thresh, h->launch_seq++, h->margin_scale, stream, evs ? evs->a : nullptr,
-                                      evs ? evs->b : nullptr));
-    else if (geo && !h->select_v1)
+    if (geo && !h->select_v1)
       HIP_TRY(npa_launch_select_geo(P, h->wpack, batch, 0, t0, pc->n_stride, cur_s, pc->points, pc->velocities, pc->n_points,
                                     flags, ws + L.trig, mu, lam, pts, dist, count, h->sel_stats_dev, 0,
                                     h->rows_bf16 ? nullptr : h->audit_dev, h->audit_thresh, h->launch_seq++, h->margin_scale,
@@ -1500,72 +1468,12 @@ extern "C" int npa_forward_end(npa_handle* h) {
   return NPA_OK;
 }
 
-// ---- the whole forward call as one launch (pan_scene.hip), opt-in -----------------------------------------------------
-#ifndef NPA_EXPERIMENTS
-static int npa_pan_scene_supported(int, int, int) { return 0; }
-static hipError_t npa_launch_pan_scene(const DevParams&, const float*, int, int, const float*, const float*, const int*, float*, float*, float*,
-                                       const float*, const float*, float*, float*, float*, float*, int*, float*, float*, float*, float*,
-                                       int*, float*, int*, float*, double*, double*, float*, int, int, unsigned*, unsigned*, unsigned,
-                                       unsigned, float, hipStream_t, hipEvent_t, hipEvent_t) {
-  return hipErrorInvalidValue;
-}
-#else
-extern "C" int npa_pan_scene_supported(int E, int T, int M);
-extern "C" hipError_t npa_launch_pan_scene(const DevParams& P, const float* wpack, int batch, int n_stride, const float* points,
-                                           const float* vel, const int* n_points, float* cur_s, float* cur_u, float* cur_d,
-                                           const float* ref_s, const float* ref_us, float* mu, float* lam, float* pts,
-                                           float* dist, int* count, float* out_s, float* out_u, float* out_d, float* out_md,
-                                           int* out_iters, float* out_np, int* flags, float* state, double* qp_info,
-                                           double* warm, float* trig, int iters, int debug, unsigned* stats, unsigned* audit,
-                                           unsigned audit_thresh, unsigned audit_seed, float margin_scale, hipStream_t stream,
-                                           hipEvent_t ev_start, hipEvent_t ev_stop);
-#endif
-// the pending call (begun) qualifies: the default selection (geometric keys, exact rows) and the register-resident interior-
-// point solve, nothing that needs a launch of its own between the two
-static bool scene_kernel_applies(npa_handle* h) {
-  const PendingCall& pc = h->pc;
-  const DevParams& P = h->P;
-  return h->scene_kernel && pc.active && pc.dune && pc.batch >= h->scene_min_batch && h->key_terms == 4 && !h->select_v1 &&
-         !h->rows_bf16 && !h->qp_generic && !P.qp_aset && !(h->aset_auto && pc.batch <= h->aset_small_batch) && pc.out_d &&
-         npa_pan_scene_supported(P.E, P.T, P.M) && (P.T != 20 || h->qp_scan_wide);
-}
-static int forward_scene_launch(npa_handle* h, int iters) {
-  std::lock_guard<std::mutex> lock(h->mu);
-  PendingCall* pc = &h->pc;
-  const DevParams& P = h->P;
-  const int batch = pc->batch;
-  const ScratchLayout L = npa_scratch_layout(batch, P.T, mdim(P), P.E, kstride(h));
-  float* ws = pc->ws;
-  EventPair* ev = next_event(h, h->ev_qp, h->n_qp);       // (profile: the one launch is booked under the solve's events)
-  const unsigned seq = h->launch_seq;
-  h->launch_seq += (unsigned)iters;
-  HIP_TRY(npa_launch_pan_scene(P, h->wpack, batch, pc->n_stride, pc->points, pc->velocities, pc->n_points, ws + L.cur_s,
-                               ws + L.cur_u, ws + L.cur_d, pc->ref_s, pc->ref_us, ws + L.mu, ws + L.lam, ws + L.pts, ws + L.dist,
-                               (int*)(ws + L.count), pc->out_s, pc->out_u, pc->out_d, pc->out_md, pc->out_iters, pc->out_np,
-                               (int*)(ws + L.flags), pc->state, (double*)(ws + L.qp_info),
-                               h->qp_warm ? (double*)(ws + L.warm) : nullptr, ws + L.trig, iters, 0, h->sel_stats_dev,
-                               h->audit_dev, h->audit_thresh, seq, h->margin_scale, pc->stream, ev ? ev->a : nullptr,
-                               ev ? ev->b : nullptr));
-  return NPA_OK;
-}
-
-// (diagnostics, not in the header: words 1, 2 of the selection's statistics -- slices the scene-wide selection handed to the
-// per-slice body / finished itself since the handle was created; synchronises the device)
+// (diagnostics, not in the header: the four words of the selection's statistics since the handle was created; synchronises the device)
 extern "C" int npa_dbg_select_stats(npa_handle* h, unsigned out[4]) {
   if (!h || !out || !h->sel_stats_dev) return NPA_E_ARG;
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(out, h->sel_stats_dev, 4 * sizeof(unsigned), hipMemcpyDeviceToHost));
   return NPA_OK;
-}
-
-extern "C" int npa_forward_scene(npa_handle* h, int iters) {
-  if (!h) return fail(NPA_E_ARG, "npa_forward_scene: null handle");
-  if (!h->pc.active) return fail(NPA_E_ARG, "npa_forward_scene: no forward in progress on this handle");
-  if (iters <= 0) iters = h->P.K;
-  if (iters > h->P.K) return fail(NPA_E_ARG, "npa_forward_scene: more iterations than the handle's iter_num");
-  if (!scene_kernel_applies(h)) return 0;
-  const int rc = forward_scene_launch(h, iters);
-  return rc == NPA_OK ? 1 : rc;
 }
 
 extern "C" int npa_forward_batch_flags(npa_handle* h, int batch, int n_stride, const float* nom_s, const float* nom_u,
@@ -1579,9 +1487,6 @@ extern "C" int npa_forward_batch_flags(npa_handle* h, int batch, int n_stride, c
                              out_u, out_d, out_min_distance, out_iters, out_nrmp_points, workspace, workspace_bytes,
                              state, state_bytes, stream_, flags);
   if (rc != NPA_OK) return rc;
-  rc = npa_forward_scene(h, 0);              // 1: the whole loop went out as one launch (opt-in, pan_scene.hip); 0: not this call
-  if (rc < 0) { npa_forward_end(h); return rc; }
-  if (rc == 1) return npa_forward_end(h);
   for (int k = 0; k < h->P.K; ++k) {
     rc = npa_forward_iter(h, k);
     if (rc != NPA_OK) { npa_forward_end(h); return rc; }

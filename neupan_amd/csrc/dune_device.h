@@ -1,5 +1,5 @@
 // dune_device.h -- device side of dune.hip up to and including select_geo_kernel (helpers, encoder, key and selection
-// kernels); the host launchers and the calibration kernels stay in dune.hip.  Included by dune.hip and by pan_scene.hip.
+// kernels); the host launchers and the calibration kernels stay in dune.hip.  Included by dune.hip.
 #pragma once
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -1,5 +1,5 @@
 // nrmp_qp_device.h -- device side of nrmp_qp.hip (constants, helpers, the kernel); the host launchers stay in nrmp_qp.hip.
-// Included by nrmp_qp.hip and by pan_scene.hip.  (No include guard games: each translation unit includes it once.)
+// Included by nrmp_qp.hip.  (No include guard games: each translation unit includes it once.)
 #pragma once
 #define QP_THREADS 64          // lanes cooperating on one scene (one wavefront)
 #ifndef NPA_QP_WAVES

@@ -81,17 +81,9 @@ extern "C" int npa_forward_batch_group(int n, const npa_forward_call* calls, int
                            a.workspace_bytes, a.state, a.state_bytes, a.stream, flags);
     if (rc != NPA_OK) break;                                          // (calls[begun] itself did not begin)
   }
-  // a call that runs as ONE launch (npa_forward_scene: opt-in scene kernel, all of the handle's iterations) needs no interleaving
-  unsigned long long whole = 0;                                       // (bit c: call c went out as one launch; n <= 64 checked below)
-  for (int c = 0; c < n && rc == NPA_OK; ++c) {
-    if (c >= 64) break;
-    const int r = npa_forward_scene(calls[c].h, calls[c].iter_num);
-    if (r < 0) rc = r;
-    else if (r == 1) whole |= 1ull << c;
-  }
   for (int k = 0; k < kmax && rc == NPA_OK; ++k)
     for (int c = 0; c < n && rc == NPA_OK; ++c)
-      if (k < calls[c].iter_num && !(c < 64 && (whole >> c & 1ull))) rc = npa_forward_iter(calls[c].h, k);
+      if (k < calls[c].iter_num) rc = npa_forward_iter(calls[c].h, k);
   for (int c = 0; c < begun; ++c) {
     const int e = npa_forward_end(calls[c].h);
     if (rc == NPA_OK) rc = e;

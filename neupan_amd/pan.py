@@ -150,9 +150,6 @@ class PAN(torch.nn.Module):
                                  "there is no CPU fallback")
         self.device = torch.device(device if device is not None else "cuda")
         self._lib = _lib.load()
-        # (the library reads its knobs when the handle is created; this one also decides whether forward_batch asks for the
-        # one-launch form at all, csrc/pan_scene.hip)
-        self._scene_kernel = os.environ.get("NPA_SCENE_KERNEL", "0") not in ("", "0")
 
         G = np.asarray(robot.G, dtype=np.float32)
         h = np.asarray(robot.h, dtype=np.float32).reshape(-1)
@@ -369,12 +366,8 @@ class PAN(torch.nn.Module):
         lib, h = self._lib, self._h
         with torch.cuda.device(self.device):
             try:
-                # 1: the loop went out as one launch (a handle created with NPA_SCENE_KERNEL=1, and the call qualifies)
                 # (self.iter_num, not the handle's creation-time K: the reference's PAN.iter_num is an attribute callers may lower)
-                whole = lib.npa_forward_scene(h, int(self.iter_num)) if self._scene_kernel else 0
-                if whole < 0:
-                    check(whole, "npa_forward_scene")
-                for k in range(0 if whole == 1 else self.iter_num):
+                for k in range(self.iter_num):
                     rc = lib.npa_forward_iter(h, k)
                     if rc:
                         check(rc, "npa_forward_iter")

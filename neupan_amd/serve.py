@@ -64,6 +64,7 @@ class ControlGatherer:
         self._pending = 0                        # rows of the current group handed to collect()
         self._cur_group = 0
         self._gloo = dist.get_backend() == "gloo"
+        self._last_waited = None
 
     # ------------------------------------------------------------------ indices
     def begin(self, n: int) -> int:
@@ -97,6 +98,37 @@ class ControlGatherer:
             self._staged_group[p][r] = g
             self._cv.notify_all()
 
+    def stage_many(self, idxs, opts, stream=None):
+        """stage() for several steps that ran on ONE stream (the steps of a merged launch chain finish together: their last
+        launch is the same): one stream switch, one fused copy (torch._foreach_copy_), one event for all their rows -- instead
+        of that per step.  (Measured, one rank under torch.distributed.run on the driver's 20-step region: the per-step form cost
+        8 % of the rate -- all of it host time on the issuing threads, `host_issue_ms_per_step` 0.05 -> 0.12 -- the communicator
+        itself nothing, profiles/r06_torchrun_overhead.txt.)"""
+        if not self.active or not idxs:
+            return
+        if not self.cuda or not hasattr(torch, "_foreach_copy_"):
+            for i, o in zip(idxs, opts):
+                self.stage(i, o, stream)
+            return
+        rows = [divmod(i, self.slots) for i in idxs]
+        gmax = max(g for g, _ in rows)
+        with self._cv:
+            self._cv.wait_for(lambda: self._flushed >= gmax - 1)
+            fls = {self._flush_ev[g & 1] for g, _ in rows if g >= 2}
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(st):
+            for fl in fls:
+                if fl is not None:
+                    st.wait_event(fl)
+            torch._foreach_copy_([self.stage_buf[g & 1][r] for g, r in rows], list(opts), non_blocking=True)
+            ev = self._copied[rows[0][0] & 1][rows[0][1]]
+            ev.record(st)
+        with self._cv:
+            for g, r in rows:
+                self._copied[g & 1][r] = ev
+                self._staged_group[g & 1][r] = g
+            self._cv.notify_all()
+
     # ------------------------------------------------------------------ the collecting thread (one, in step order)
     def collect(self, i: int, opt_u: torch.Tensor | None = None):
         """Hand step i to the gather.  Returns the gathered controls of that step, a (world, B, 2, T) view of the result
@@ -112,7 +144,10 @@ class ControlGatherer:
         with self._cv:
             self._cv.wait_for(lambda: self._staged_group[p][r] == g)
         if self.cuda:
-            self.comm.wait_event(self._copied[p][r])
+            ev = self._copied[p][r]
+            if ev is not self._last_waited:          # (rows staged by one stage_many share their event)
+                self.comm.wait_event(ev)
+                self._last_waited = ev
         self._pending += 1
         if r == self.slots - 1:
             self._flush(g)
@@ -236,8 +271,12 @@ class StepLoop:
         if not mine:
             return
         res = self.groups[w].issue(len(mine))
+        one_stream = self.streams is not None and len({self.streams[i % self.nfl] for i in mine}) == 1
+        if self.gatherer is not None and one_stream and hasattr(self.gatherer, "stage_many"):
+            # a merged chain: its steps finish together -- their controls are staged together
+            self.gatherer.stage_many([base + i for i in mine], [o["opt_u"] for o in res], self.streams[mine[0] % self.nfl])
         for i, o in zip(mine, res):
-            if self.gatherer is not None:
+            if self.gatherer is not None and not (one_stream and hasattr(self.gatherer, "stage_many")):
                 if self.streams is not None:
                     self.gatherer.stage(base + i, o["opt_u"], self.streams[i % self.nfl])
                 else:

@@ -1221,117 +1221,3 @@ def test_merged_group_launches_equal_call_by_call(cfgname, B, nfl, over):
     for j in range(nfl):
         for k in ref[j][0]:
             assert np.array_equal(o3[j][k], ref[j][0][k], equal_nan=True), (cfgname, "own streams", j, k)
-
-
-@pytest.mark.parametrize("cfgname,B,over", [("diff_1k_T10_K10", 256, {}), ("diff_1k_T10_K10", 80, {"iter_threshold": 0.1}),
-                                            ("dyna_4k_T10_K10", 64, {}), ("acker_2k_T20_K15", 64, {}), ("poly8_5k_T10_K10", 64, {})])
-@pytest.mark.experiments
-def test_scene_kernel_agrees_with_the_two_launch_path(cfgname, B, over):
-    """NPA_SCENE_KERNEL=1 (csrc/pan_scene.hip, opt-in): the whole K-iteration loop as ONE launch, a wave keeping its scene from
-    the first selection to the last stop test, against the default 2 K launches.  The two run the same statements (textual
-    includes) but NOT the same machine code: inside another kernel the compiler contracts other multiply-add pairs, a solve
-    ends a last bit away, and the PAN iteration carries that like any other +-1 ulp (verdict A / D territory).  So: the rows of
-    the selection, the distances and the iteration counts equal; controls equal to rounding on nearly every scene and within
-    the tolerance of the parity tests on all but the chaotic ones; every solve converged -- on repeated calls (state carried
-    over), ragged clouds with empty scenes, through forward_batch, a prepared step and a breadth-first group."""
-    import torch
-    from gpu_helpers import make_gpu_pan
-    from neupan_amd.pan import StepGroup
-    cfg = CONFIGS[cfgname]
-    two = make_gpu_pan(cfg, **over)
-    one = _with_env({"NPA_SCENE_KERNEL": "1"}, lambda: make_gpu_pan(cfg, **over))
-    batch = make_batch(cfg, 12000, B)
-    keys = ("nom_s", "nom_u", "ref_s", "ref_us", "points")
-    args = [batch[k] for k in keys] + [batch.get("velocities")]
-    n_pts = np.full(B, batch["points"].shape[2], dtype=np.int32)
-    n_pts[:6] = [0, 1, 7, 64, 65, 257]
-    early = over.get("iter_threshold", 0.0) > 0
-
-    def close(a, b, what):
-        du = np.abs(a["opt_u"].cpu().numpy().astype(np.float64) - b["opt_u"].cpu().numpy()).reshape(B, -1).max(1)
-        ds = np.abs(a["opt_s"].cpu().numpy().astype(np.float64) - b["opt_s"].cpu().numpy()).reshape(B, -1).max(1)
-        print(what, "controls: median %.2g, share <= 1e-6 %.3f, <= 1e-4 %.3f, max %.2g; states max %.2g" %
-              (np.median(du), (du <= 1e-6).mean(), (du <= 1e-4).mean(), du.max(), ds.max()))
-        assert np.isfinite(du).all() and np.isfinite(ds).all()
-        assert np.median(du) <= 1e-6 and (du <= 1e-4).mean() >= 0.9, what
-        ia, ib = a["iters"].cpu().numpy(), b["iters"].cpu().numpy()
-        assert (ia == ib).mean() >= (0.9 if early else 1.0), what
-        if not early:                               # (every scene ran K iterations from the same rows of iteration 0 ...)
-            same_rows = np.array_equal(a["min_distance"].cpu().numpy(), b["min_distance"].cpu().numpy(), equal_nan=True)
-            assert same_rows or (du > 1e-6).any(), what       # ... the first slice's nearest distance does not depend on the iterate
-    for rep in range(3):                               # (calls 2 and 3 start from the state the first one left)
-        a, b = two.forward_batch(*args), one.forward_batch(*args)
-        close(a, b, (cfgname, "call", rep))
-        q = one.last_qp_info()
-        assert (q[:, 3] == 0).all() and q[:, 1].max() <= 1e-9, rep
-    if early:
-        it = b["iters"].cpu().numpy()
-        print("iterations executed with the early exit on: min %d max %d" % (it.min(), it.max()))
-    a, b = two.forward_batch(*args, n_points=n_pts, reset_state=True), one.forward_batch(*args, n_points=n_pts, reset_state=True)
-    close(a, b, (cfgname, "ragged"))
-    assert np.isinf(b["min_distance"].cpu().numpy()[0])              # (the scene without points)
-    # the serving forms: one library call per step, and a breadth-first group of two planners
-    dev = torch.device("cuda", 0)
-    targs = [torch.from_numpy(x).to(dev) if x is not None else None for x in args]
-    s2 = two.make_step(*targs, reset_every_step=True)
-    s1 = one.make_step(*targs, reset_every_step=True)
-    ref = {k: v.clone() if isinstance(v, torch.Tensor) else v for k, v in s2().items()}
-    close(ref, s1(), (cfgname, "prepared step"))
-    other = _with_env({"NPA_SCENE_KERNEL": "1"}, lambda: make_gpu_pan(cfg, **over))
-    so = other.make_step(*targs, reset_every_step=True)
-    st = [torch.cuda.Stream(device=dev) for _ in range(2)]
-    torch.cuda.synchronize()
-    res = StepGroup([s1, so], st).issue()
-    torch.cuda.synchronize()
-    close(ref, res[0], (cfgname, "group member 0")); close(ref, res[1], (cfgname, "group member 1"))
-    assert np.array_equal(res[0]["opt_u"].cpu().numpy(), res[1]["opt_u"].cpu().numpy())     # (the same code on the same inputs)
-    assert one.audit()["violations"] == 0
-
-
-@pytest.mark.experiments
-@pytest.mark.parametrize("cfgname,B", [("diff_1k_T10_K10", 96), ("dyna_4k_T10_K10", 24), ("acker_2k_T20_K15", 24), ("poly8_5k_T10_K10", 12)])
-def test_scene_wide_selection_equals_the_per_slice_selection(cfgname, B):
-    """NPA_SELECT_SCENE=1 (csrc/select_scene.h, opt-in): the selection stage with ONE wave per scene -- the keys of all slices per
-    point in one pass, the candidates of all slices in a second one, the exact encoder over candidates of several slices packed
-    into full tiles (the frame a per-lane operand), the per-slice body for what it does not take -- against select_geo_kernel
-    (one wave per slice).  The nomination differs, the rows may not: any superset of the true nearest M ranked on the exact
-    (distance, index) keys gives the same rows, bitwise -- on random clouds, moving points, the car's 21 slices, the 8-edge
-    polygon, walls / blobs (more candidates than the ranking holds: per-slice body), ragged and empty clouds, and through a
-    whole forward call."""
-    import ctypes as C
-    from gpu_helpers import make_gpu_pan, wall_batch
-    cfg = CONFIGS[cfgname]
-    old = make_gpu_pan(cfg)
-    new = _with_env({"NPA_SELECT_SCENE": "1"}, lambda: make_gpu_pan(cfg))
-    batch = make_batch(cfg, 3000, B)
-    f = new._lib.npa_dbg_select_stats
-    f.restype, f.argtypes = C.c_int, [C.c_void_p, C.POINTER(C.c_uint)]
-
-    def stats():                                   # (slices for the per-slice body, slices the fast path finished) so far
-        st = (C.c_uint * 4)()
-        assert f(new._h, st) == 0
-        return int(st[1]), int(st[2])
-    s0 = stats()                                   # (the create-time self-test ran the stage too)
-    r, e = _stage_np(new, batch), _stage_np(old, batch)
-    for k in ("mu", "lam", "pts", "dist", "count"):
-        assert np.array_equal(r[k], e[k]), k
-    s1 = stats()
-    slow, fast = s1[0] - s0[0], s1[1] - s0[1]
-    assert slow + fast == B * (cfg.T + 1) and fast > 0          # every slice went one way or the other; the fast path is used
-    if cfgname == "diff_1k_T10_K10":
-        assert fast >= 0.9 * B * (cfg.T + 1)
-        wb = wall_batch(cfg, 32)
-        r, e = _stage_np(new, wb, n_points=wb["n_points"]), _stage_np(old, wb, n_points=wb["n_points"])
-        for k in ("mu", "lam", "pts", "dist", "count"):
-            assert np.array_equal(r[k], e[k]), ("walls", k)
-        rb = make_batch(cfg, 3100, 9)
-        n_pts = np.array([0, 1, 5, 63, 64, 65, 255, 256, 257], dtype=np.int32)
-        r, e = _stage_np(new, rb, n_points=n_pts), _stage_np(old, rb, n_points=n_pts)
-        assert np.array_equal(r["count"], e["count"])
-        for k in ("mu", "lam", "pts", "dist"):
-            assert np.array_equal(r[k][1:], e[k][1:]), ("ragged", k)
-    args = [batch[k] for k in ("nom_s", "nom_u", "ref_s", "ref_us", "points")] + [batch.get("velocities")]
-    a, b = old.forward_batch(*args), new.forward_batch(*args)
-    for k in ("opt_s", "opt_u", "opt_d", "min_distance", "iters", "nrmp_points"):
-        assert np.array_equal(a[k].cpu().numpy(), b[k].cpu().numpy(), equal_nan=True), ("forward", k)
-    assert new.audit()["violations"] == 0
