@@ -721,7 +721,8 @@ __device__ __forceinline__ void load_weights(const float* __restrict__ wpack, in
 // 4 waves per SIMD at <= 72 VGPRs and a single LDS copy of the weight fragments, which leaves room
 // (216 VGPRs per SIMD, 130 KB LDS) for a QP workgroup of another batch to be co-resident.
 template <int E, int SPLIT, int WAVES>
-__global__ __attribute__((amdgpu_flat_work_group_size(64 * WAVES, 64 * WAVES), amdgpu_waves_per_eu(WAVES >= 8 ? 7 : 4)))
+// (exact keys for six to eight edges: three waves per SIMD -- the canonical reductions cost the 128-register build 6 - 10 spills)
+__global__ __attribute__((amdgpu_flat_work_group_size(64 * WAVES, 64 * WAVES), amdgpu_waves_per_eu(WAVES >= 8 ? 7 : ((SPLIT == 0 && E >= 6) ? 3 : 4))))
 void dune_kernel(
     DevParams P, const float* __restrict__ wpack, int n_stride, const float* __restrict__ cur_s,
     const float* __restrict__ points, const float* __restrict__ vel, const int* __restrict__ n_points,

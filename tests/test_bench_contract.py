@@ -13,7 +13,7 @@ def _line(name):
 
 
 def test_default_bench_line_carries_every_contract_field():
-    d = _line("r05_bench_full.json")             # (the full record of the default command; its compact last line is r05_bench.json)
+    d = _line("r06_bench_full.json")             # (the full record of the default command; its compact last line is r06_bench.json)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -69,26 +69,37 @@ def test_default_bench_line_carries_every_contract_field():
     assert ee["iter_threshold"] == 0.1 and 2 <= ee["iterations_mean"] < d["config"]["K"] and ee["plans_per_s"] > d["value"]
     assert 0 < hh["plans_per_s"] < d["value"] and hh["bytes_per_step"] > 256 * 8 * 1000
     # the compact last line of the same run: what the driver parses
-    c = _line("r05_bench.json")
+    c = _line("r06_bench.json")
     assert len(json.dumps(c)) <= 6144 and c["value"] == d["value"] and c["roofline"]["frac"] == d["roofline"]["frac"]
     assert c["cpu_baseline"]["value"] == d["cpu_baseline"]["value"] and c["parity"]["A"] is True and c["parity"]["D_stalled"] == 0
+    # round 6: the closed-loop cycle rides in the line; the metric's own schedule (one launch chain per
+    # 256-scene step) sits in the part of the compact line that is never dropped, next to the scenes per merged launch
+    fc = x["fleet_cycle"]
+    assert fc["robots"] == 256 and fc["shipped"]["K"] == 2 and fc["k10"]["K"] == d["config"]["K"]
+    assert fc["shipped"]["robot_cycles_per_s"] > fc["k10"]["robot_cycles_per_s"] > 0 and 0 < fc["k10"]["front_end_share"] < fc["shipped"]["front_end_share"] < 1
+    assert c["extra"]["fleet_cycle"]["k10"]["robot_cycles_per_s"] == fc["k10"]["robot_cycles_per_s"]
+    assert c["config"]["scenes_per_launch"] == 1280 and 0 < c["config"]["plans_per_s_one_chain_per_step"] < c["value"]
 
 
 def test_driver_flag_line_is_the_same_contract():
     """What the round driver runs (--steps 20 --warmup 5): one wave of chains, lower by its issue ramp."""
-    d, full = _line("r05_bench_driver_flags.json"), _line("r05_bench.json")
-    assert len(open(os.path.join(ROOT, "profiles", "r05_bench_driver_flags.json")).read().strip()) <= 6144      # the line the driver parses
+    d, full = _line("r06_bench_driver_flags.json"), _line("r06_bench.json")
+    assert len(open(os.path.join(ROOT, "profiles", "r06_bench_driver_flags.json")).read().strip()) <= 6144      # the line the driver parses
     assert d["steps"] == 20 and d["warmup"] == 5 and d["metric"] == full["metric"] and d["config"]["workload"] == full["config"]["workload"]
     assert 0.7 * full["value"] <= d["value"] <= full["value"]
     for k in ("roofline", "cpu_baseline", "parity", "extra"):
         assert k in d, k
     assert d["roofline"]["pmc"]["current"]["nrmp_qp_group_kernel"] is True and d["roofline"]["frac"] > 0.03
-    t = _line("r05_bench_torchrun1.json")
-    assert t["n_gpus"] == 1 and t["value"] >= 0.9 * full["value"]          # one rank with a live RCCL communicator: within 10 %
+    t = _line("r06_bench_torchrun1.json")
+    assert t["n_gpus"] == 1 and t["value"] >= 0.93 * full["value"]         # one rank with a live RCCL communicator and its gathers
+    # round 6: the same under the driver's flags -- the per-GPU value an N-GPU run multiplies (it lost 10 % to host-side staging
+    # of the gathered controls in round 5)
+    t20 = _line("r06_bench_torchrun1_driver_flags.json")
+    assert t20["n_gpus"] == 1 and t20["steps"] == 20 and t20["value"] >= 0.93 * d["value"]
 
 
 def test_tracked_pmc_file_matches_the_built_kernels():
-    """bench.py prices the roofline with a kernel's record of profiles/r05_pmc.json only while the code the tree builds IS
+    """bench.py prices the roofline with a kernel's record of profiles/r06_pmc.json only while the code the tree builds IS
     the code that was measured: by the fingerprint of the kernel's machine code (bench.kernel_isa_hash: function bytes +
     kernel descriptor of the measured instantiation, read from the built library), or -- where the ROCm LLVM tools are not
     installed -- by the hash of the source files the kernel is built from.  An edit of the dominant kernel that changes its
@@ -97,7 +108,7 @@ def test_tracked_pmc_file_matches_the_built_kernels():
     from neupan_amd import build
     build.build(force=False, verbose=False)
     pj = bench.load_pmc(bench.WORKLOAD)
-    assert pj["_file"] == "profiles/r05_pmc.json"              # the newest tracked record is the one the tree is priced with
+    assert pj["_file"] == "profiles/r06_pmc.json"              # the newest tracked record is the one the tree is priced with
     for name in ("nrmp_qp_kernel", "nrmp_qp_group_kernel", "select_geo_kernel", "select_geo_group_kernel"):
         k = pj["kernels"][name]
         isa = bench.kernel_isa_hash(k["kernel"])

@@ -250,5 +250,27 @@ def test_coalesced_gather_over_rccl_on_one_gpu():
         v = g.collect(base, outs[1])
         g.join(); torch.cuda.synchronize()
         assert torch.all(v == 7.0) and g.collectives == 4
+        # stage_many (round 6): the steps of a merged launch chain -- ONE stream -- staged with one fused copy and one event;
+        # two chains of two steps per group of four slots, three groups, values that tell step and slot apart
+        slots2 = 4
+        g2 = ControlGatherer(dist, 1, device=dev, slots=slots2, shape=(B, 2, T))
+        chains = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        outs2 = [torch.empty((B, 2, T), device=dev) for _ in range(slots2)]
+        views2 = [None] * slots2
+        n = 3 * slots2
+        base = g2.begin(n)
+        for r0 in range(0, n, slots2):
+            for c in range(2):                                   # chain c owns slots c and c + 2
+                mine = [r0 + c, r0 + c + 2]
+                with torch.cuda.stream(chains[c]):
+                    for i in mine:
+                        outs2[i % slots2].fill_(float(10 * i + 1))
+                g2.stage_many([base + i for i in mine], [outs2[i % slots2] for i in mine], chains[c])
+            for i in range(r0, r0 + slots2):
+                views2[i % slots2] = g2.collect(base + i, outs2[i % slots2])
+        g2.join(); torch.cuda.synchronize()
+        assert g2.collectives == 3
+        for j in range(slots2):
+            assert torch.all(views2[j] == float(10 * (2 * slots2 + j) + 1)), (j, float(views2[j].flatten()[0]))
     finally:
         dist.destroy_process_group()
