@@ -229,7 +229,9 @@ def test_other_baseline_configs_parity_distribution(cfgname, scenes):
     # relaxation of verdict C to 1e-4 on this workload)
     rep = _ensemble_verdict(cfgname, scenes, step_tol=1e-5 if acker else None)
     assert rep["A_well_posed_all_le_tol"], rep
-    _assert_follows_the_reference_step_by_step(rep, 0.9 if acker else 0.995)
+    # (the car's share: 97.8 % of 960 steps on 64 scenes x 12 members, every one of the 21 above 1e-5 explained by the oracle's own
+    # one-step spread, profiles/r06_parity_wide.json -- held to 95 % here, 90 % until round 6)
+    _assert_follows_the_reference_step_by_step(rep, 0.95 if acker else 0.995)
     if acker:
         # C on the car: a scene may exceed 1e-5 before its ensemble diverges only through steps that are explained above
         # (flat first QPs: the oracle's own one-step spread under +-1 ulp is as large), and never beyond the north-star 1e-4
