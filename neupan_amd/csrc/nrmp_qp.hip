@@ -33,6 +33,7 @@
 #include "aset_reduce.h"
 #include <hip/hip_ext.h>
 #include <cstdlib>
+#include <type_traits>
 
 #include "nrmp_qp_device.h"
 

@@ -175,6 +175,41 @@ __device__ __forceinline__ void scan_suffix3(double& a, double& b, double& c, do
   QP_SCAN_STEP3(0x101); QP_SCAN_STEP3(0x102); QP_SCAN_STEP3(0x104); QP_SCAN_STEP3(0x108);
   if constexpr (WIDE) { a = fma(row0, readlane_f64(a, 16), a); b = fma(row0, readlane_f64(b, 16), b); c = fma(row0, readlane_f64(c, 16), c); }
 }
+// ---- fp64 broadcast inside a 16-lane row, FUSED with the multiply-add (round 6) ------------------------------------------------
+// gfx90a+ give the double-precision ALU one DPP control, row_newbcast:N -- every lane reads lane N of its own 16-lane row -- and
+// v_fmac_f64 takes it:   acc += src[lane N of my row] * (-mul)   is ONE instruction.  The route through two v_readlane_b32 into a
+// scalar pair and a v_fma_f64 with a scalar operand is three, with wait states between them (s_nop 0 after the write, s_nop 1 in
+// front of the use).  The compiler neither selects the DPP form of v_fmac_f64 (update_dpp on a double becomes v_mov_b64_dpp +
+// v_fma_f64) nor sees the hazards of an asm statement, so the wait states are part of the statements:
+//   VALU write of a VGPR -> DPP read of it: 2 wait states  (LEAD: s_nop 1 in front; `src` has just been written)
+//   VALU write of a VGPR -> v_readlane of it: 1 wait state (TAIL: s_nop 0 behind; the compiler's v_readlane follows)
+// LEAD marks `src` read-write so that every later statement that reads it is ordered behind this one.
+template <int N, bool LEAD, bool TAIL>
+__device__ __forceinline__ void fmac_rowbcast(double& acc, double& src, double mul) {
+  static_assert(N >= 0 && N < 16, "row_newbcast lane");
+  if constexpr (LEAD && TAIL)
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf\n\ts_nop 0" : "+v"(acc), "+v"(src) : "v"(mul), "n"(N));
+  else if constexpr (LEAD)
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc), "+v"(src) : "v"(mul), "n"(N));
+  else if constexpr (TAIL)
+    asm("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf\n\ts_nop 0" : "+v"(acc) : "v"(src), "v"(mul), "n"(N));
+  else
+    asm("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(N));
+}
+// one step of a substitution chain:  x -= x[lane N of my row] * mul   (x is written by the step before: always LEAD)
+template <int N, bool TAIL>
+__device__ __forceinline__ void subst_rowbcast(double& x, double mul) {
+  static_assert(N >= 0 && N < 16, "row_newbcast lane");
+  if constexpr (TAIL)
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %0, -%1 row_newbcast:%2 row_mask:0xf bank_mask:0xf\n\ts_nop 0" : "+v"(x) : "v"(mul), "n"(N));
+  else
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %0, -%1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(mul), "n"(N));
+}
+// compile-time loop: f(std::integral_constant<int, I>{}) for I = I0 .. N-1 (the row_newbcast lane is an immediate of the instruction)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
 // a wave-uniform double made provably uniform (both halves through v_readfirstlane): the compiler may then keep it in a
 // scalar register pair -- and, when it runs short of those, park it in a lane of a spill VGPR (v_readlane to fetch it)
 // instead of sending a whole vector register to scratch memory

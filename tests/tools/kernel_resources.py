@@ -201,6 +201,75 @@ def lost_instructions(lib=LIB):
     return hits
 
 
+# ---- wait states in front of the hand-written DPP instructions ---------------------------------------------------------------
+# nrmp_qp_device.h issues v_fmac_f64_dpp (row_newbcast) from asm statements: the compiler schedules around them but does not see
+# what they are, so the two hazards of such an instruction are the SOURCE's business (the s_nop inside the statements) -- and
+# a copy the register allocator may put right in front of a statement is nobody's.  Checked here on the machine code:
+#   a VGPR written by a vector instruction is not read through DPP within the next 2 wait states,
+#   a VGPR written by a DPP instruction of ours is not read by v_readlane within the next 1 wait state
+# (a wait state = one instruction issued, s_nop N = N + 1; a branch target in between ends the window: conservative = clean).
+def _vregs(tok):
+    tok = tok.strip().lstrip("-|").rstrip("|")
+    m = re.match(r"v\[(\d+):(\d+)\]$", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def dpp_hazards(ins):
+    """[(offset, instruction, what)] for one kernel; ins as _parse_disassembly returns them."""
+    if not ins:
+        return []
+    base = ins[0][2]
+    bad = []
+    for i, (mn, ops, a, _) in enumerate(ins):
+        is_dpp = mn.endswith("_dpp") or "row_newbcast" in ops or "row_shr" in ops or "row_shl" in ops or "quad_perm" in ops or "row_bcast" in ops or "row_mirror" in ops or "row_half_mirror" in ops
+        is_rl = mn.startswith("v_readlane")
+        if not (is_dpp or is_rl):
+            continue
+        toks = [t for t in re.split(r",\s*", ops.split(" row_")[0].split(" quad_perm")[0])]
+        if len(toks) < 2:
+            continue
+        src = _vregs(toks[1])                       # DPP applies to src0; v_readlane reads its vsrc0
+        need = 2 if is_dpp else 1
+        ws, j = 0, i - 1
+        while j >= 0 and ws < need:
+            pm, po = ins[j][0], ins[j][1]
+            if pm == "s_nop":
+                ws += int(po.strip() or 0, 0) + 1
+                j -= 1
+                continue
+            if pm.startswith("v_") and not pm.startswith(("v_cmp", "v_readlane", "v_readfirstlane")):
+                wrote = _vregs(re.split(r",\s*", po)[0]) if po else set()
+                if is_rl and not (pm.endswith("_dpp") and "f64" in pm):
+                    wrote = set()                   # (the compiler's own instructions in front of a v_readlane: its business)
+                if wrote & src:
+                    bad.append(("%x" % (a - base), (mn + " " + ops).strip(), f"{pm} {po.strip()} only {ws} wait state(s) ahead"))
+                    break
+            ws += 1
+            j -= 1
+    return bad
+
+
+def dpp_hazard_report(lib=LIB):
+    """{kernel symbol: hazards} over every kernel of the library that contains a double-precision DPP instruction."""
+    hits = {}
+    with tempfile.TemporaryDirectory() as d:
+        for co in _code_objects(lib, d):
+            text = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], stdout=subprocess.PIPE, text=True).stdout
+            cur, block = None, []
+            for l in text.splitlines() + ["0 <end>:"]:
+                m = re.match(r"^[0-9a-f]+ <(.+)>:", l)
+                if m:
+                    if cur and any("v_fmac_f64_dpp" in x for x in block):
+                        hits[cur] = dpp_hazards(_parse_disassembly(block))
+                    cur, block = m.group(1), []
+                else:
+                    block.append(l)
+    return hits
+
+
 def demangle(name):
     try:
         return subprocess.run([os.path.join(LLVM, "llvm-cxxfilt"), name], stdout=subprocess.PIPE, text=True).stdout.strip().split("(")[0]
@@ -209,6 +278,13 @@ def demangle(name):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--dpp":          # python tests/tools/kernel_resources.py --dpp [library ...]
+        for lib in sys.argv[2:] or [LIB]:
+            for k, v in dpp_hazard_report(lib).items():
+                print(demangle(k)[:90], "hazards:", len(v))
+                for x in v[:10]:
+                    print("       ", x)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "--lost":         # python tests/tools/kernel_resources.py --lost [library ...]
         for lib in sys.argv[2:] or [LIB]:
             h = lost_instructions(lib)
