@@ -205,6 +205,40 @@ __device__ __forceinline__ void subst_rowbcast(double& x, double mul) {
   else
     asm("s_nop 1\n\tv_fmac_f64_dpp %0, %0, -%1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(mul), "n"(N));
 }
+// One column of the factor's LDS image, written by the lanes of MASK only: the EXEC mask is set and restored inside the statement,
+// both from constants of the instruction stream (the call sits under `if (lane < 2T)` of wave-uniform code in a 64-lane workgroup:
+// EXEC there is lanes 0 .. 2T-1 = RESTORE; the compiler never sees another EXEC).  LDS operations of a wave complete in order, so
+// the counts the compiler keeps for its own s_waitcnt stay on the safe side of these stores.  LAST: five wait states behind the
+// restore, what a DPP instruction wants after a scalar write of EXEC.  (With the statements outside any `if` -- EXEC all ones -- the
+// stand-alone kernel came out with a 36-byte private segment that no instruction touches: a register-allocation artefact of hipcc
+// 7.2 around 106 scalar registers; tests/test_abi.py asserts there is none.)
+typedef __attribute__((address_space(3))) double lds_f64;
+__device__ __forceinline__ unsigned lds_addr(const double* p) { return (unsigned)(size_t)((const lds_f64*)p); }
+template <unsigned MASK, int OFF, bool LAST, unsigned RESTORE>
+__device__ __forceinline__ void park_store(unsigned addr, double v) {
+  // (restored from a constant, not from a saved copy: the kernel is at its limit of scalar registers)
+  if constexpr (LAST)
+    asm volatile("s_mov_b64 exec, %2\n\tds_write_b64 %0, %1 offset:%3\n\ts_mov_b64 exec, %4\n\ts_nop 4" : : "v"(addr), "v"(v), "n"(MASK), "n"(OFF), "n"(RESTORE) : "memory");
+  else
+    asm volatile("s_mov_b64 exec, %2\n\tds_write_b64 %0, %1 offset:%3\n\ts_mov_b64 exec, %4" : : "v"(addr), "v"(v), "n"(MASK), "n"(OFF), "n"(RESTORE) : "memory");
+}
+// columns C .. N-2 of the row a lane holds, scaled by 1/L_ii, four columns per statement
+template <int C, int N>
+__device__ __forceinline__ void park_rows(unsigned lrow, const double (&arow)[N], double myinv) {
+  constexpr unsigned ALL = (1u << N) - 1u;
+  if constexpr (C + 4 <= N - 1) {
+    const double v0 = arow[C] * myinv, v1 = arow[C + 1] * myinv, v2 = arow[C + 2] * myinv, v3 = arow[C + 3] * myinv;
+    asm volatile("s_mov_b64 exec, %5\n\tds_write_b64 %0, %1 offset:%9\n\ts_mov_b64 exec, %6\n\tds_write_b64 %0, %2 offset:%10\n\t"
+                 "s_mov_b64 exec, %7\n\tds_write_b64 %0, %3 offset:%11\n\ts_mov_b64 exec, %8\n\tds_write_b64 %0, %4 offset:%12\n\ts_mov_b64 exec, %13"
+                 : : "v"(lrow), "v"(v0), "v"(v1), "v"(v2), "v"(v3),
+                     "n"(ALL & ~((2u << C) - 1u)), "n"(ALL & ~((2u << (C + 1)) - 1u)), "n"(ALL & ~((2u << (C + 2)) - 1u)), "n"(ALL & ~((2u << (C + 3)) - 1u)),
+                     "n"(C * 8), "n"(C * 8 + 8), "n"(C * 8 + 16), "n"(C * 8 + 24), "n"(ALL) : "memory");
+    park_rows<C + 4, N>(lrow, arow, myinv);
+  } else if constexpr (C < N - 1) {
+    park_store<ALL & ~((2u << C) - 1u), C * 8, C == N - 2, ALL>(lrow, arow[C] * myinv);
+    park_rows<C + 1, N>(lrow, arow, myinv);
+  }
+}
 // compile-time loop: f(std::integral_constant<int, I>{}) for I = I0 .. N-1 (the row_newbcast lane is an immediate of the instruction)
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {

@@ -200,6 +200,29 @@ def test_no_kernel_has_instructions_that_only_run_with_exec_zero():
     assert lost == {}, {k: v[:4] for k, v in lost.items()}
 
 
+def test_hand_written_dpp_instructions_have_their_wait_states():
+    """Round 6: the T = 10 QP kernels broadcast a lane's double inside the multiply-add itself (v_fmac_f64_dpp ... row_newbcast, asm
+    statements of nrmp_qp_device.h) -- the compiler schedules around such a statement but does not know its hazards: a VGPR written
+    by a vector instruction may not be read through DPP within 2 wait states, one written by the statement not by v_readlane
+    within 1.  The statements carry their own s_nop; what the register allocator puts around them is checked here on the MACHINE
+    CODE of the built library (tests/tools/kernel_resources.dpp_hazards; the instruction itself is checked on the device:
+    tests/tools/hw/dpp_f64_check.hip, bitwise fma in all 64 lanes for every row_newbcast lane)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import kernel_resources as kr
+    mk = lambda seq: [(m, o, 4 * i, None) for i, (m, o) in enumerate(seq)]
+    dpp = ("v_fmac_f64_dpp", "v[8:9], v[4:5], -v[4:5] row_newbcast:3 row_mask:0xf bank_mask:0xf")
+    assert len(kr.dpp_hazards(mk([("v_mul_f64", "v[4:5], v[0:1], v[2:3]"), ("s_nop", "0"), dpp]))) == 1
+    assert kr.dpp_hazards(mk([("v_mul_f64", "v[4:5], v[0:1], v[2:3]"), ("s_nop", "1"), dpp])) == []
+    assert kr.dpp_hazards(mk([("v_mul_f64", "v[4:5], v[0:1], v[2:3]"), ("v_add_f64", "v[0:1], v[0:1], v[2:3]"), ("s_nop", "0"), dpp])) == []
+    assert len(kr.dpp_hazards(mk([dpp, ("v_readlane_b32", "s3, v9, 4")]))) == 1
+    assert kr.dpp_hazards(mk([dpp, ("s_nop", "0"), ("v_readlane_b32", "s3, v9, 4")])) == []
+    if not kr.tools_available():
+        pytest.skip("ROCm LLVM tools not installed")
+    rep = kr.dpp_hazard_report()
+    assert len(rep) >= 2, list(rep)                     # the stand-alone and the group instantiation of T = 10
+    assert all(v == [] for v in rep.values()), {k: v[:4] for k, v in rep.items() if v}
+
+
 def test_build_refuses_an_unvalidated_compiler(monkeypatch):
     """neupan_amd.build fails (not warns) on a hipcc other than the validated one unless NPA_ALLOW_UNVALIDATED=1."""
     from neupan_amd import build as b
