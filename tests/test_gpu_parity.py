@@ -5,6 +5,8 @@ North-star tolerance: control L2 <= 1e-4 vs the reference path.  The reference's
 solver (ECOS, tolerances 1e-8) is only accurate to ~1e-3 on the flat steering directions
 of this QP (see DESIGN.md "What 1e-4 means here"), so these tests compare with the oracle,
 which converges two orders tighter, and report the distribution over scenes."""
+import os
+import sys
 import numpy as np
 import pytest
 
@@ -99,6 +101,33 @@ def test_nrmp_stage_vs_oracle(cfgname, nscn, npts, over):
                                out["opt_u"].cpu().numpy()[0].astype(np.float64),
                                out["opt_d"].cpu().numpy()[0].astype(np.float64), act_tol=1e-3)
         assert cert["feas"] < 1e-6 and cert["dyn"] < 1e-5, cert      # fp32-rounded solution
+
+
+@pytest.mark.gpu
+def test_register_resident_qp_equals_the_generic_instantiation(tmp_path):
+    """Round 6: the T = 10 kernel broadcasts inside the multiply-add (v_fmac_f64_dpp row_newbcast over matrix rows held twice across
+    two DPP rows), writes the factor's LDS image under constant EXEC masks and takes the step length from a maximum of products;
+    the generic instantiation (NPA_QP_GENERIC=1: matrices in LDS, v_readlane / LDS broadcasts, any (T, M)) does none of that and
+    runs the same interior-point method.  Both stop at 1e-14: their fp64 solutions of the SAME 256 QPs (the selection's rows are
+    bitwise the same in both processes) agree far below the oracle tests' 2e-5 -- a lane of the factorisation fed from the wrong
+    copy would not.  The variable is read once per process: two child processes."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, env in (("fast", {}), ("generic", {"NPA_QP_GENERIC": "1"})):
+        f = str(tmp_path / f"{tag}.npz")
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "qp_stage_dump.py"), "diff_1k_T10_K10", "256", f],
+                           cwd=root, env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:]
+        outs[tag] = np.load(f)
+    a, g = outs["fast"], outs["generic"]
+    assert np.array_equal(a["mu"], g["mu"]) and np.array_equal(a["count"], g["count"])       # the same QPs
+    assert (a["info"][:, 3] == 0).all() and (g["info"][:, 3] == 0).all()
+    assert a["info"][:, 1].max() <= 1e-13 and g["info"][:, 1].max() <= 1e-13                # both at their limit point
+    d = np.abs(a["x64"] - g["x64"]).max(axis=1)
+    # (measured: median 2e-15, 90 % below 4e-13, largest 1e-9 over 256 cold solves; the same iteration counts in both)
+    assert np.median(d) <= 1e-12 and d.max() <= 1e-7, (float(np.median(d)), float(d.max()))
+    assert np.array_equal(a["info"][:, 14], g["info"][:, 14])
 
 
 PANS = [("diff_n1000_k3", "diff_1k_T10_K10", dict(iter_num=3)),
