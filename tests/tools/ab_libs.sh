@@ -1,5 +1,5 @@
 #!/bin/bash
-# alternate two (or more) builds of the library on ONE box: bash tests/tools/_ab.sh tag rounds libA libB ...
+# alternate two (or more) builds of the library on ONE box: bash tests/tools/ab_libs.sh tag rounds libA libB ...
 tag=$1; rounds=$2; shift 2
 out=gpurun_out/$tag; mkdir -p $out
 for r in $(seq 1 $rounds); do
