@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 6: the lines of record in ONE GPU call, most important first (every step under its own timeout, nothing fatal):
-#     gpurun --timeout 2400 -- 'bash tests/tools/record_round6.sh'
+#     gpurun --timeout 3000 -- 'bash tests/tools/record_round6.sh --pmc'      (--pmc: re-collect the counter records first, after a kernel change;
+#     copy gpurun_out/r06/pmc_*.json to profiles/r06_pmc*.json afterwards)
 # Writes gpurun_out/r06final/ ; what is to be judged is copied into profiles/ afterwards (profiles/README.md names the commands).
 out=gpurun_out/r06final
 rm -rf $out; mkdir -p $out
@@ -8,6 +9,12 @@ export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 t0=$(date +%s)
 stamp() { echo "[$(( $(date +%s) - t0 )) s] $*" | tee -a $out/steps.log; }
 py=python
+if [ "$1" = "--pmc" ]; then      # (counters first: the bench lines below price their roofline with profiles/r06_pmc*.json)
+  stamp "PMC passes (kernels alone)"
+  mkdir -p gpurun_out/r06
+  for w in diff_1k_T10_K10 acker_2k_T20_K15 poly8_5k_T10_K10; do ( cd /tmp; timeout 450 $py $GRAFT_REPO_ROOT/tests/tools/pmc_collect.py $w > $GRAFT_REPO_ROOT/gpurun_out/r06/pmc_$w.log 2>&1 ); done
+  cp gpurun_out/r06/pmc_diff_1k_T10_K10.json profiles/r06_pmc.json; cp gpurun_out/r06/pmc_acker_2k_T20_K15.json profiles/r06_pmc_acker.json; cp gpurun_out/r06/pmc_poly8_5k_T10_K10.json profiles/r06_pmc_poly8.json
+fi
 stamp "gpu tests"
 timeout 600 $py -m pytest tests -m gpu -x -q > $out/gpu_tests_raw.txt 2>&1; echo "rc $?" >> $out/gpu_tests_raw.txt
 grep -v "RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl\|amdgpu.ids" $out/gpu_tests_raw.txt > $out/gpu_tests.txt
