@@ -102,3 +102,35 @@ def test_table_key_rule_keeps_every_true_member_and_prunes():
         kept.append(int(surv.sum()))
     assert viol == 0
     assert np.median(kept) <= 3 * M and max(kept) < 400, (np.median(kept), max(kept))
+
+
+def test_shortened_search_for_the_nominating_bound_is_an_upper_bound():
+    """Stage 1 nominates through the msel-th smallest of the 64 lane minima (select_geo_body.inc: a bit-by-bit search on ballots).
+    Round 6 stops the search twelve bits short and fills them with ones.  Restated in numpy on the bit patterns of float keys: the
+    result is >= the exact msel-th smallest (so every lane the exact bound admits still nominates: the candidates stay a superset),
+    at most 2^12 - 1 key units above it (5e-4 of the key), and 0xFFFFFFFF exactly when fewer than msel lanes hold a point."""
+    rng = np.random.default_rng(3)
+
+    def search(lmin, msel, stop):
+        bound = 0
+        for bit in range(31, stop - 1, -1):
+            trial = bound | ((1 << bit) - 1)
+            if int((lmin <= trial).sum()) < msel:
+                bound |= 1 << bit
+        return bound | ((1 << stop) - 1)
+    for trial_no in range(400):
+        msel = int(rng.integers(1, 11))
+        nvalid = int(rng.integers(0, 65))
+        g = np.abs(rng.normal(0.0, rng.choice([0.01, 0.5, 3.0, 40.0]), 64)).astype(np.float32)
+        if trial_no % 7 == 0:
+            g[: nvalid // 2] = g[0]                             # ties
+        lmin = g.view(np.uint32).astype(np.uint64)
+        lmin[nvalid:] = 0xFFFFFFFF                              # lanes without a point
+        exact = search(lmin, msel, 0)
+        assert exact == int(np.sort(lmin)[msel - 1])            # the full search IS the msel-th smallest, with multiplicity
+        short = search(lmin, msel, 12)
+        assert short >= exact and short - exact <= 0xFFF and (short >> 12) == (exact >> 12)
+        assert (short == 0xFFFFFFFF) == (nvalid < msel)
+        if nvalid >= msel and exact > 0x00800000:               # (a normal float: the slack is below 2^-11 of the key)
+            gs, ge = np.uint32(short).view(np.float32), np.uint32(exact).view(np.float32)
+            assert 0.0 <= float(gs - ge) <= 5e-4 * float(ge) + 1e-30
