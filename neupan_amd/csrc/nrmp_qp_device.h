@@ -32,6 +32,12 @@
                                //   1e-10 .. 1e-12, best iterate after three non-improving iterations: 13 of 3 360 benchmark QPs, one of
                                //   them 1.2e-4 from the oracle in the controls) end at <= 1e-13 with it (CPU replay of the kernel's
                                //   method, profiles/r05_qp_stall_study.txt: +0.2 .. +1.0 iterations per solve, the maximum unchanged)
+#define QP_STALL_NEAR_MERIT 1e-6 // the rule of three non-improving iterations holds below this best merit; above it the patience is
+#define QP_STALL_FAR 8           //   this (profiles/r06_qp_stall_patience.txt: no effect on the solves that converged before)
+#define QP_CENTRAL_GAMMA 1e-3    // centrality safeguard of a blocked step: every product l w stays above this x their mean,
+#define QP_CENTRAL_SHRINK 0.7    //   the step shortened by this factor,
+#define QP_CENTRAL_TRIES 6       //   at most this often,
+#define QP_CENTRAL_ALPHA 0.9     //   checked for steps shorter than this only (profiles/r06_qp_centrality.txt)
 // the cold starting point: u = 0, d mid-range, slacks >= 1, multipliers QP_START_MU / slack -- or, for the SECOND cold attempt
 // of a solve whose first one jammed (cold_alt), unit multipliers, round 2's start -- (a macro: used before the loop and, in the
 // instantiations with warm start, again at the loop top when a warm attempt is dropped)

@@ -90,6 +90,22 @@ SIGMA_MU_RES = 0.01     # ... nor below this x the largest scaled residual: comp
                         #   1e-10 .. 1e-12 and ended there (three non-improving iterations: "stalled"); with it 1 of 3 360 ends above
                         #   1e-13 (1.8e-13), for +0.2 .. +1.0 iterations per solve (profiles/r05_qp_stall_study.txt)
 RETRY_MERIT = 1e-9      # a cold solve that ends above this is repeated once with unit multipliers (round 2's start)
+# "the best iterate stands after STALL non-improving iterations" is an END-GAME rule (a merit that wanders at 1e-10 .. 1e-12); far from
+# convergence the merit is the complementarity gap, which may sit still for several iterations while feasibility improves (heavy
+# centring, short steps): there the patience is STALL_FAR.  (Round 6: three solves in 5 120 of the 8-edge hull's, ended at merit 0.65 -
+# 0.86 by the rule of three, converge in 14 - 19 iterations with it.)
+STALL_NEAR_MERIT = 1e-6
+STALL_NEAR = 3
+STALL_FAR = 8           # QP_STALL_FAR (profiles/r06_qp_stall_patience.txt: the solves that converged before are untouched)
+# Centrality safeguard of the step (round 6): a step that leaves one complementarity product far behind the others (l_i w_i < CENTRAL_GAMMA x
+# their mean) jams the method -- the next steps are blocked by that pair in turn (one solve in 512 of the moving-cloud workload sat at
+# mu = 1e-3 for 27 iterations with every residual at 1e-10).  The step is shortened (x CENTRAL_SHRINK, at most CENTRAL_TRIES times) until
+# the products stay inside the wide neighbourhood; checked only for steps shorter than CENTRAL_ALPHA (a full step of the end game
+# keeps them balanced by itself).  CENTRAL_GAMMA = 0: off.
+CENTRAL_GAMMA = 1e-3    # QP_CENTRAL_* of nrmp_qp_device.h (profiles/r06_qp_centrality.txt)
+CENTRAL_SHRINK = 0.7
+CENTRAL_TRIES = 6
+CENTRAL_ALPHA = 0.9
 
 
 def solve_condensed(pb: NrmpProblem, tol=1e-14, max_iter=40, trace=None, warm=None, _alt=False, sigma_mu_res=None):
@@ -152,7 +168,7 @@ def solve_condensed(pb: NrmpProblem, tol=1e-14, max_iter=40, trace=None, warm=No
             best = (merit, x.copy(), it); stall = 0
         else:
             stall += 1
-        if merit <= tol or stall >= 3 or it == max_iter or mu < 1e-17:
+        if merit <= tol or stall >= (STALL_NEAR if best[0] <= STALL_NEAR_MERIT else STALL_FAR) or it == max_iter or mu < 1e-17:
             break
         Dc = lc / wc
         Df = lf / (wf + lf / ro)
@@ -182,6 +198,12 @@ def solve_condensed(pb: NrmpProblem, tol=1e-14, max_iter=40, trace=None, warm=No
         dx, dwc, dlc, dwf, dlf = solve(lc * wc + dwc * dlc - sigma_mu, lf * wf + dwf * dlf - sigma_mu)
         eta = min(max(STEP_ETA, 1.0 - mu), 1.0 - STEP_CAP)
         a = min(1.0, eta * min(max_step(wc, dwc), max_step(lc, dlc), max_step(wf, dwf), max_step(lf, dlf)))
+        if CENTRAL_GAMMA > 0.0 and a < CENTRAL_ALPHA:
+            for _ in range(CENTRAL_TRIES):
+                prod = np.concatenate([(lc + a * dlc) * (wc + a * dwc), (lf + a * dlf) * (wf + a * dwf)])
+                if prod.min() >= CENTRAL_GAMMA * prod.mean():
+                    break
+                a *= CENTRAL_SHRINK
         x = x + a * dx; wc = wc + a * dwc; lc = lc + a * dlc; wf = wf + a * dwf; lf = lf + a * dlf
         lam_out = (lc, lf)
     if warm is not None and not best[0] <= WARM_ACCEPT:

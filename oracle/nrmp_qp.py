@@ -134,7 +134,11 @@ def dense_ipm(P, q, A, b, G, h, tol=1e-14, max_iter=60):
             stall = 0
         else:
             stall += 1
-        if merit <= tol or stall >= 3 or it == max_iter:
+        # (round 6: the rule of three is an END-GAME rule.  Far from convergence the merit is the complementarity gap, which may sit
+        # still for several iterations while feasibility improves: on 7 of 66 560 benchmark QPs this solver -- and the kernel, which
+        # shared the rule -- returned an iterate at merit 0.6 - 0.9 after four or five iterations.  Found by scanning 1024 scenes
+        # per workload with the kernel's status word; profiles/r06_qp_robustness.txt)
+        if merit <= tol or stall >= (3 if best[0] <= 1e-6 else 12) or it == max_iter:
             break
         D = lam / w
         K[:n, :n] = P + G.T @ (D[:, None] * G)
@@ -161,6 +165,14 @@ def dense_ipm(P, q, A, b, G, h, tol=1e-14, max_iter=60):
             sigma_mu = max((mu_aff / mu) ** 3 * mu, SIGMA_MU_RES * res)
             dz, dy, dw, dl = solve(lam * w + dw * dl - sigma_mu)
             a = min(1.0, 0.995 * min(max_step(w, dw), max_step(lam, dl)))
+            # centrality safeguard of a blocked step (the same rule as the kernel's, QP_CENTRAL_*): no product lam w may fall below
+            # 1e-3 x their mean -- one badly centred pair blocks every later step in turn
+            if a < 0.9:
+                for _ in range(6):
+                    prod = (lam + a * dl) * (w + a * dw)
+                    if prod.min() >= 1e-3 * prod.mean():
+                        break
+                    a *= 0.7
             z, y, w, lam = z + a * dz, y + a * dy, w + a * dw, lam + a * dl
     merit, z, y, lam, w, it_used = best
     return z, y, lam, w, {"iters": it_used, "merit": merit}

@@ -132,6 +132,38 @@ def test_register_resident_qp_equals_the_generic_instantiation(tmp_path):
     assert dit.max() <= 2 and (dit == 0).mean() >= 0.8, (float(dit.max()), float((dit == 0).mean()))
 
 
+# (workload, scene): QPs of these scenes' forward calls that round 5's interior-point heuristics gave up on -- found in round 6 by scanning
+# 1024 scenes per workload (tests/tools/qp_status_scan.py); none is among the scenes any earlier test or bench leg looks at
+HARD_SCENES = [("poly8_5k_T10_K10", 122), ("poly8_5k_T10_K10", 202), ("poly8_5k_T10_K10", 408), ("poly8_5k_T10_K10", 961),
+               ("dyna_4k_T10_K10", 204), ("acker_2k_T20_K15", 544), ("acker_2k_T20_K15", 850)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfgname", sorted({w for w, _ in HARD_SCENES}))
+def test_solves_that_used_to_jam_converge(cfgname):
+    """Seven of 66 560 QPs (1024 scenes x K of each workload) ended at merit 4e-4 .. 0.86 with status 4 until round 6: the rule "the best
+    iterate stands after three non-improving iterations" fired at merit ~1 while the residuals were still falling (8-edge hull, car),
+    and one solve sat at mu = 1e-3 behind a single badly centred pair (moving cloud).  With the patience of QP_STALL_FAR far from
+    convergence and the centrality safeguard of blocked steps every QP of these calls converges, and the controls agree with the
+    oracle's (whose solver never had the rule)."""
+    from gpu_helpers import make_gpu_pan
+    cfg = CONFIGS[cfgname]
+    pan = make_gpu_pan(cfg)
+    orc = make_oracle(cfg, iter_num=1)
+    for _, b in [x for x in HARD_SCENES if x[0] == cfgname]:
+        sc = make_batch(cfg, b, 1)
+        out = pan.forward_batch_trace(sc["nom_s"], sc["nom_u"], sc["ref_s"], sc["ref_us"], sc["points"], sc["velocities"])
+        qi = out["trace_qp_info"].cpu().numpy()[0]
+        assert (qi[:, 3] == 0).all() and qi[:, 1].max() <= 1e-9, (b, qi[:, 3], qi[:, 1].max())
+        # the FIRST iteration's QP (the same nominal on both sides; for five of the seven it is the one that used to jam) against the
+        # oracle's solve of it.  (The whole K-iteration fixed point of these scenes is not a fair target: 5e-2 between two valid
+        # evaluations on the car's scene 544 -- what the ensemble verdicts of this file exist for.)
+        one = make_scene(cfg, b)
+        s, u, d = orc.forward(one["nom_s"], one["nom_u"], one["ref_s"], one["ref_us"], one["points"], one["velocities"])
+        du = float(np.sqrt(((out["trace_u"].cpu().numpy()[0, 0] - u) ** 2).sum()))
+        assert du <= 1e-4, (b, du)
+
+
 PANS = [("diff_n1000_k3", "diff_1k_T10_K10", dict(iter_num=3)),
         ("diff_n200_k10", "diff_1k_T10_K10", dict(iter_num=10, dune_max_num=200)),
         ("dyna_n300_k4", "dyna_4k_T10_K10", dict(iter_num=4, dune_max_num=300)),

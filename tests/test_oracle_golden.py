@@ -243,7 +243,8 @@ def test_condensed_solver_repeats_a_jammed_cold_solve():
     """Scene 66 of the acker workload: from the centred cold start (multipliers 3 / slack) the interior-point method jams --
     a step lands on the boundary too early, three non-improving iterations end the solve at 3e-6 -- while unit multipliers
     go through.  oracle/condensed_ipm.py carries the kernel's rule (nrmp_qp.hip, QP_RETRY_MERIT): a cold solve that ends
-    above 1e-9 is repeated once from unit multipliers (warm_code 5).  The solution is the uncondensed oracle's."""
+    above 1e-9 is repeated once from unit multipliers (warm_code 5).  The solution is the uncondensed oracle's.  (Round 6's
+    centrality safeguard removes this jam at its root; the retry stays as the backstop and is exercised here under round 5's rules.)"""
     from neupan_amd.scenes import make_scene
     from oracle import condensed_ipm as ci
     cfg = CONFIGS["acker_2k_T20_K15"]
@@ -259,15 +260,21 @@ def test_condensed_solver_repeats_a_jammed_cold_solve():
     orc.nrmp = hook
     orc.forward(sc["nom_s"], sc["nom_u"], sc["ref_s"], sc["ref_us"], sc["points"], sc["velocities"])
     pb = pbs[-1]
+    # round 6: with the centrality safeguard of blocked steps (CENTRAL_*) the centred start goes through by itself ...
     s, u, d, info = solve_condensed(pb)
-    assert info["warm_code"] == 5 and info["merit"] <= 1e-12, info
-    old = ci.RETRY_MERIT
+    assert info["warm_code"] == 0 and info["merit"] <= 1e-12, info
+    old = (ci.RETRY_MERIT, ci.STALL_FAR, ci.CENTRAL_GAMMA)
     try:
-        ci.RETRY_MERIT = float("inf")                     # without the rule: the jam
+        # ... under round 5's rules it jams (three non-improving iterations end it at 3e-6) and the retry from unit multipliers saves it
+        ci.STALL_FAR, ci.CENTRAL_GAMMA = 3, 0.0
+        s5, u5, d5, info5 = solve_condensed(pb)
+        assert info5["warm_code"] == 5 and info5["merit"] <= 1e-12, info5
+        ci.RETRY_MERIT = float("inf")                     # without the retry rule: the jam
         s1, u1, d1, info1 = solve_condensed(pb)
     finally:
-        ci.RETRY_MERIT = old
+        ci.RETRY_MERIT, ci.STALL_FAR, ci.CENTRAL_GAMMA = old
     assert info1["warm_code"] == 0 and info1["merit"] > 1e-9, info1
+    np.testing.assert_allclose(u5, u, atol=1e-7)
     s0, u0, d0 = solve_nrmp_qp(pb)
     np.testing.assert_allclose(u, u0, atol=5e-5)          # (acker QPs are flat in the steering direction: DESIGN.md section 5)
 
