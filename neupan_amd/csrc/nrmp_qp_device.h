@@ -38,6 +38,10 @@
 #define QP_CENTRAL_SHRINK 0.7    //   the step shortened by this factor,
 #define QP_CENTRAL_TRIES 6       //   at most this often,
 #define QP_CENTRAL_ALPHA 0.9     //   checked for steps shorter than this only (profiles/r06_qp_centrality.txt)
+#define QP_CORRECTOR_MIN_AFF 0.1 // an affine direction that can be followed for less than this takes no second-order corrector: dw_aff dl_aff
+                                 //   describes a point the iterate never gets near, and correcting for it can send the iterate round a
+                                 //   cycle (one solve in 10 240 of the polygon robot's: mu 2e-3 -> 6e-3 -> 4e-3 -> 8e-3 -> 2e-3 ..., every
+                                 //   residual at 1e-9, both cold starts).  The other solves are unchanged (profiles/r06_qp_corrector.txt)
 // the cold starting point: u = 0, d mid-range, slacks >= 1, multipliers QP_START_MU / slack -- or, for the SECOND cold attempt
 // of a solve whose first one jammed (cold_alt), unit multipliers, round 2's start -- (a macro: used before the loop and, in the
 // instantiations with warm start, again at the loop top when a warm attempt is dropped)

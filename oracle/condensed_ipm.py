@@ -106,6 +106,12 @@ CENTRAL_GAMMA = 1e-3    # QP_CENTRAL_* of nrmp_qp_device.h (profiles/r06_qp_cent
 CENTRAL_SHRINK = 0.7
 CENTRAL_TRIES = 6
 CENTRAL_ALPHA = 0.9
+# Mehrotra's second-order corrector is built from the affine direction; when that direction can only be followed for a few per cent of
+# its length (a_aff < CORRECTOR_MIN_AFF) the products dw_aff * dl_aff describe a point the iterate never gets near, and the "correction"
+# can drive the iterate round a cycle (round 6: one solve in 10 240 of the shipped polygon robot's, mu going 2e-3 -> 6e-3 -> 4e-3 -> 8e-3
+# -> 2e-3 ... with every residual below 1e-9, both cold starts, 51 iterations).  Such a step is taken as a plain centring step
+# (the known safeguard of Mehrotra-type methods for short affine steps).  0: off.
+CORRECTOR_MIN_AFF = 0.1  # QP_CORRECTOR_MIN_AFF of nrmp_qp_device.h (profiles/r06_qp_corrector.txt)
 
 
 def solve_condensed(pb: NrmpProblem, tol=1e-14, max_iter=40, trace=None, warm=None, _alt=False, sigma_mu_res=None):
@@ -195,7 +201,8 @@ def solve_condensed(pb: NrmpProblem, tol=1e-14, max_iter=40, trace=None, warm=No
         a_aff = min(max_step(wc, dwc), max_step(lc, dlc), max_step(wf, dwf), max_step(lf, dlf))
         mu_aff = ((lc + a_aff * dlc) @ (wc + a_aff * dwc) + (lf + a_aff * dlf) @ (wf + a_aff * dwf)) / max(m, 1)
         sigma_mu = max((mu_aff / mu) ** 3 * mu, SIGMA_MU_MIN, smr * res)
-        dx, dwc, dlc, dwf, dlf = solve(lc * wc + dwc * dlc - sigma_mu, lf * wf + dwf * dlf - sigma_mu)
+        cw = 1.0 if a_aff >= CORRECTOR_MIN_AFF else 0.0
+        dx, dwc, dlc, dwf, dlf = solve(lc * wc + cw * dwc * dlc - sigma_mu, lf * wf + cw * dwf * dlf - sigma_mu)
         eta = min(max(STEP_ETA, 1.0 - mu), 1.0 - STEP_CAP)
         a = min(1.0, eta * min(max_step(wc, dwc), max_step(lc, dlc), max_step(wf, dwf), max_step(lf, dlf)))
         if CENTRAL_GAMMA > 0.0 and a < CENTRAL_ALPHA:

@@ -163,7 +163,8 @@ def dense_ipm(P, q, A, b, G, h, tol=1e-14, max_iter=60):
             a_aff = min(max_step(w, dw), max_step(lam, dl))
             mu_aff = (lam + a_aff * dl) @ (w + a_aff * dw) / m
             sigma_mu = max((mu_aff / mu) ** 3 * mu, SIGMA_MU_RES * res)
-            dz, dy, dw, dl = solve(lam * w + dw * dl - sigma_mu)
+            # (no second-order corrector on an affine step shorter than 0.1: the kernel's QP_CORRECTOR_MIN_AFF, same reason)
+            dz, dy, dw, dl = solve(lam * w + (dw * dl if a_aff >= 0.1 else 0.0) - sigma_mu)
             a = min(1.0, 0.995 * min(max_step(w, dw), max_step(lam, dl)))
             # centrality safeguard of a blocked step (the same rule as the kernel's, QP_CENTRAL_*): no product lam w may fall below
             # 1e-3 x their mean -- one badly centred pair blocks every later step in turn

@@ -32,6 +32,11 @@ RULES_CENTRAL = [("shipped in round 5 (rule of three anywhere, no safeguard)", R
                  ("+ centrality 1e-3 x0.7 x6, steps below 0.5", {"STALL_FAR": 8, "CENTRAL_GAMMA": 1e-3, "CENTRAL_ALPHA": 0.5}),
                  ("+ centrality 1e-4 x0.7 x6, steps below 0.9", {"STALL_FAR": 8, "CENTRAL_GAMMA": 1e-4, "CENTRAL_ALPHA": 0.9}),
                  ("+ centrality 1e-2 x0.7 x6, steps below 0.9", {"STALL_FAR": 8, "CENTRAL_GAMMA": 1e-2, "CENTRAL_ALPHA": 0.9})]
+RULES_CORR = [("shipped before (stall 8, centrality 1e-3 below 0.9, corrector always)", {"CORRECTOR_MIN_AFF": 0.0}),
+              ("no corrector when the affine step is below 0.05", {"CORRECTOR_MIN_AFF": 0.05}),
+              ("no corrector when the affine step is below 0.1  = SHIPPED", {"CORRECTOR_MIN_AFF": 0.1}),
+              ("no corrector when the affine step is below 0.2", {"CORRECTOR_MIN_AFF": 0.2}),
+              ("no corrector when the affine step is below 0.3", {"CORRECTOR_MIN_AFF": 0.3})]
 RULES = [("round 2 (eta = 0.995, unit multipliers, floor 0.01, drops at 0 / 3 / 7)", ROUND2),
          ("+ centring target >= 1e-15", {**ROUND2, "SIGMA_MU_MIN": 1e-15}),
          ("+ eta = max(0.995, 1 - mu) <= 1 - 1e-6", {**ROUND2, "SIGMA_MU_MIN": 1e-15, "STEP_CAP": 1e-6}),
@@ -48,7 +53,7 @@ RULES = [("round 2 (eta = 0.995, unit multipliers, floor 0.01, drops at 0 / 3 / 
 
 def job(arg):
     name, b, stall = arg if len(arg) == 3 else (*arg, 0)
-    rules_ = {0: RULES, 1: RULES_STALL, 2: RULES_CENTRAL}[int(stall)]
+    rules_ = {0: RULES, 1: RULES_STALL, 2: RULES_CENTRAL, 3: RULES_CORR}[int(stall)]
     from helpers import CONFIGS, make_oracle
     from neupan_amd.scenes import make_scene
     from oracle import condensed_ipm as ci
@@ -64,7 +69,7 @@ def job(arg):
         return r
     orc.nrmp = hook
     orc.forward(sc["nom_s"], sc["nom_u"], sc["ref_s"], sc["ref_us"], sc["points"], sc["velocities"])
-    shipped = {k: getattr(ci, k) for k in ("STEP_ETA", "STEP_CAP", "START_MU", "SIGMA_MU_MIN", "WARM_DELTA", "WARM_DROP", "RETRY_MERIT", "STALL_FAR", "CENTRAL_GAMMA", "CENTRAL_ALPHA")}
+    shipped = {k: getattr(ci, k) for k in ("STEP_ETA", "STEP_CAP", "START_MU", "SIGMA_MU_MIN", "WARM_DELTA", "WARM_DROP", "RETRY_MERIT", "STALL_FAR", "CENTRAL_GAMMA", "CENTRAL_ALPHA", "CORRECTOR_MIN_AFF")}
     out = []
     for _, rules in rules_:
         for k, v in {**shipped, **rules}.items():
@@ -138,12 +143,15 @@ def main():
     if "--central" in sys.argv:               # (round 6: the centrality safeguard of the step -> profiles/r06_qp_centrality.txt)
         RULES = RULES_CENTRAL
         sys.argv.remove("--central")
+    if "--corrector" in sys.argv:             # (round 6: no second-order corrector on a short affine step -> profiles/r06_qp_corrector.txt)
+        RULES = RULES_CORR
+        sys.argv.remove("--corrector")
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     procs = int(sys.argv[2]) if len(sys.argv) > 2 else (os.cpu_count() or 1)
     from concurrent.futures import ProcessPoolExecutor
     import multiprocessing as mp
     with ProcessPoolExecutor(procs, mp_context=mp.get_context("spawn")) as ex:
-        res = list(ex.map(job, [(w, b, 1 if RULES is RULES_STALL else (2 if RULES is RULES_CENTRAL else 0)) for w in WORK for b in range(n)]))
+        res = list(ex.map(job, [(w, b, 1 if RULES is RULES_STALL else (2 if RULES is RULES_CENTRAL else (3 if RULES is RULES_CORR else 0))) for w in WORK for b in range(n)]))
     lines = [f"interior-point iterations per QP over the oracle's PAN loop, {n} scenes per workload, every QP of every scene (tests/tools/qp_step_study.py)",
              "columns: mean / max over all QPs | mean / max over the LAST QP of a call | solves by warm code (0 cold, 1 warm used, 2 / 3 dropped at the first / a later checkpoint, 4 repeated cold, 5 cold retry) | solves that end above 1e-12, largest final merit"]
     for w in WORK:
@@ -156,7 +164,7 @@ def main():
             lines.append(f"  {label:82s} {it.mean():6.2f} /{it.max():3d} | {np.mean(last):6.2f} /{max(last):3d} | {by} | {bad}, {max(r[2] for r in rows):.1e}")
     txt = "\n".join(lines)
     print(txt)
-    with open(os.path.join(ROOT, "profiles", "r06_qp_stall_patience.txt" if RULES is RULES_STALL else ("r06_qp_centrality.txt" if RULES is RULES_CENTRAL else "r03_qp_step_study.txt")), "w") as f:
+    with open(os.path.join(ROOT, "profiles", "r06_qp_stall_patience.txt" if RULES is RULES_STALL else ("r06_qp_centrality.txt" if RULES is RULES_CENTRAL else ("r06_qp_corrector.txt" if RULES is RULES_CORR else "r03_qp_step_study.txt"))), "w") as f:
         f.write(txt + "\n")
 
 
