@@ -40,11 +40,11 @@ f=$(find /tmp/ks2 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" $
 stamp "phases of a QP solve / of a slice wave (s_memtime builds)"
 timeout 300 $py tests/tools/qp_phase_cycles.py > $out/qp_phase_cycles_raw.txt 2>&1
 grep -v "hipcc\|amdgpu.ids" $out/qp_phase_cycles_raw.txt > $out/qp_phase_cycles.txt
-timeout 300 $py tests/tools/select_phase_cycles.py > $out/select_phase_cycles.txt 2>&1
+timeout 300 $py tests/tools/select_phase_cycles.py 2>&1 | grep -v "amdgpu.ids" > $out/select_phase_cycles.txt
 stamp "other configurations, GPU only (the parity legs ride in the lines above)"
 for w in acker_2k_T20_K15 dyna_4k_T10_K10 poly8_5k_T10_K10; do timeout 200 $py bench.py --workload $w --no-cpu --no-latency --no-extras > $out/bench_$w.json 2>/dev/null; done
 stamp "64-scene x 12-member parity of the other configurations"
-timeout 900 $py tests/tools/parity_wide.py > $out/parity_wide.json 2> $out/parity_wide.log
+timeout 900 $py tests/tools/parity_wide.py 2> $out/parity_wide.log | tail -1 > $out/parity_wide.json
 stamp "done"
 python - <<P
 import json,glob
