@@ -287,6 +287,7 @@ class Loop:
         last = self.run(steps)
         t_issue = time.perf_counter() - t0          # host time to enqueue every step (the GPU is still working)
         torch.cuda.synchronize(dev)
+        t_drain = time.perf_counter() - t0          # ... until the device has finished them (and the gathers behind them)
         if barrier:
             barrier()
         torch.cuda.synchronize(dev)
@@ -305,7 +306,7 @@ class Loop:
             assert g.numel() == self.world * self.batch * 2 * self.cfg.T
         self.last_iters = np.concatenate(its) if its else None
         na = sum(q.get("aset_launches", 0) for q in profs)
-        return dict(elapsed=elapsed, t_issue=t_issue, last=last,
+        return dict(elapsed=elapsed, t_issue=t_issue, t_drain=t_drain, last=last,
                     prof={"launches": nl, "dune_ms": avg("dune_ms"), "select_ms": avg("select_ms"), "nrmp_ms": avg("nrmp_ms"),
                           "aset_launches": na,
                           "aset_ms": sum(q.get("aset_ms", 0.0) * q.get("aset_launches", 0) for q in profs) / max(na, 1)})
@@ -605,6 +606,7 @@ def compact(line, full_path):
         if k in line:
             out[k] = {kk: vv for kk, vv in line[k].items() if kk != "note"}
     out["host_issue_ms_per_step"] = line.get("host_issue_ms_per_step")
+    out["region_ms"] = line.get("region_ms")
     if "margin_audit" in line:
         out["margin_audit"] = {k: line["margin_audit"][k] for k in ("points", "violations")}
     x = line.get("extra")
@@ -753,6 +755,7 @@ def main():
     barrier = dist.barrier if dist is not None else None
     r = lp.timed(args.steps, args.warmup, barrier)
     elapsed, t_issue, prof, last = r["elapsed"], r["t_issue"], r["prof"], r["last"]
+    r["elapsed_rank"] = elapsed
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -902,6 +905,9 @@ def main():
         # host time to enqueue a step (one library call = 21 launches) next to the step's wall time: when the two are close
         # the step is bound by the host's launch rate, not by the kernels
         "host_issue_ms_per_step": round(1e3 * t_issue / args.steps, 4),
+        # rank 0's timed region in its three parts: issuing the steps, waiting for the device, the closing barrier of the contract
+        "region_ms": {"issue": round(1e3 * t_issue, 3), "drain": round(1e3 * (r["t_drain"] - t_issue), 3),
+                      "closing_barrier": round(1e3 * (r["elapsed_rank"] - r["t_drain"]), 3)},
         "margin_audit": audit,
     }
 
