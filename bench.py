@@ -56,6 +56,7 @@ import torch  # noqa: E402
 WORKLOAD = "diff_1k_T10_K10"
 BATCH = 256
 BURST_DEFAULT = 1
+CHAIN_THREADS_DEFAULT = -1  # issuing threads of a chained loop: -1 one per chain, 0 the calling thread alone (one group call per round)
 CHAINS_DEFAULT = -1        # -1: batches in flight / 5 (four chains of five steps at 20 in flight, eight at 40)
 # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table (256 CUs x 4 SIMDs, 2.4 GHz)
 PEAK_FP64_VALU_TFLOPS = 78.6
@@ -187,6 +188,7 @@ class Loop:
                            # set of 20 live streams would push the process past the ~24 hardware queues the device schedules
                            # without time-slicing)
 
+    CHAIN_THREADS = -1     # issuing threads of a chained loop (--chain-threads; see __init__)
     BURST = False          # StepLoop(burst=...): set once from the command line, every Loop of the process follows it
     CHAINS = 0             # > 0: the batches in flight form this many launch chains -- the steps of a chain share ONE stream, are
                            # issued as one group call and run every stage as one merged launch (npa_forward_batch_group)
@@ -204,7 +206,9 @@ class Loop:
         self.chains = chains = min(chains, nfl) if (chains > 0 and Loop.BURST and not graph) else 0
         user_threads = issue_threads
         if chains:
-            issue_threads = chains              # one issuing thread per chain (slot j belongs to thread j % threads)
+            # Loop.CHAIN_THREADS < 0: one issuing thread per chain (slot j belongs to thread j % threads); >= 0: that many threads
+            # (0: the calling thread issues every chain of a round in ONE breadth-first group call)
+            issue_threads = chains if Loop.CHAIN_THREADS < 0 else min(Loop.CHAIN_THREADS, chains)
         pool = Loop.STREAMS.setdefault(str(dev), [])
         while len(pool) < (chains or nfl):
             pool.append(torch.cuda.Stream(device=dev))
@@ -687,6 +691,9 @@ def main():
     ap.add_argument("--burst", type=int, default=BURST_DEFAULT,
                     help="1: the steps a host thread issues in one round of the chains go out as ONE breadth-first library call "
                          "(npa_forward_batch_group: staging of every chain, then PAN iteration 0 of every chain, ...); 0: call by call")
+    ap.add_argument("--chain-threads", type=int, default=CHAIN_THREADS_DEFAULT,
+                    help="host threads issuing the launch chains (-1: one per chain; 0: the calling thread issues all chains of a round "
+                         "in one breadth-first group call)")
     ap.add_argument("--chains", type=int, default=CHAINS_DEFAULT,
                     help="launch chains the batches in flight form: the steps of a chain share one stream and run every stage as ONE "
                          "merged launch (npa_forward_batch_group); -1 (default): batches in flight / 5; 0: one stream and one launch "
@@ -748,6 +755,7 @@ def main():
     else:
         nfl = 20 if (dist is None or args.steps <= 20) else 18
     Loop.BURST = bool(args.burst)
+    Loop.CHAIN_THREADS = args.chain_threads
     Loop.CHAINS = (max(1, nfl // 5) if args.chains < 0 else args.chains) if merged else 0
     lp = Loop(args.workload, B, nfl, dev, rank=rank, world=world, dist=None if os.environ.get("NPA_BENCH_NOGATHER") else dist,
               graph=args.graph, issue_threads=args.issue_threads)

@@ -868,6 +868,7 @@ class StepGroup:
         self.calls, self.flags, self.lib, self.device = calls, calls[0]["flags"], calls[0]["lib"], calls[0]["device"]
         self.steps, self.streams = list(steps), list(streams) if streams is not None else None
         self.arr = (NpaForwardCall * len(steps))()
+        self._subs = {}                 # ctypes arrays of member selections other than a prefix (issue_members)
         names = [f[0] for f in NpaForwardCall._fields_]
         for a, c, st in zip(self.arr, calls, streams):
             h, B, n_stride, *rest = c["args"]
@@ -893,21 +894,39 @@ class StepGroup:
         n = len(self.calls) if n is None else n
         if not 1 <= n <= len(self.calls):
             raise NeupanAmdError(f"StepGroup.issue: {n} members requested of {len(self.calls)}")
+        return self._issue(self.arr, range(n))
+
+    def issue_members(self, idx):
+        """issue() for an arbitrary selection of members, in the order given (a partial round of a serving loop whose members
+        are kept in chain-major order: neupan_amd.serve.StepLoop).  The library merges runs of consecutive members that share a
+        stream exactly as for a prefix."""
+        idx = tuple(int(i) for i in idx)
+        if not idx or any(not 0 <= i < len(self.calls) for i in idx):
+            raise NeupanAmdError(f"StepGroup.issue_members: members {idx} of {len(self.calls)}")
+        if idx == tuple(range(len(idx))):
+            return self._issue(self.arr, idx)
+        sub = self._subs.get(idx)
+        if sub is None:
+            sub = self._subs[idx] = (type(self.arr[0]) * len(idx))(*[self.arr[i] for i in idx])
+        return self._issue(sub, idx)
+
+    def _issue(self, arr, members):
+        n = len(members)
         # the group entry point's own argument checks, made here with a message (the library returns a bare NPA_E_ARG for them)
-        hs = [self.arr[i].h for i in range(n)]
+        hs = [arr[i].h for i in range(n)]
         if len(set(hs)) != n or any(not h for h in hs):
             raise NeupanAmdError("StepGroup.issue: the members of a group must be distinct live handles (one batch at a time per handle)")
-        if any(self.arr[i].iter_num < 1 for i in range(n)):
+        if any(arr[i].iter_num < 1 for i in range(n)):
             raise NeupanAmdError("StepGroup.issue: iter_num < 1")
-        for c in self.calls[:n]:
-            c["validate"]()
-        for i in range(n):
-            pre = getattr(self.steps[i], "pre_issue", None)
+        for m in members:
+            self.calls[m]["validate"]()
+        for m in members:
+            pre = getattr(self.steps[m], "pre_issue", None)
             if pre is not None:
-                with torch.cuda.stream(self.streams[i]):
+                with torch.cuda.stream(self.streams[m]):
                     pre()
         with torch.cuda.device(self.device):
-            rc = self.lib.npa_forward_batch_group(n, self.arr, self.flags)
+            rc = self.lib.npa_forward_batch_group(n, arr, self.flags)
         if rc:
             check(rc, "npa_forward_batch_group")
-        return [c["finish"]() for c in self.calls[:n]]
+        return [self.calls[m]["finish"]() for m in members]

@@ -237,9 +237,23 @@ class StepLoop:
                 from .pan import StepGroup as group_cls
             from ._lib import NeupanAmdError
             nw = max(self.threads, 1)
+            # a thread's members in CHAIN-MAJOR order (the slots of one stream next to each other, streams in order of first
+            # appearance): npa_forward_batch_group merges runs of consecutive members that share a stream, and interleaves the
+            # runs breadth-first -- so ONE call from ONE thread starts every chain of the round within its first launches
+            # (threads = 0: all chains; no hand-over of the interpreter lock between issuing threads in front of the launches)
+            self._members, self._pos = [], []
+            for w in range(nw):
+                mem = [j for j in range(self.nfl) if j % nw == w]
+                if streams is not None:
+                    first = {}
+                    for j in mem:
+                        first.setdefault(streams[j], len(first))
+                    mem.sort(key=lambda j: (first[streams[j]], j))
+                self._members.append(mem)
+                self._pos.append({j: k for k, j in enumerate(mem)})
             try:
-                self.groups = [group_cls([steps[j] for j in range(self.nfl) if j % nw == w],
-                                         [streams[j] for j in range(self.nfl) if j % nw == w] if streams is not None else None)
+                self.groups = [group_cls([steps[j] for j in self._members[w]],
+                                         [streams[j] for j in self._members[w]] if streams is not None else None)
                                for w in range(nw)]
             except NeupanAmdError as e:          # members that cannot be grouped (HIP-graph steps, mixed flags): call by call
                 self.groups, self.burst_refused = None, str(e)
@@ -270,17 +284,32 @@ class StepLoop:
         mine = [i for i in range(r0, min(n, r0 + self.nfl)) if (i % self.nfl) % nw == w]
         if not mine:
             return
-        res = self.groups[w].issue(len(mine))
-        one_stream = self.streams is not None and len({self.streams[i % self.nfl] for i in mine}) == 1
-        if self.gatherer is not None and one_stream and hasattr(self.gatherer, "stage_many"):
-            # a merged chain: its steps finish together -- their controls are staged together
-            self.gatherer.stage_many([base + i for i in mine], [o["opt_u"] for o in res], self.streams[mine[0] % self.nfl])
+        pos = self._pos[w]
+        mine.sort(key=lambda i: pos[i % self.nfl])                    # the group's (chain-major) order
+        idx = [pos[i % self.nfl] for i in mine]
+        if idx == list(range(len(idx))):
+            res = self.groups[w].issue(len(idx))
+        else:                                                         # (a partial round: not a prefix of the member list)
+            res = self.groups[w].issue_members(idx)
+        if self.gatherer is not None:
+            if self.streams is not None and hasattr(self.gatherer, "stage_many"):
+                # a merged chain's steps finish together -- their controls are staged together, one fused copy per stream
+                by = {}
+                for i, o in zip(mine, res):
+                    by.setdefault(self.streams[i % self.nfl], []).append((i, o))
+                for st, lst in by.items():
+                    lst.sort(key=lambda x: x[0])
+                    if len(lst) > 1:
+                        self.gatherer.stage_many([base + i for i, _ in lst], [o["opt_u"] for _, o in lst], st)
+                    else:
+                        self.gatherer.stage(base + lst[0][0], lst[0][1]["opt_u"], st)
+            else:
+                for i, o in sorted(zip(mine, res), key=lambda x: x[0]):
+                    if self.streams is not None:
+                        self.gatherer.stage(base + i, o["opt_u"], self.streams[i % self.nfl])
+                    else:
+                        self.gatherer.stage(base + i, o["opt_u"])
         for i, o in zip(mine, res):
-            if self.gatherer is not None and not (one_stream and hasattr(self.gatherer, "stage_many")):
-                if self.streams is not None:
-                    self.gatherer.stage(base + i, o["opt_u"], self.streams[i % self.nfl])
-                else:
-                    self.gatherer.stage(base + i, o["opt_u"])
             outs[i] = o
             if evs is not None:
                 evs[i].set()

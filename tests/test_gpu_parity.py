@@ -1215,6 +1215,59 @@ def test_breadth_first_group_issue_equals_call_by_call():
     loop.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", [0, 1, 2, 3])
+def test_chains_issued_from_one_group_call_equal_one_thread_per_chain(threads):
+    """Three launch chains (steps that share a stream) issued by 0 (the calling thread), 1, 2 or 3 threads: StepLoop keeps a
+    thread's members in chain-major order, so ONE npa_forward_batch_group call merges each chain's steps and interleaves the chains
+    breadth-first.  Whole rounds, a partial round (members selected by position: StepGroup.issue_members) and several rounds
+    in one run plan bitwise what planning every batch alone plans, and the merged path is what ran."""
+    import ctypes as C
+    import torch
+    from gpu_helpers import make_gpu_pan
+    from neupan_amd import _lib
+    from neupan_amd.serve import StepLoop
+    cfg = CONFIGS["diff_1k_T10_K10"]
+    lib = _lib.load()
+    lib.npa_dbg_group_merged_launches.restype = C.c_ulonglong
+    nfl, chains, B = 9, 3, 16
+    batches = [make_batch(cfg, 9500 + 50 * j, B) for j in range(nfl)]
+    keys = ("nom_s", "nom_u", "ref_s", "ref_us", "points")
+    ref = []
+    for bt in batches:
+        p = make_gpu_pan(cfg)
+        ref.append(p.forward_batch(*[bt[k] for k in keys])["opt_u"].cpu().numpy())
+    dev = torch.device("cuda", 0)
+    pans = [make_gpu_pan(cfg) for _ in range(nfl)]
+    pool = [torch.cuda.Stream(device=dev) for _ in range(chains)]
+    streams = [pool[j % chains] for j in range(nfl)]
+    args = [[torch.from_numpy(bt[k]).to(dev) for k in keys] for bt in batches]
+    torch.cuda.synchronize()
+    steps = []
+    for j in range(nfl):
+        with torch.cuda.stream(streams[j]):
+            steps.append(pans[j].make_step(*args[j], reset_every_step=True))
+    torch.cuda.synchronize()
+    cur = torch.cuda.current_stream(dev)
+    loop = StepLoop(steps, streams, None, cur, threads=threads, burst=True)
+    assert loop.groups is not None and len(loop.groups) == max(threads, 1)
+    try:
+        for n in (nfl, 4, 2 * nfl + 5):
+            m0 = lib.npa_dbg_group_merged_launches()
+            last = loop.run(n)
+            torch.cuda.synchronize()
+            for j in range(min(n, nfl)):
+                o, g = last[j]
+                assert np.array_equal(o["opt_u"].cpu().numpy(), ref[j]), (threads, n, j)
+                assert (o["iters"].cpu().numpy() == cfg.iter_num).all()
+            if n == nfl and threads != 2:      # three chains of three steps: 3 x K merged PAN iterations (the library counts those), whoever
+                # issued them.  (Two threads: thread 0's slots 0 2 4 6 8 leave ONE step of the second chain in its group -- a run of
+                # one cannot merge and the library then keeps that whole group call by call; the plans are the same.)
+                assert lib.npa_dbg_group_merged_launches() - m0 == chains * cfg.iter_num, (threads, n)
+    finally:
+        loop.close()
+
+
 @pytest.mark.parametrize("cfgname,B,nfl,over", [("diff_1k_T10_K10", 40, 5, {}), ("diff_1k_T10_K10", 24, 10, {"iter_threshold": 0.1}),
                                                 ("dyna_4k_T10_K10", 16, 3, {}), ("acker_2k_T20_K15", 16, 4, {}),
                                                 ("poly8_5k_T10_K10", 16, 2, {}), ("diff_1k_T10_K10", 24, 17, {})])
