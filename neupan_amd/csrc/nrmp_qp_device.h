@@ -18,6 +18,12 @@
 #define QP_STEP_ETA 0.995      // fraction of the step to the boundary, RAISED towards 1 as the gap closes: eta = max(0.995, 1 - mu),
 #define QP_STEP_CAP 1e-6       //   never above 1 - 1e-6.  The fixed 0.995 made the end game linear (x 0.005 per iteration)
 #define QP_START_MU 3.0        // cold start: multipliers = 3 / slack (every row starts on the central path of mu = 3)
+#ifndef NPA_QP_WIDE_LDS
+#define NPA_QP_WIDE_LDS 1      // T = 20: the factorisation's deferred trailing updates through LDS in chunks (nrmp_qp_body.inc, WLDS); 0: all through v_readlane
+#endif
+#ifndef QP_WLDS_CH
+#define QP_WLDS_CH 4           // ... pairs of columns per chunk
+#endif
 #ifndef QP_CHOL_LOOK
 #define QP_CHOL_LOOK 3         // columns behind the pivot whose trailing update is broadcast with v_readlane (the rest: LDS, one pivot late)
 #endif

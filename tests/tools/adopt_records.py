@@ -41,7 +41,8 @@ if __name__ == "__main__":
     print("cpu baseline ", full["cpu_baseline"]["value"], full["cpu_baseline"]["cores"], "parity A/C", full["parity"]["A_well_posed_all_le_tol"], full["parity"]["C_le_1e-5_until_ensemble_diverges"],
           "frac_le_1e-4", full["parity"]["frac_le_1e-4"])
     for k, v in e["other_configs"].items():
-        print("  ", k, v["plans_per_s"], v["parity"].get("A_well_posed_all_le_tol"), v["parity"].get("C_le_1e-5_until_ensemble_diverges"))
+        if isinstance(v, dict) and "plans_per_s" in v:
+            print("  ", k, v["plans_per_s"], v["parity"].get("A_well_posed_all_le_tol"), v["parity"].get("C_le_1e-5_until_ensemble_diverges"))
     for w in ("acker_2k_T20_K15", "dyna_4k_T10_K10", "poly8_5k_T10_K10"):
         print("   GPU only", w, line(os.path.join(SRC, f"bench_{w}.json"))["value"])
     print(open(os.path.join(SRC, "gpu_tests.txt")).read().strip().split("\n")[-2:], open(os.path.join(SRC, "smoke.log")).read().strip().split("\n")[-2:])
