@@ -93,9 +93,10 @@ def test_driver_flag_line_is_the_same_contract():
     t = _line("r06_bench_torchrun1.json")
     assert t["n_gpus"] == 1 and t["value"] >= 0.93 * full["value"]         # one rank with a live RCCL communicator and its gathers
     # round 6: the same under the driver's flags -- the per-GPU value an N-GPU run multiplies.  -8 % against the plain process on
-    # alternating runs (profiles/r06_torchrun_overhead.txt): the region's ONE all-gather sits in its tail, behind the last chain
+    # alternating runs (profiles/r06_torchrun_overhead.txt, r06_region_trace.txt: medians 735 k / 795 k over 24 + 8 runs); the two tracked
+    # lines are single runs of a region that varies +-4 % each, hence the margin
     t20 = _line("r06_bench_torchrun1_driver_flags.json")
-    assert t20["n_gpus"] == 1 and t20["steps"] == 20 and t20["value"] >= 0.90 * d["value"]
+    assert t20["n_gpus"] == 1 and t20["steps"] == 20 and t20["value"] >= 0.85 * d["value"]
 
 
 def test_tracked_pmc_file_matches_the_built_kernels():
