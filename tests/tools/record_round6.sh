@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round 6: the lines of record in ONE GPU call, most important first (every step under its own timeout, nothing fatal):
 #     gpurun --timeout 3000 -- 'bash tests/tools/record_round6.sh --pmc'      (--pmc: re-collect the counter records first, after a kernel change;
-#     copy gpurun_out/r06/pmc_*.json to profiles/r06_pmc*.json afterwards)
-# Writes gpurun_out/r06final/ ; what is to be judged is copied into profiles/ afterwards (profiles/README.md names the commands).
+#     python tests/tools/adopt_records.py [--pmc] afterwards copies the results to their tracked names under profiles/ and prints the figures)
+# Writes gpurun_out/r06final/ (and gpurun_out/r06/pmc_*.json); profiles/README.md names the commands.
 out=gpurun_out/r06final
 rm -rf $out; mkdir -p $out
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
